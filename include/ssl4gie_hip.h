@@ -1,0 +1,195 @@
+/* libssl4gie_hip.so — C ABI of the MI355X (gfx950) compute path for the SSL4GIE hot path.
+ *
+ * The reference (ESandML/SSL4GIE) is pure Python/PyTorch and has no native boundary of its own:
+ * its hot path is the ATen ops reached from timm `Block`/`PatchEmbed` (un-vendored) and
+ * `Models/mae/models_mae.py`, `Models/models.py`.  Every entry point below names the reference
+ * call site(s) whose arithmetic it replaces.  Conventions:
+ *   - plain C types only; device pointers + explicit sizes/strides + a HIP stream (`void*`);
+ *   - nothing is allocated, freed or synchronised inside; workspaces are caller-allocated and
+ *     sized by the matching `*_workspace_bytes()` query;
+ *   - returns 0 on success, SSL4GIE_EARG (1000) for an invalid argument, otherwise a hipError_t;
+ *   - re-entrant (no mutable globals), callable from any host thread;
+ *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
+ *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
+ */
+#ifndef SSL4GIE_HIP_H
+#define SSL4GIE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSL4GIE_F32 0
+#define SSL4GIE_BF16 1
+#define SSL4GIE_EARG 1000
+
+int ssl4gie_abi_version(void);
+
+/* ---------------------------------------------------------------- LayerNorm (eps=1e-6)
+ * replaces nn.LayerNorm at models_mae.py:227 / models.py:384,498 inside timm Block
+ * (norm1/norm2) and the final `norm` (models_mae.py:168).  x fp32 [rows, cols]; y in
+ * y_dtype; mean/rstd fp32 [rows] saved for backward (may be NULL). */
+int ssl4gie_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y,
+                          int y_dtype, float* mean, float* rstd, int rows, int cols, float eps,
+                          void* stream);
+size_t ssl4gie_layernorm_bwd_workspace_bytes(int rows, int cols);
+/* dx = (dres ? dres : 0) + LN'(dy); dx_lp (optional) is the same value in lp_dtype (feeds the
+ * next backward GEMM); dgamma/dbeta overwritten or accumulated. */
+int ssl4gie_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                          const float* mean, const float* rstd, const float* dres, float* dx,
+                          void* dx_lp, int lp_dtype, float* dgamma, float* dbeta, int accumulate,
+                          float* workspace, int rows, int cols, void* stream);
+
+/* column sums of x[rows, cols] (row stride ld) -> out[cols]: bias gradients of nn.Linear */
+size_t ssl4gie_colsum_workspace_bytes(int rows, int cols);
+int ssl4gie_colsum(const void* x, int dtype, float* out, int accumulate, float* workspace,
+                   int rows, int cols, long long ld, void* stream);
+
+/* ---------------------------------------------------------------- GEMM with fused epilogues
+ * replaces nn.Linear fwd/bwd (timm Attention.qkv/proj, Mlp.fc1/fc2; decoder_embed/decoder_pred
+ * models_mae.py:47,59), the patch-embed conv lowered to a GEMM (models_mae.py:33), and the
+ * batched QK^T / PV products of the fp32 parity attention.
+ *   C[b](m,n) = epilogue( alpha * sum_k A[b](m,k) * B[b](k,n) )
+ * A(m,k) at A + b1*sAb1 + b2*sAb2 + m*sAm + k*sAk (element strides), likewise B(k,n);
+ * C row-major with row stride ldc.  Fast MFMA-bf16 paths: "NT" (sAk==1 && sBk==1, K%64==0)
+ * and "TN" (sAm==1 && sBn==1, split-K through the workspace); anything else takes the generic
+ * f32-MFMA kernel. */
+enum {
+    SSL4GIE_EPI_NONE = 0,          /* C = alpha*acc                       */
+    SSL4GIE_EPI_BIAS = 1,          /* C = acc + bias[n]                   */
+    SSL4GIE_EPI_BIAS_GELU = 2,     /* C = u = acc + bias[n]; out2 = gelu(u) (exact erf) */
+    SSL4GIE_EPI_BIAS_RESIDUAL = 3, /* C = acc + bias[n] + residual[m,n] (fp32 residual) */
+    SSL4GIE_EPI_DGELU = 4          /* C = acc * gelu'(aux[m,n])           */
+};
+typedef struct ssl4gie_gemm_desc {
+    int M, N, K;
+    int batch1, batch2; /* >=1 */
+    const void* A;
+    long long sAm, sAk, sAb1, sAb2;
+    const void* B;
+    long long sBk, sBn, sBb1, sBb2;
+    void* C;
+    long long ldc, sCb1, sCb2;
+    int dtype_ab; /* SSL4GIE_F32 | SSL4GIE_BF16 */
+    int dtype_c;  /* type of C, out2 and aux */
+    float alpha;
+    int epilogue;
+    const float* bias;     /* [N] */
+    const float* residual; /* fp32 [M, N], row stride ldr */
+    long long ldr;
+    const void* aux; /* [M, N] row stride ldc, dtype_c */
+    void* out2;      /* [M, N] row stride ldc, dtype_c */
+    int accumulate;  /* C += (EPI_NONE only) */
+} ssl4gie_gemm_desc;
+size_t ssl4gie_gemm_workspace_bytes(const ssl4gie_gemm_desc* d);
+int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
+/* ---------------------------------------------------------------- attention
+ * replaces timm Attention.forward == Models/models.py:195-209 minus windowing:
+ * softmax(q k^T * hd^-1/2) v on the packed qkv activation [B, N, 3, H, hd] (row = token).
+ * out [B, N, H*hd]; lse fp32 [B, H, N] (saved for backward).  bf16 path is one fused kernel
+ * (whole K/V of a head staged in LDS, softmax in registers, no N x N materialisation); the
+ * f32 parity path materialises scores in the caller-provided workspace. */
+size_t ssl4gie_attn_workspace_bytes(int dtype, int B, int N, int H, int hd);
+int ssl4gie_attn_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int N, int H,
+                     int hd, void* workspace, void* stream);
+int ssl4gie_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                     void* dqkv, int dtype, int B, int N, int H, int hd, void* workspace,
+                     void* stream);
+
+/* ---------------------------------------------------------------- casts
+ * fp32 master weights -> MFMA operand copies (bf16), plain and transposed ([R,C] -> [C,R]). */
+int ssl4gie_cast(const float* src, void* dst, int dst_dtype, long long n, void* stream);
+int ssl4gie_cast_transpose(const float* src, void* dst, int dst_dtype, int rows, int cols,
+                           void* stream);
+
+/* ---------------------------------------------------------------- MAE glue
+ * random_masking (models_mae.py:123-148): stable argsort of fp32 noise [B, L] ->
+ * ids_shuffle / ids_restore (int64, bit-exact) and mask (fp32; 1 = removed). */
+int ssl4gie_mask_argsort(const float* noise, long long* ids_shuffle, long long* ids_restore,
+                         float* mask, int B, int L, int len_keep, void* stream);
+/* im2col of non-overlapping p x p patches (PatchEmbed conv k=s=p as a GEMM, models_mae.py:152):
+ * out[b*nsel + j, c*p*p + py*p + px] = img[b, c, gy*p+py, gx*p+px], patch = ids ? ids[b, j] : j.
+ * order==1 emits the 'nhwpqc' layout of patchify (models_mae.py:95-107) instead. */
+int ssl4gie_patch_gather(const float* img, const long long* ids, void* out, int out_dtype,
+                         int B, int C, int H, int W, int p, int nsel, long long ids_stride,
+                         int order, void* stream);
+/* encoder input assembly (models_mae.py:155-163 / models.py:445-448):
+ * x[b,0,:] = cls + pos[0]; x[b,1+j,:] = y[b*nsel+j,:] + pos[1 + (ids ? ids[b,j] : j)] */
+int ssl4gie_tokens_assemble(const void* y, int y_dtype, const float* cls, const float* pos,
+                            const long long* ids, long long ids_stride, float* x, int B,
+                            int nsel, int D, void* stream);
+/* backward of the above: dy[b*nsel+j] = dx[b,1+j]; dcls = sum_b dx[b,0] */
+int ssl4gie_tokens_assemble_bwd(const float* dx, void* dy, int dy_dtype, float* dcls,
+                                int accumulate, int B, int nsel, int D, void* stream);
+/* decoder input assembly (models_mae.py:177-183): xd[b,0] = y[b,0] + dpos[0];
+ * xd[b,1+i] = (r = ids_restore[b,i]) < nkeep ? y[b,1+r] : mask_token, + dpos[1+i] */
+int ssl4gie_decoder_assemble(const void* y, int y_dtype, const float* mask_token,
+                             const float* dpos, const long long* ids_restore, float* xd, int B,
+                             int L, int nkeep, int D, void* stream);
+size_t ssl4gie_decoder_assemble_bwd_workspace_bytes(int B, int L, int D);
+/* dy[b,0] = dxd[b,0]; dy[b,1+j] = dxd[b, 1+ids_shuffle[b,j]] (j<nkeep);
+ * dmask_token = sum over removed positions of dxd */
+int ssl4gie_decoder_assemble_bwd(const float* dxd, const long long* ids_shuffle, void* dy,
+                                 int dy_dtype, float* dmask_token, int accumulate,
+                                 float* workspace, int B, int L, int nkeep, int D, void* stream);
+/* forward_loss (models_mae.py:198-214) and its gradient.  pred fp32 [B, 1+L, P] (row 0 of each
+ * sample = cls, ignored), img fp32 NCHW, mask [B, L] (1 = removed).
+ *   per_patch (optional) [B, L] = mask * mean_k (pred - target)^2   (host sums / mask.sum())
+ *   dpred (optional) [B, 1+L, P] = gscale_host * gscale_dev[0] * mask * 2 (pred-target) / P,
+ *   cls rows zeroed; gscale_dev may be NULL (=1): the upstream scalar gradient on device. */
+int ssl4gie_mae_loss(const float* pred, const float* img, const float* mask, float* per_patch,
+                     float* dpred, const float* gscale_dev, float gscale_host, int norm_pix,
+                     int B, int C, int H, int W, int p, void* stream);
+
+/* ---------------------------------------------------------------- transformer-block executor
+ * One timm Block: x += proj(attn(norm1(x))); x += fc2(gelu(fc1(norm2(x)))).
+ * Residual stream fp32; MFMA operands in `dtype`.  `w*` are operand-type copies of the weights
+ * ([out,in] row-major) and `w*_t` their transposes ([in,out]) used by the data-gradient GEMMs.
+ * Saved activations live in caller-owned buffers (`ssl4gie_block_act`). */
+typedef struct ssl4gie_block_weights {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const float *bqkv, *bproj, *bfc1, *bfc2;
+    const void *wqkv, *wproj, *wfc1, *wfc2;         /* [3D,D] [D,D] [F,D] [D,F] */
+    const void *wqkv_t, *wproj_t, *wfc1_t, *wfc2_t; /* transposes (backward only) */
+} ssl4gie_block_weights;
+typedef struct ssl4gie_block_grads { /* fp32, same shapes as the fp32 master parameters */
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float *bqkv, *bproj, *bfc1, *bfc2;
+    float *wqkv, *wproj, *wfc1, *wfc2;
+} ssl4gie_block_grads;
+typedef struct ssl4gie_block_act { /* per-block saved activations; T = tokens = B*N */
+    float *mean1, *rstd1, *mean2, *rstd2; /* [T] */
+    void* h1;                             /* [T, D]  norm1 out     */
+    void* qkv;                            /* [T, 3D]               */
+    void* attn;                           /* [T, D]  attention out */
+    float* lse;                           /* [B, H, N]             */
+    float* xmid;                          /* [T, D]  fp32          */
+    void* h2;                             /* [T, D]  norm2 out     */
+    void* u;                              /* [T, F]  fc1 pre-act   */
+    void* g;                              /* [T, F]  gelu(u)       */
+} ssl4gie_block_act;
+typedef struct ssl4gie_block_dims {
+    int B, N, D, H, F; /* F = mlp hidden */
+    int dtype;
+    float eps;
+} ssl4gie_block_dims;
+size_t ssl4gie_block_workspace_bytes(const ssl4gie_block_dims* d);
+/* x_in fp32 [T, D] -> x_out fp32 [T, D] (may alias nothing) */
+int ssl4gie_block_fwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* w,
+                      const ssl4gie_block_act* a, const float* x_in, float* x_out,
+                      void* workspace, void* stream);
+/* dx_out fp32 (+ dx_out_lp, its operand-type copy; may be NULL in f32 mode) -> dx_in fp32 and
+ * dx_in_lp; parameter grads overwritten (accumulate=0) or accumulated. */
+int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* w,
+                      const ssl4gie_block_act* a, const ssl4gie_block_grads* g,
+                      const float* x_in, const float* dx_out, const void* dx_out_lp,
+                      float* dx_in, void* dx_in_lp, int accumulate, void* workspace,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

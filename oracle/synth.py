@@ -1,0 +1,110 @@
+"""Deterministic synthetic weights / inputs shared by the golden generator and the tests.
+
+TEST INFRASTRUCTURE.  Weights are a pure function of (key name, shape, seed) so that the
+112 M-parameter ViT-B state_dict never has to be stored in a fixture: the generator
+(`tests/golden/make_golden.py`) loads them into the *reference* classes, the tests load the
+same tensors into the build's classes, and the fixture stores a checksum of them.
+"""
+from __future__ import annotations
+
+import hashlib
+import zlib
+
+import numpy as np
+import torch
+
+from .mae_ref import MAEConfig, sincos_2d
+
+
+def _gen(key: str, seed: int) -> torch.Generator:
+    h = zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1 & 0xFFFFFFFF)
+    return torch.Generator("cpu").manual_seed(int(h))
+
+
+def _block_shapes(d: int, hidden: int):
+    return {
+        "norm1.weight": (d,), "norm1.bias": (d,),
+        "attn.qkv.weight": (3 * d, d), "attn.qkv.bias": (3 * d,),
+        "attn.proj.weight": (d, d), "attn.proj.bias": (d,),
+        "norm2.weight": (d,), "norm2.bias": (d,),
+        "mlp.fc1.weight": (hidden, d), "mlp.fc1.bias": (hidden,),
+        "mlp.fc2.weight": (d, hidden), "mlp.fc2.bias": (d,),
+    }
+
+
+def mae_shapes(cfg: MAEConfig) -> dict:
+    """state_dict schema of the reference MaskedAutoencoderViT (254 tensors for
+    ViT-B)."""
+    d, dd, p, l = cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_size, cfg.num_patches
+    s = {"cls_token": (1, 1, d), "pos_embed": (1, l + 1, d),
+         "patch_embed.proj.weight": (d, cfg.in_chans, p, p), "patch_embed.proj.bias": (d,)}
+    for i in range(cfg.depth):
+        for k, v in _block_shapes(d, int(d * cfg.mlp_ratio)).items():
+            s[f"blocks.{i}.{k}"] = v
+    s["norm.weight"] = (d,)
+    s["norm.bias"] = (d,)
+    s["decoder_embed.weight"] = (dd, d)
+    s["decoder_embed.bias"] = (dd,)
+    s["mask_token"] = (1, 1, dd)
+    s["decoder_pos_embed"] = (1, l + 1, dd)
+    for i in range(cfg.decoder_depth):
+        for k, v in _block_shapes(dd, int(dd * cfg.mlp_ratio)).items():
+            s[f"decoder_blocks.{i}.{k}"] = v
+    s["decoder_norm.weight"] = (dd,)
+    s["decoder_norm.bias"] = (dd,)
+    s["decoder_pred.weight"] = (p * p * cfg.in_chans, dd)
+    s["decoder_pred.bias"] = (p * p * cfg.in_chans,)
+    return s
+
+
+def synth_tensor(key: str, shape, seed: int) -> torch.Tensor:
+    g = _gen(key, seed)
+    if key.endswith("pos_embed"):
+        raise ValueError("pos_embed tables are not random")
+    if "norm" in key and key.endswith(".weight"):
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if key.endswith(".bias"):
+        return 0.02 * torch.randn(shape, generator=g)
+    if key in ("cls_token", "mask_token"):
+        return 0.02 * torch.randn(shape, generator=g)
+    fan_out = shape[0]
+    fan_in = int(np.prod(shape[1:]))
+    std = (2.0 / (fan_in + fan_out)) ** 0.5
+    return std * torch.randn(shape, generator=g)
+
+
+def mae_state_dict(cfg: MAEConfig, seed: int = 0) -> dict:
+    sd = {}
+    for k, shp in mae_shapes(cfg).items():
+        if k == "pos_embed":
+            sd[k] = torch.from_numpy(sincos_2d(cfg.embed_dim, cfg.grid)).float()[None]
+        elif k == "decoder_pos_embed":
+            sd[k] = torch.from_numpy(sincos_2d(cfg.decoder_embed_dim, cfg.grid)).float()[None]
+        else:
+            sd[k] = synth_tensor(k, shp, seed)
+    return sd
+
+
+def state_dict_digest(sd: dict) -> str:
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def synth_images(b: int, cfg: MAEConfig, seed: int = 0) -> torch.Tensor:
+    """N(0,1) images ~ post-Normalize statistics."""
+    g = torch.Generator("cpu").manual_seed(1000 + seed)
+    return torch.randn(b, cfg.in_chans, cfg.img_size, cfg.img_size, generator=g)
+
+
+def synth_noise(b: int, l: int, seed: int = 0) -> np.ndarray:
+    """Masking noise in [0,1) from the host generator with tied rows redrawn, so that the
+    reference's non-stable argsort and the stable rule agree."""
+    g = torch.Generator("cpu").manual_seed(2000 + seed)
+    noise = torch.rand(b, l, generator=g).numpy()
+    for r in range(b):
+        while len(np.unique(noise[r])) != l:
+            noise[r] = torch.rand(l, generator=g).numpy()
+    return noise

@@ -1,0 +1,493 @@
+// Fused multi-head attention forward / backward for short sequences (N <= 256) on gfx950.
+//
+// Replaces timm Attention.forward (un-vendored) == Models/models.py:195-209 minus the window
+// permutation:  softmax(q k^T * hd^-1/2) v  on the packed activation qkv[B, N, 3, H, hd].
+//
+// bf16 path — one workgroup (4 waves) per (batch, head); the whole K and V of the head are
+// staged once into LDS (N=197, hd=64: 2 x 28 KiB -> 2 workgroups per CU), no N x N score
+// matrix ever reaches HBM:
+//   * scores are computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_16x16x32_bf16), so that a lane owns
+//     one query column: the softmax max/sum are in-register reductions + 2 cross-lane shuffles;
+//   * the fp32 S^T accumulators, converted to bf16, ARE the B operand of O^T = V^T P^T (the k-slot
+//     permutation that implies is applied to the V fragment, which is read out of LDS with the
+//     hardware-transposing ds_read_b64_tr_b16) — P never touches LDS;
+//   * one XOR-swizzled LDS image serves both row reads (ds_read_b128) and transposed reads
+//     (conflict-free for both, verified with tools/lds_bank_sim.py).
+// Backward recomputes P from the saved log-sum-exp in two phases inside one launch: phase A
+// (waves own query tiles; LDS = K, V) produces dQ; phase B (waves own key tiles; LDS = Q, dO)
+// produces dK and dV — so no gradient is ever summed across workgroups (no atomics).
+//
+// f32 parity path — scores materialised in a caller workspace and driven through the generic
+// strided-batched f32-MFMA GEMM + row softmax kernels below (exact fp32).
+#include "common.h"
+#include "ssl4gie_hip.h"
+
+#include <math.h>
+#include <string.h>
+
+// ------------------------------------------------------------------ LDS image helpers
+template <int HD> DEVI int kv_swz(int row) { return HD == 64 ? (row & 6) : ((row >> 1) & 2); }
+template <int HD> DEVI int img_off(int row, int chunk) {
+    return row * (HD * 2) + ((chunk ^ kv_swz<HD>(row)) << 4);
+}
+
+// stage a [n, HD] bf16 slice (row stride rs elements) into an image of npad rows (zero padded)
+template <int HD>
+DEVI void stage_rows(char* img, const bf16_t* src, long long rs, int n, int npad, int tid) {
+    constexpr int CPR = HD / 8;
+    for (int idx = tid; idx < npad * CPR; idx += 256) {
+        const int row = idx / CPR, c = idx % CPR;
+        u32x4 v = {0, 0, 0, 0};
+        if (row < n) v = *(const u32x4*)(src + (size_t)row * rs + c * 8);
+        *(u32x4*)(img + img_off<HD>(row, c)) = v;
+    }
+}
+// MFMA operand, 16 rows x 32 k: lane l -> row row0 + (l&15), elements k = ks*32 + 8*(l>>4) .. +7
+template <int HD> DEVI bf16x8 row_frag(const char* img, int row0, int ks, int lane) {
+    return *(const bf16x8*)(img + img_off<HD>(row0 + (lane & 15), ks * 4 + (lane >> 4)));
+}
+DEVI bf16x8 row_frag_global(const bf16_t* base, long long rs, int row, int ks, int lane) {
+    return *(const bf16x8*)(base + (size_t)row * rs + ks * 32 + 8 * (lane >> 4));
+}
+// transposed MFMA operand over a 32-row block: lane (g = l>>4, i = l&15) receives
+//   element jj: img[row0 + 16*(jj>>2) + 4g + (jj&3)][x0 + i]
+// i.e. exactly the k-slot order in which two adjacent 16x16 f32 accumulator tiles, packed to
+// bf16, present their rows (see pack8 below).
+template <int HD> DEVI bf16x8 tr_frag(const char* img, int row0, int x0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int r0 = row0 + 4 * g + q, r1 = r0 + 16;
+    const int c = (x0 >> 3) + (p >> 1);
+    typedef __attribute__((address_space(3))) s16x4* lp_t;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(img + img_off<HD>(r0, c) + ((p & 1) << 3)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(img + img_off<HD>(r1, c) + ((p & 1) << 3)));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+DEVI bf16x8 pack8(f32x4 a, f32x4 b) {
+    bf16x8 v;
+    v[0] = (__bf16)a[0]; v[1] = (__bf16)a[1]; v[2] = (__bf16)a[2]; v[3] = (__bf16)a[3];
+    v[4] = (__bf16)b[0]; v[5] = (__bf16)b[1]; v[6] = (__bf16)b[2]; v[7] = (__bf16)b[3];
+    return v;
+}
+DEVI float group_max(float v) {  // across the 4 lane groups (lanes l, l^16, l^32, l^48)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+DEVI float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------ forward
+template <int HD, int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv,
+                                                            bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, int N, int H,
+                                                            float scale) {
+    constexpr int NPAD = NKT * 16, RB = HD * 2, KS = HD / 32, DT = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kimg = smem;
+    char* Vimg = smem + NPAD * RB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * HD;
+    const long long rs = 3LL * D;
+    const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
+    stage_rows<HD>(Kimg, qb + D, rs, N, NPAD, tid);
+    stage_rows<HD>(Vimg, qb + 2 * D, rs, N, NPAD, tid);
+    __syncthreads();
+    const float c = scale * 1.44269504088896340736f;
+    const int nqt = (N + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + (lane & 15);
+        const int qrow = q < N ? q : N - 1;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(qb, rs, qrow, ks, lane);
+        f32x4 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            s[kt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                s[kt] = MFMA16(row_frag<HD>(Kimg, kt * 16, ks, lane), qf[ks], s[kt]);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kt * 16 + 4 * g + r >= N) s[kt][r] = -INFINITY;
+                mx = fmaxf(mx, s[kt][r]);
+            }
+        mx = group_max(mx);
+        const float mc = mx * c;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kt][r] * c - mc);
+                s[kt][r] = p;
+                sum += p;
+            }
+        sum = group_sum(sum);
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kp = 0; kp < NKT / 2; ++kp) {
+            const bf16x8 pf = pack8(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt] = MFMA16(tr_frag<HD>(Vimg, kp * 32, dt * 16, lane), pf, o[dt]);
+        }
+        const float inv = 1.0f / sum;
+        if (q < N) {
+            bf16_t* orow = out + ((size_t)b * N + q) * D + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) st4(orow + dt * 16, o[dt] * inv);
+            if (g == 0) lse[((size_t)b * H + h) * N + q] = mx * scale + __logf(sum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward
+template <int HD, int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+    int N, int H, float scale) {
+    constexpr int NPAD = NKT * 16, RB = HD * 2, KS = HD / 32, DT = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* img0 = smem;
+    char* img1 = smem + NPAD * RB;
+    float* lse_s = (float*)(smem + 2 * NPAD * RB);
+    float* del_s = lse_s + NPAD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * HD;
+    const long long rs = 3LL * D;
+    const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
+    const bf16_t* ob = out + (size_t)b * N * D + h * HD;
+    const bf16_t* dob = dout + (size_t)b * N * D + h * HD;
+    bf16_t* dqb = dqkv + (size_t)b * N * rs + h * HD;
+    const float* lrow = lse + ((size_t)b * H + h) * N;
+    const float LOG2E = 1.44269504088896340736f;
+    const float c = scale * LOG2E;
+
+    // ---------------- phase A: dQ (waves own query tiles); LDS = K, V
+    stage_rows<HD>(img0, qb + D, rs, N, NPAD, tid);
+    stage_rows<HD>(img1, qb + 2 * D, rs, N, NPAD, tid);
+    for (int i = tid; i < NPAD; i += 256) {
+        lse_s[i] = i < N ? lrow[i] : 0.f;
+        del_s[i] = 0.f;
+    }
+    __syncthreads();
+    const int nqt = (N + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + (lane & 15);
+        const int qrow = q < N ? q : N - 1;
+        bf16x8 qf[KS], dof[KS];
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = row_frag_global(qb, rs, qrow, ks, lane);
+            dof[ks] = row_frag_global(dob, D, qrow, ks, lane);
+            const bf16x8 of = row_frag_global(ob, D, qrow, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
+        }
+        dl = group_sum(dl);  // delta_q = sum_d dO[q,d] O[q,d]
+        if (g == 0 && q < N) del_s[q] = dl;
+        const float l2 = lse_s[qrow] * LOG2E;
+        f32x4 s[NKT], dp[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            s[kt] = f32x4{0, 0, 0, 0};
+            dp[kt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s[kt] = MFMA16(row_frag<HD>(img0, kt * 16, ks, lane), qf[ks], s[kt]);
+                dp[kt] = MFMA16(row_frag<HD>(img1, kt * 16, ks, lane), dof[ks], dp[kt]);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = (kt * 16 + 4 * g + r < N)
+                                    ? __builtin_amdgcn_exp2f(s[kt][r] * c - l2) : 0.f;
+                s[kt][r] = p * (dp[kt][r] - dl);  // dS^T
+            }
+        f32x4 dq[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kp = 0; kp < NKT / 2; ++kp) {
+            const bf16x8 dsf = pack8(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                dq[dt] = MFMA16(tr_frag<HD>(img0, kp * 32, dt * 16, lane), dsf, dq[dt]);
+        }
+        if (q < N) {
+            bf16_t* r = dqb + (size_t)q * rs + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) st4(r + dt * 16, dq[dt] * scale);
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase B: dK, dV (waves own key tiles); LDS = Q, dO
+    stage_rows<HD>(img0, qb, rs, N, NPAD, tid);
+    stage_rows<HD>(img1, dob, D, N, NPAD, tid);
+    __syncthreads();
+    for (int kt = wave; kt < nqt; kt += 4) {
+        const int key = kt * 16 + (lane & 15);
+        const int krow = key < N ? key : N - 1;
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = row_frag_global(qb + D, rs, krow, ks, lane);
+            vf[ks] = row_frag_global(qb + 2 * D, rs, krow, ks, lane);
+        }
+        f32x4 dk[DT], dv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            dk[dt] = f32x4{0, 0, 0, 0};
+            dv[dt] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll 2
+        for (int qp = 0; qp < NKT / 2; ++qp) {
+            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = MFMA16(row_frag<HD>(img0, qp * 32, ks, lane), kf[ks], s0);
+                s1 = MFMA16(row_frag<HD>(img0, qp * 32 + 16, ks, lane), kf[ks], s1);
+                p0 = MFMA16(row_frag<HD>(img1, qp * 32, ks, lane), vf[ks], p0);
+                p1 = MFMA16(row_frag<HD>(img1, qp * 32 + 16, ks, lane), vf[ks], p1);
+            }
+            // lane holds S[q = qp*32 (+16) + 4g + r][key]; p0/p1 hold dP
+            const int qa = qp * 32 + 4 * g;
+            const f32x4 la = *(const f32x4*)(lse_s + qa), lb = *(const f32x4*)(lse_s + qa + 16);
+            const f32x4 da = *(const f32x4*)(del_s + qa), db = *(const f32x4*)(del_s + qa + 16);
+            f32x4 pa, pb, dsa, dsb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pa[r] = (qa + r < N) ? __builtin_amdgcn_exp2f(s0[r] * c - la[r] * LOG2E) : 0.f;
+                pb[r] = (qa + 16 + r < N) ? __builtin_amdgcn_exp2f(s1[r] * c - lb[r] * LOG2E) : 0.f;
+                dsa[r] = pa[r] * (p0[r] - da[r]);
+                dsb[r] = pb[r] * (p1[r] - db[r]);
+            }
+            const bf16x8 pf = pack8(pa, pb), dsf = pack8(dsa, dsb);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = MFMA16(tr_frag<HD>(img1, qp * 32, dt * 16, lane), pf, dv[dt]);
+                dk[dt] = MFMA16(tr_frag<HD>(img0, qp * 32, dt * 16, lane), dsf, dk[dt]);
+            }
+        }
+        if (key < N) {
+            bf16_t* r = dqb + (size_t)key * rs + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                st4(r + D + dt * 16, dk[dt] * scale);
+                st4(r + 2 * D + dt * 16, dv[dt]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ f32 row kernels
+// one wave per row; rows of `cols` floats (cols <= a few thousand)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s,
+                                                           float* __restrict__ lse,
+                                                           long long rows, int cols) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* p = s + row * cols;
+    float mx = -INFINITY;
+    for (int i = lane; i < cols; i += 64) mx = fmaxf(mx, p[i]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < cols; i += 64) {
+        const float e = expf(p[i] - mx);
+        p[i] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int i = lane; i < cols; i += 64) p[i] *= inv;
+    if (lse && lane == 0) lse[row] = mx + logf(sum);
+}
+__global__ __launch_bounds__(256) void exp_rows_kernel(float* __restrict__ s,
+                                                       const float* __restrict__ lse,
+                                                       long long rows, int cols) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* p = s + row * cols;
+    const float l = lse[row];
+    for (int i = lane; i < cols; i += 64) p[i] = expf(p[i] - l);
+}
+// dP <- P * (dP - sum(P*dP))
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ p,
+                                                               float* __restrict__ dp,
+                                                               long long rows, int cols) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* pr = p + row * cols;
+    float* dr = dp + row * cols;
+    float d = 0.f;
+    for (int i = lane; i < cols; i += 64) d += pr[i] * dr[i];
+    d = wave_sum(d);
+    for (int i = lane; i < cols; i += 64) dr[i] = pr[i] * (dr[i] - d);
+}
+
+// ------------------------------------------------------------------ host side
+static ssl4gie_gemm_desc bdesc(int M, int N, int K, int B, int H) {
+    ssl4gie_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.N = N; d.K = K; d.batch1 = B; d.batch2 = H;
+    d.dtype_ab = SSL4GIE_F32; d.dtype_c = SSL4GIE_F32; d.alpha = 1.f;
+    d.epilogue = SSL4GIE_EPI_NONE;
+    return d;
+}
+
+extern "C" size_t ssl4gie_attn_workspace_bytes(int dtype, int B, int N, int H, int hd) {
+    (void)hd;
+    if (dtype == SSL4GIE_BF16) return 0;
+    return (size_t)2 * B * H * N * N * sizeof(float);  // scores + dscores
+}
+
+template <int HD, int NKT>
+static int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale,
+                      hipStream_t st) {
+    const size_t lds = (size_t)2 * NKT * 16 * HD * 2;
+    auto k = attn_fwd_bf16_kernel<HD, NKT>;
+    if (lds > 65536)
+        HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse,
+                       N, H, scale);
+    LAUNCH_CHECK();
+    return 0;
+}
+template <int HD, int NKT>
+static int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                      void* dqkv, int B, int N, int H, float scale, hipStream_t st) {
+    const size_t lds = (size_t)2 * NKT * 16 * HD * 2 + 2 * NKT * 16 * sizeof(float);
+    auto k = attn_bwd_bf16_kernel<HD, NKT>;
+    if (lds > 65536)
+        HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ssl4gie_attn_fwd(const void* qkv, void* out, float* lse, int dtype, int B, int N,
+                                int H, int hd, void* workspace, void* stream) {
+    REQUIRE(qkv && out && lse && B > 0 && N > 0 && H > 0 && hd > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int D = H * hd;
+    if (dtype == SSL4GIE_BF16) {
+        REQUIRE(hd == 32 || hd == 64);
+        REQUIRE(N <= 256);
+#define FWD(HD_)                                                                      \
+    if (N <= 64) return launch_fwd<HD_, 4>(qkv, out, lse, B, N, H, scale, st);        \
+    if (N <= 224) return launch_fwd<HD_, 14>(qkv, out, lse, B, N, H, scale, st);      \
+    return launch_fwd<HD_, 16>(qkv, out, lse, B, N, H, scale, st);
+        if (hd == 64) { FWD(64) } else { FWD(32) }
+#undef FWD
+    }
+    REQUIRE(dtype == SSL4GIE_F32 && workspace);
+    float* S = (float*)workspace;
+    const float* q = (const float*)qkv;
+    // S = scale * Q K^T
+    ssl4gie_gemm_desc d = bdesc(N, N, hd, B, H);
+    d.A = q; d.sAm = 3LL * D; d.sAk = 1; d.sAb1 = (long long)N * 3 * D; d.sAb2 = hd;
+    d.B = q + D; d.sBk = 1; d.sBn = 3LL * D; d.sBb1 = (long long)N * 3 * D; d.sBb2 = hd;
+    d.C = S; d.ldc = N; d.sCb1 = (long long)H * N * N; d.sCb2 = (long long)N * N;
+    d.alpha = scale;
+    int rc = ssl4gie_gemm(&d, nullptr, 0, stream);
+    if (rc) return rc;
+    const long long rows = (long long)B * H * N;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S,
+                       lse, rows, N);
+    LAUNCH_CHECK();
+    // O = P V
+    d = bdesc(N, hd, N, B, H);
+    d.A = S; d.sAm = N; d.sAk = 1; d.sAb1 = (long long)H * N * N; d.sAb2 = (long long)N * N;
+    d.B = q + 2 * D; d.sBk = 3LL * D; d.sBn = 1; d.sBb1 = (long long)N * 3 * D; d.sBb2 = hd;
+    d.C = out; d.ldc = D; d.sCb1 = (long long)N * D; d.sCb2 = hd;
+    return ssl4gie_gemm(&d, nullptr, 0, stream);
+}
+
+extern "C" int ssl4gie_attn_bwd(const void* qkv, const void* out, const void* dout,
+                                const float* lse, void* dqkv, int dtype, int B, int N, int H,
+                                int hd, void* workspace, void* stream) {
+    REQUIRE(qkv && out && dout && lse && dqkv && B > 0 && N > 0 && H > 0 && hd > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int D = H * hd;
+    if (dtype == SSL4GIE_BF16) {
+        REQUIRE(hd == 32 || hd == 64);
+        REQUIRE(N <= 256);
+#define BWD(HD_)                                                                               \
+    if (N <= 64) return launch_bwd<HD_, 4>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);     \
+    if (N <= 224) return launch_bwd<HD_, 14>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);   \
+    return launch_bwd<HD_, 16>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);
+        if (hd == 64) { BWD(64) } else { BWD(32) }
+#undef BWD
+    }
+    REQUIRE(dtype == SSL4GIE_F32 && workspace);
+    float* P = (float*)workspace;
+    float* dP = P + (size_t)B * H * N * N;
+    const float* q = (const float*)qkv;
+    const float* dO = (const float*)dout;
+    float* dq = (float*)dqkv;
+    const long long sS1 = (long long)H * N * N, sS2 = (long long)N * N;
+    const long long sQ1 = (long long)N * 3 * D, sO1 = (long long)N * D;
+    const long long rows = (long long)B * H * N;
+    int rc;
+    // P = exp(scale Q K^T - lse)
+    ssl4gie_gemm_desc d = bdesc(N, N, hd, B, H);
+    d.A = q; d.sAm = 3LL * D; d.sAk = 1; d.sAb1 = sQ1; d.sAb2 = hd;
+    d.B = q + D; d.sBk = 1; d.sBn = 3LL * D; d.sBb1 = sQ1; d.sBb2 = hd;
+    d.C = P; d.ldc = N; d.sCb1 = sS1; d.sCb2 = sS2; d.alpha = scale;
+    if ((rc = ssl4gie_gemm(&d, nullptr, 0, stream))) return rc;
+    hipLaunchKernelGGL(exp_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, lse,
+                       rows, N);
+    LAUNCH_CHECK();
+    // dV[key, d] = sum_q P[q, key] dO[q, d]
+    d = bdesc(N, hd, N, B, H);
+    d.A = P; d.sAm = 1; d.sAk = N; d.sAb1 = sS1; d.sAb2 = sS2;
+    d.B = dO; d.sBk = D; d.sBn = 1; d.sBb1 = sO1; d.sBb2 = hd;
+    d.C = dq + 2 * D; d.ldc = 3LL * D; d.sCb1 = sQ1; d.sCb2 = hd;
+    if ((rc = ssl4gie_gemm(&d, nullptr, 0, stream))) return rc;
+    // dP = dO V^T
+    d = bdesc(N, N, hd, B, H);
+    d.A = dO; d.sAm = D; d.sAk = 1; d.sAb1 = sO1; d.sAb2 = hd;
+    d.B = q + 2 * D; d.sBk = 1; d.sBn = 3LL * D; d.sBb1 = sQ1; d.sBb2 = hd;
+    d.C = dP; d.ldc = N; d.sCb1 = sS1; d.sCb2 = sS2;
+    if ((rc = ssl4gie_gemm(&d, nullptr, 0, stream))) return rc;
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st,
+                       P, dP, rows, N);
+    LAUNCH_CHECK();
+    // dQ = scale dS K
+    d = bdesc(N, hd, N, B, H);
+    d.A = dP; d.sAm = N; d.sAk = 1; d.sAb1 = sS1; d.sAb2 = sS2;
+    d.B = q + D; d.sBk = 3LL * D; d.sBn = 1; d.sBb1 = sQ1; d.sBb2 = hd;
+    d.C = dq; d.ldc = 3LL * D; d.sCb1 = sQ1; d.sCb2 = hd; d.alpha = scale;
+    if ((rc = ssl4gie_gemm(&d, nullptr, 0, stream))) return rc;
+    // dK = scale dS^T Q
+    d = bdesc(N, hd, N, B, H);
+    d.A = dP; d.sAm = 1; d.sAk = N; d.sAb1 = sS1; d.sAb2 = sS2;
+    d.B = q; d.sBk = 3LL * D; d.sBn = 1; d.sBb1 = sQ1; d.sBb2 = hd;
+    d.C = dq + D; d.ldc = 3LL * D; d.sCb1 = sQ1; d.sCb2 = hd; d.alpha = scale;
+    return ssl4gie_gemm(&d, nullptr, 0, stream);
+}

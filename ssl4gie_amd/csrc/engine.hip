@@ -1,0 +1,211 @@
+// Native executor for one pre-LN transformer block (forward and backward): issues the whole
+// kernel sequence on the caller's stream from C++ — no Python per-op dispatch, nothing allocated,
+// nothing synchronised, so a stack of blocks can be replayed from a hipGraph.
+//
+// Reference: timm Block (un-vendored) instantiated at models_mae.py:39-41,53-55 and
+// looped at models_mae.py:166-167,186-187 / Models/models.py:451-454.
+//
+// Forward (7 launches):  LN1 -> QKV GEMM(+bias) -> fused attention -> proj GEMM(+bias+residual)
+//                        -> LN2 -> fc1 GEMM(+bias, GELU; saves u and gelu(u)) -> fc2 GEMM(+bias+res).
+// Backward: data-gradient GEMMs are NT products against pre-transposed weight copies (GELU' fused
+// in the fc2 one), weight-gradient GEMMs are split-K TN products over the token axis, bias
+// gradients are two-stage column sums, and both LayerNorm backward kernels add the residual
+// gradient and emit the operand-type copy the next GEMM consumes.
+#include "common.h"
+#include "ssl4gie_hip.h"
+
+#include <string.h>
+
+extern "C" int ssl4gie_abi_version(void) { return 1; }
+
+namespace {
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+size_t esize(int dt) { return dt == SSL4GIE_BF16 ? 2 : 4; }
+
+struct BwdLayout {
+    size_t du, dh, dxmid, dxmid_lp, dattn, dqkv, ln_ws, col_ws, gemm_ws, attn_ws, total;
+    size_t gemm_ws_bytes;
+};
+
+ssl4gie_gemm_desc lin_desc(int M, int N, int K, int dt) {
+    ssl4gie_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.N = N; d.K = K; d.batch1 = 1; d.batch2 = 1;
+    d.dtype_ab = dt; d.dtype_c = dt; d.alpha = 1.f; d.epilogue = SSL4GIE_EPI_NONE;
+    return d;
+}
+// dW[N_out, K_in] = dY[T, N_out]^T X[T, K_in]
+ssl4gie_gemm_desc wgrad_desc(int n_out, int k_in, int T, const void* dY, const void* X, float* dW,
+                             int dt, int accumulate) {
+    ssl4gie_gemm_desc d = lin_desc(n_out, k_in, T, dt);
+    d.A = dY; d.sAm = 1; d.sAk = n_out;
+    d.B = X; d.sBk = k_in; d.sBn = 1;
+    d.C = dW; d.ldc = k_in; d.dtype_c = SSL4GIE_F32; d.accumulate = accumulate;
+    return d;
+}
+
+BwdLayout bwd_layout(const ssl4gie_block_dims* d) {
+    const size_t T = (size_t)d->B * d->N, D = d->D, F = d->F, es = esize(d->dtype);
+    BwdLayout L;
+    size_t o = 0;
+    L.du = o; o += align_up(T * F * es);
+    L.dh = o; o += align_up(T * D * es);
+    L.dxmid = o; o += align_up(T * D * 4);
+    L.dxmid_lp = o; o += (d->dtype == SSL4GIE_F32) ? 0 : align_up(T * D * es);
+    L.dattn = o; o += align_up(T * D * es);
+    L.dqkv = o; o += align_up(T * 3 * D * es);
+    L.ln_ws = o; o += align_up(ssl4gie_layernorm_bwd_workspace_bytes((int)T, (int)D));
+    L.col_ws = o; o += align_up(ssl4gie_colsum_workspace_bytes((int)T, (int)(3 * D > F ? 3 * D : F)));
+    size_t g = 0;
+    const int dims[4][2] = {{(int)(3 * D), (int)D}, {(int)D, (int)D}, {(int)F, (int)D}, {(int)D, (int)F}};
+    for (int i = 0; i < 4; ++i) {
+        // pointers only matter for alignment checks: use 16-B aligned dummies
+        ssl4gie_gemm_desc w = wgrad_desc(dims[i][0], dims[i][1], (int)T, (const void*)256,
+                                         (const void*)256, (float*)256, d->dtype, 0);
+        const size_t b = ssl4gie_gemm_workspace_bytes(&w);
+        if (b > g) g = b;
+    }
+    L.gemm_ws_bytes = g;
+    L.gemm_ws = o; o += align_up(g);
+    L.attn_ws = o; o += align_up(ssl4gie_attn_workspace_bytes(d->dtype, d->B, d->N, d->H, d->D / d->H));
+    L.total = o;
+    return L;
+}
+
+bool dims_ok(const ssl4gie_block_dims* d) {
+    return d && d->B > 0 && d->N > 0 && d->D > 0 && d->H > 0 && d->F > 0 && d->D % d->H == 0 &&
+           d->D % 4 == 0 && d->F % 4 == 0 &&
+           (d->dtype == SSL4GIE_F32 || d->dtype == SSL4GIE_BF16);
+}
+
+// y[T, n_out] = x[T, k_in] W[n_out, k_in]^T (+ epilogue)
+int linear_fwd(const void* x, const void* W, int T, int n_out, int k_in, int dt,
+               ssl4gie_gemm_desc ep /* C, dtype_c, epilogue fields set */, void* stream) {
+    ep.M = T; ep.N = n_out; ep.K = k_in; ep.batch1 = ep.batch2 = 1;
+    ep.A = x; ep.sAm = k_in; ep.sAk = 1;
+    ep.B = W; ep.sBk = 1; ep.sBn = k_in;
+    ep.dtype_ab = dt; ep.alpha = 1.f;
+    return ssl4gie_gemm(&ep, nullptr, 0, stream);
+}
+// dx[T, k_in] = dy[T, n_out] W[n_out, k_in]; uses the transposed copy Wt[k_in, n_out] if given
+int linear_bwd_data(const void* dy, const void* W, const void* Wt, int T, int n_out, int k_in,
+                    int dt, ssl4gie_gemm_desc ep, void* stream) {
+    ep.M = T; ep.N = k_in; ep.K = n_out; ep.batch1 = ep.batch2 = 1;
+    ep.A = dy; ep.sAm = n_out; ep.sAk = 1;
+    if (Wt) { ep.B = Wt; ep.sBk = 1; ep.sBn = n_out; }
+    else    { ep.B = W;  ep.sBk = k_in; ep.sBn = 1; }
+    ep.dtype_ab = dt; ep.alpha = 1.f;
+    return ssl4gie_gemm(&ep, nullptr, 0, stream);
+}
+
+#define RC(expr)                 \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__) return rc__;   \
+    } while (0)
+
+}  // namespace
+
+extern "C" size_t ssl4gie_block_workspace_bytes(const ssl4gie_block_dims* d) {
+    if (!dims_ok(d)) return 0;
+    return bwd_layout(d).total;  // forward only needs the attention workspace (subset)
+}
+
+extern "C" int ssl4gie_block_fwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* w,
+                                 const ssl4gie_block_act* a, const float* x_in, float* x_out,
+                                 void* workspace, void* stream) {
+    REQUIRE(dims_ok(d) && w && a && x_in && x_out);
+    const int T = d->B * d->N, D = d->D, F = d->F, dt = d->dtype;
+    const BwdLayout L = bwd_layout(d);
+    REQUIRE(workspace || L.total == 0);
+    char* ws = (char*)workspace;
+
+    RC(ssl4gie_layernorm_fwd(x_in, w->ln1_g, w->ln1_b, a->h1, dt, a->mean1, a->rstd1, T, D,
+                             d->eps, stream));
+    ssl4gie_gemm_desc e;
+    memset(&e, 0, sizeof(e));
+    e.C = a->qkv; e.ldc = 3 * D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_BIAS; e.bias = w->bqkv;
+    RC(linear_fwd(a->h1, w->wqkv, T, 3 * D, D, dt, e, stream));
+    RC(ssl4gie_attn_fwd(a->qkv, a->attn, a->lse, dt, d->B, d->N, d->H, D / d->H, ws + L.attn_ws,
+                        stream));
+    memset(&e, 0, sizeof(e));
+    e.C = a->xmid; e.ldc = D; e.dtype_c = SSL4GIE_F32; e.epilogue = SSL4GIE_EPI_BIAS_RESIDUAL;
+    e.bias = w->bproj; e.residual = x_in; e.ldr = D;
+    RC(linear_fwd(a->attn, w->wproj, T, D, D, dt, e, stream));
+    RC(ssl4gie_layernorm_fwd(a->xmid, w->ln2_g, w->ln2_b, a->h2, dt, a->mean2, a->rstd2, T, D,
+                             d->eps, stream));
+    memset(&e, 0, sizeof(e));
+    e.C = a->u; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_BIAS_GELU; e.bias = w->bfc1;
+    e.out2 = a->g;
+    RC(linear_fwd(a->h2, w->wfc1, T, F, D, dt, e, stream));
+    memset(&e, 0, sizeof(e));
+    e.C = x_out; e.ldc = D; e.dtype_c = SSL4GIE_F32; e.epilogue = SSL4GIE_EPI_BIAS_RESIDUAL;
+    e.bias = w->bfc2; e.residual = a->xmid; e.ldr = D;
+    RC(linear_fwd(a->g, w->wfc2, T, D, F, dt, e, stream));
+    return 0;
+}
+
+extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* w,
+                                 const ssl4gie_block_act* a, const ssl4gie_block_grads* g,
+                                 const float* x_in, const float* dx_out, const void* dx_out_lp,
+                                 float* dx_in, void* dx_in_lp, int accumulate, void* workspace,
+                                 void* stream) {
+    REQUIRE(dims_ok(d) && w && a && g && x_in && dx_out && dx_in && workspace);
+    const int T = d->B * d->N, D = d->D, F = d->F, dt = d->dtype;
+    REQUIRE(dt == SSL4GIE_F32 || dx_out_lp);
+    const BwdLayout L = bwd_layout(d);
+    char* ws = (char*)workspace;
+    void* du = ws + L.du;
+    void* dh = ws + L.dh;
+    float* dxmid = (float*)(ws + L.dxmid);
+    void* dxmid_lp = (dt == SSL4GIE_F32) ? (void*)dxmid : (void*)(ws + L.dxmid_lp);
+    void* dattn = ws + L.dattn;
+    void* dqkv = ws + L.dqkv;
+    float* ln_ws = (float*)(ws + L.ln_ws);
+    float* col_ws = (float*)(ws + L.col_ws);
+    void* gws = ws + L.gemm_ws;
+    const void* dy = (dt == SSL4GIE_F32) ? (const void*)dx_out : dx_out_lp;
+    ssl4gie_gemm_desc e, wg;
+
+    // ---- fc2
+    memset(&e, 0, sizeof(e));
+    e.C = du; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_DGELU; e.aux = a->u;
+    RC(linear_bwd_data(dy, w->wfc2, w->wfc2_t, T, D, F, dt, e, stream));
+    wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, dt, accumulate);
+    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
+    RC(ssl4gie_colsum(dy, dt, g->bfc2, accumulate, col_ws, T, D, D, stream));
+    // ---- fc1
+    memset(&e, 0, sizeof(e));
+    e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
+    RC(linear_bwd_data(du, w->wfc1, w->wfc1_t, T, F, D, dt, e, stream));
+    wg = wgrad_desc(F, D, T, du, a->h2, g->wfc1, dt, accumulate);
+    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
+    RC(ssl4gie_colsum(du, dt, g->bfc1, accumulate, col_ws, T, F, F, stream));
+    // ---- LN2 (adds the residual gradient dx_out)
+    RC(ssl4gie_layernorm_bwd(dh, dt, a->xmid, w->ln2_g, a->mean2, a->rstd2, dx_out, dxmid,
+                             dt == SSL4GIE_F32 ? nullptr : dxmid_lp, dt, g->ln2_g, g->ln2_b,
+                             accumulate, ln_ws, T, D, stream));
+    // ---- proj
+    memset(&e, 0, sizeof(e));
+    e.C = dattn; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
+    RC(linear_bwd_data(dxmid_lp, w->wproj, w->wproj_t, T, D, D, dt, e, stream));
+    wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, dt, accumulate);
+    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
+    RC(ssl4gie_colsum(dxmid_lp, dt, g->bproj, accumulate, col_ws, T, D, D, stream));
+    // ---- attention
+    RC(ssl4gie_attn_bwd(a->qkv, a->attn, dattn, a->lse, dqkv, dt, d->B, d->N, d->H, D / d->H,
+                        ws + L.attn_ws, stream));
+    // ---- qkv
+    memset(&e, 0, sizeof(e));
+    e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
+    RC(linear_bwd_data(dqkv, w->wqkv, w->wqkv_t, T, 3 * D, D, dt, e, stream));
+    wg = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, dt, accumulate);
+    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
+    RC(ssl4gie_colsum(dqkv, dt, g->bqkv, accumulate, col_ws, T, 3 * D, 3 * D, stream));
+    // ---- LN1 (adds the residual gradient dxmid)
+    RC(ssl4gie_layernorm_bwd(dh, dt, x_in, w->ln1_g, a->mean1, a->rstd1, dxmid, dx_in,
+                             dt == SSL4GIE_F32 ? nullptr : dx_in_lp, dt, g->ln1_g, g->ln1_b,
+                             accumulate, ln_ws, T, D, stream));
+    return 0;
+}

@@ -1,0 +1,411 @@
+// MAE glue kernels (integer masking, patch gather, token assembly, loss) and weight casts.
+// All HBM-bound byte/row movers: 16-byte vector accesses, one row per wave or per block, no
+// atomics (every reduction is two-stage and deterministic).
+//
+// Reference: Models/mae/models_mae.py:95-107 (patchify), :123-148 (random_masking),
+// :150-170 (forward_encoder glue), :172-196 (forward_decoder glue), :198-214 (forward_loss).
+#include "common.h"
+#include "ssl4gie_hip.h"
+#include "internal.h"
+
+// ------------------------------------------------------------------ casts
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        st4(dst + i, ld4(src + i));
+    } else {
+        for (long long j = i; j < n; ++j) Elem<T>::st(dst + j, src[j]);
+    }
+}
+// dst[c][r] = src[r][c] through a 32x33 LDS tile
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src,
+                                                             T* __restrict__ dst, int rows,
+                                                             int cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 8, c = c0 + tx;
+        tile[ty + i * 8][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, r = r0 + tx;
+        if (c < cols && r < rows) Elem<T>::st(dst + (size_t)c * rows + r, tile[tx][ty + i * 8]);
+    }
+}
+
+extern "C" int ssl4gie_cast(const float* src, void* dst, int dst_dtype, long long n,
+                            void* stream) {
+    REQUIRE(src && dst && n >= 0);
+    REQUIRE(dst_dtype == SSL4GIE_F32 || dst_dtype == SSL4GIE_BF16);
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((n + 1023) / 1024);
+    if (dst_dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, src, (bf16_t*)dst, n);
+    else
+        hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ssl4gie_cast_transpose(const float* src, void* dst, int dst_dtype, int rows,
+                                      int cols, void* stream) {
+    REQUIRE(src && dst && rows > 0 && cols > 0);
+    REQUIRE(dst_dtype == SSL4GIE_F32 || dst_dtype == SSL4GIE_BF16);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
+    if (dst_dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, block, 0, st, src, (bf16_t*)dst, rows, cols);
+    else
+        hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, block, 0, st, src, (float*)dst, rows, cols);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ random masking (integer)
+// Stable ascending argsort by counting: rank(i) = #{j : x_j < x_i  or (x_j == x_i and j < i)}.
+// ids_restore[i] = rank(i), ids_shuffle[rank(i)] = i, mask[i] = rank(i) >= len_keep.
+__global__ __launch_bounds__(256) void mask_argsort_kernel(const float* __restrict__ noise,
+                                                           long long* __restrict__ ids_shuffle,
+                                                           long long* __restrict__ ids_restore,
+                                                           float* __restrict__ mask, int L,
+                                                           int len_keep) {
+    extern __shared__ float row[];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) row[i] = noise[(size_t)b * L + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const float x = row[i];
+        int rank = 0;
+        for (int j = 0; j < L; ++j) {
+            const float y = row[j];
+            rank += (y < x) || (y == x && j < i);
+        }
+        if (ids_restore) ids_restore[(size_t)b * L + i] = rank;
+        if (ids_shuffle) ids_shuffle[(size_t)b * L + rank] = i;
+        if (mask) mask[(size_t)b * L + i] = rank >= len_keep ? 1.f : 0.f;
+    }
+}
+extern "C" int ssl4gie_mask_argsort(const float* noise, long long* ids_shuffle,
+                                    long long* ids_restore, float* mask, int B, int L,
+                                    int len_keep, void* stream) {
+    REQUIRE(noise && B >= 0 && L > 0 && L <= 16384 && len_keep >= 0 && len_keep <= L);
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(mask_argsort_kernel, dim3(B), dim3(256), L * sizeof(float),
+                       (hipStream_t)stream, noise, ids_shuffle, ids_restore, mask, L, len_keep);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ patch gather (im2col, k=s=p)
+// one block per output row (= one patch); threads sweep the C*p*p columns 4 pixels at a time.
+template <typename T>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ img,
+                                                           const long long* __restrict__ ids,
+                                                           T* __restrict__ out, int C, int H, int W,
+                                                           int p, int nsel, long long ids_stride,
+                                                           int order) {
+    const int rowi = blockIdx.x;  // b*nsel + j
+    const int b = rowi / nsel, j = rowi % nsel;
+    const int gw = W / p;
+    const int patch = ids ? (int)ids[(size_t)b * ids_stride + j] : j;
+    const int gy = patch / gw, gx = patch % gw;
+    const int P = C * p * p;
+    const float* ib = img + (size_t)b * C * H * W;
+    T* orow = out + (size_t)rowi * P;
+    for (int k4 = threadIdx.x * 4; k4 < P; k4 += blockDim.x * 4) {
+        // enumerate in (c, py, px) order so that 4 consecutive px are one 16-B read
+        const int c = k4 / (p * p), rem = k4 % (p * p), py = rem / p, px = rem % p;
+        const f32x4 v = ld4(ib + ((size_t)c * H + gy * p + py) * W + gx * p + px);
+        if (order == 0) {
+            st4(orow + k4, v);
+        } else {  // 'nhwpqc': col = (py*p + px)*C + c
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Elem<T>::st(orow + (py * p + px + i) * C + c, v[i]);
+        }
+    }
+}
+extern "C" int ssl4gie_patch_gather(const float* img, const long long* ids, void* out,
+                                    int out_dtype, int B, int C, int H, int W, int p, int nsel,
+                                    long long ids_stride, int order, void* stream) {
+    REQUIRE(img && out && B >= 0 && C > 0 && p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0);
+    REQUIRE(W % 4 == 0 && nsel > 0 && nsel <= (H / p) * (W / p) && (order == 0 || order == 1));
+    REQUIRE(out_dtype == SSL4GIE_F32 || out_dtype == SSL4GIE_BF16);
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(B * nsel), block(256);
+    if (out_dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, grid, block, 0, st, img, ids, (bf16_t*)out,
+                           C, H, W, p, nsel, ids_stride, order);
+    else
+        hipLaunchKernelGGL(patch_gather_kernel<float>, grid, block, 0, st, img, ids, (float*)out,
+                           C, H, W, p, nsel, ids_stride, order);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ encoder token assembly
+template <typename T>
+__global__ void tokens_assemble_kernel(const T* __restrict__ y, const float* __restrict__ cls,
+                                       const float* __restrict__ pos,
+                                       const long long* __restrict__ ids, long long ids_stride,
+                                       float* __restrict__ x, int nsel, int D) {
+    const int row = blockIdx.x;  // b*(nsel+1) + t
+    const int b = row / (nsel + 1), t = row % (nsel + 1);
+    float* xr = x + (size_t)row * D;
+    if (t == 0) {
+        for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4)
+            st4(xr + d, ld4(cls + d) + ld4(pos + d));
+    } else {
+        const int j = t - 1;
+        const int patch = ids ? (int)ids[(size_t)b * ids_stride + j] : j;
+        const T* yr = y + ((size_t)b * nsel + j) * D;
+        const float* pr = pos + (size_t)(1 + patch) * D;
+        for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4)
+            st4(xr + d, ld4(yr + d) + ld4(pr + d));
+    }
+}
+extern "C" int ssl4gie_tokens_assemble(const void* y, int y_dtype, const float* cls,
+                                       const float* pos, const long long* ids,
+                                       long long ids_stride, float* x, int B, int nsel, int D,
+                                       void* stream) {
+    REQUIRE(y && cls && pos && x && B >= 0 && nsel > 0 && D > 0 && D % 4 == 0);
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(B * (nsel + 1)), block(D / 4 < 256 ? 64 * ((D / 4 + 63) / 64) : 256);
+    if (y_dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(tokens_assemble_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)y,
+                           cls, pos, ids, ids_stride, x, nsel, D);
+    else if (y_dtype == SSL4GIE_F32)
+        hipLaunchKernelGGL(tokens_assemble_kernel<float>, grid, block, 0, st, (const float*)y, cls,
+                           pos, ids, ids_stride, x, nsel, D);
+    else
+        return ARG_ERR;
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+__global__ void tokens_assemble_bwd_kernel(const float* __restrict__ dx, T* __restrict__ dy,
+                                           int nsel, int D) {
+    const int row = blockIdx.x;  // b*nsel + j
+    const int b = row / nsel, j = row % nsel;
+    const float* s = dx + ((size_t)b * (nsel + 1) + 1 + j) * D;
+    T* d = dy + (size_t)row * D;
+    for (int k = threadIdx.x * 4; k < D; k += blockDim.x * 4) st4(d + k, ld4(s + k));
+}
+// out[d] (+)= sum_b src[b*stride + d]
+__global__ void strided_rowsum_kernel(const float* __restrict__ src, float* __restrict__ out,
+                                      int nrows, size_t stride, int D, int accumulate) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float s = 0.f;
+    for (int b = 0; b < nrows; ++b) s += src[(size_t)b * stride + d];
+    out[d] = accumulate ? out[d] + s : s;
+}
+extern "C" int ssl4gie_tokens_assemble_bwd(const float* dx, void* dy, int dy_dtype, float* dcls,
+                                           int accumulate, int B, int nsel, int D, void* stream) {
+    REQUIRE(dx && B >= 0 && nsel > 0 && D > 0 && D % 4 == 0);
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (dy) {
+        dim3 grid(B * nsel), block(D / 4 < 256 ? 64 * ((D / 4 + 63) / 64) : 256);
+        if (dy_dtype == SSL4GIE_BF16)
+            hipLaunchKernelGGL(tokens_assemble_bwd_kernel<bf16_t>, grid, block, 0, st, dx, (bf16_t*)dy, nsel, D);
+        else if (dy_dtype == SSL4GIE_F32)
+            hipLaunchKernelGGL(tokens_assemble_bwd_kernel<float>, grid, block, 0, st, dx, (float*)dy, nsel, D);
+        else
+            return ARG_ERR;
+        LAUNCH_CHECK();
+    }
+    if (dcls) {
+        hipLaunchKernelGGL(strided_rowsum_kernel, dim3((D + 255) / 256), dim3(256), 0, st, dx, dcls,
+                           B, (size_t)(nsel + 1) * D, D, accumulate);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ decoder token assembly
+template <typename T>
+__global__ void decoder_assemble_kernel(const T* __restrict__ y, const float* __restrict__ mtok,
+                                        const float* __restrict__ dpos,
+                                        const long long* __restrict__ ids_restore,
+                                        float* __restrict__ xd, int L, int nkeep, int D) {
+    const int row = blockIdx.x;  // b*(L+1) + t
+    const int b = row / (L + 1), t = row % (L + 1);
+    float* xr = xd + (size_t)row * D;
+    const float* pr = dpos + (size_t)t * D;
+    const T* src = nullptr;
+    if (t == 0) {
+        src = y + (size_t)b * (nkeep + 1) * D;
+    } else {
+        const int r = (int)ids_restore[(size_t)b * L + t - 1];
+        if (r < nkeep) src = y + ((size_t)b * (nkeep + 1) + 1 + r) * D;
+    }
+    for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+        const f32x4 v = src ? ld4(src + d) : ld4(mtok + d);
+        st4(xr + d, v + ld4(pr + d));
+    }
+}
+extern "C" int ssl4gie_decoder_assemble(const void* y, int y_dtype, const float* mask_token,
+                                        const float* dpos, const long long* ids_restore,
+                                        float* xd, int B, int L, int nkeep, int D, void* stream) {
+    REQUIRE(y && mask_token && dpos && ids_restore && xd && B >= 0 && L > 0 && nkeep >= 0);
+    REQUIRE(nkeep <= L && D > 0 && D % 4 == 0);
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(B * (L + 1)), block(D / 4 < 256 ? 64 * ((D / 4 + 63) / 64) : 256);
+    if (y_dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(decoder_assemble_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)y,
+                           mask_token, dpos, ids_restore, xd, L, nkeep, D);
+    else if (y_dtype == SSL4GIE_F32)
+        hipLaunchKernelGGL(decoder_assemble_kernel<float>, grid, block, 0, st, (const float*)y,
+                           mask_token, dpos, ids_restore, xd, L, nkeep, D);
+    else
+        return ARG_ERR;
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// dy rows (kept tokens) + per-sample partial sums of the removed rows (mask-token gradient)
+template <typename T>
+__global__ void decoder_assemble_bwd_kernel(const float* __restrict__ dxd,
+                                            const long long* __restrict__ ids_shuffle,
+                                            T* __restrict__ dy, float* __restrict__ partial,
+                                            int L, int nkeep, int D) {
+    const int b = blockIdx.x;
+    const float* base = dxd + (size_t)b * (L + 1) * D;
+    T* dyb = dy + (size_t)b * (nkeep + 1) * D;
+    for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+        st4(dyb + d, ld4(base + d));
+        for (int j = 0; j < nkeep; ++j) {
+            const int pos = (int)ids_shuffle[(size_t)b * L + j];
+            st4(dyb + (size_t)(1 + j) * D + d, ld4(base + (size_t)(1 + pos) * D + d));
+        }
+        f32x4 acc = {0, 0, 0, 0};
+        for (int j = nkeep; j < L; ++j) {
+            const int pos = (int)ids_shuffle[(size_t)b * L + j];
+            acc += ld4(base + (size_t)(1 + pos) * D + d);
+        }
+        st4(partial + (size_t)b * D + d, acc);
+    }
+}
+extern "C" size_t ssl4gie_decoder_assemble_bwd_workspace_bytes(int B, int L, int D) {
+    (void)L;
+    return (size_t)B * D * sizeof(float);
+}
+extern "C" int ssl4gie_decoder_assemble_bwd(const float* dxd, const long long* ids_shuffle,
+                                            void* dy, int dy_dtype, float* dmask_token,
+                                            int accumulate, float* workspace, int B, int L,
+                                            int nkeep, int D, void* stream) {
+    REQUIRE(dxd && ids_shuffle && dy && dmask_token && workspace && B >= 0 && L > 0);
+    REQUIRE(nkeep >= 0 && nkeep <= L && D > 0 && D % 4 == 0);
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(B), block(D / 4 < 256 ? 64 * ((D / 4 + 63) / 64) : 256);
+    if (dy_dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(decoder_assemble_bwd_kernel<bf16_t>, grid, block, 0, st, dxd,
+                           ids_shuffle, (bf16_t*)dy, workspace, L, nkeep, D);
+    else if (dy_dtype == SSL4GIE_F32)
+        hipLaunchKernelGGL(decoder_assemble_bwd_kernel<float>, grid, block, 0, st, dxd,
+                           ids_shuffle, (float*)dy, workspace, L, nkeep, D);
+    else
+        return ARG_ERR;
+    LAUNCH_CHECK();
+    return ssl4gie_internal_reduce_partials(workspace, dmask_token, B, D, (size_t)D, accumulate, st);
+}
+
+// ------------------------------------------------------------------ MAE loss (+ its gradient)
+// one wave per patch; P = C*p*p target values gathered in 'nhwpqc' order (NV = ceil(P/64) per lane)
+template <int NV>
+__global__ __launch_bounds__(256) void mae_loss_kernel(
+    const float* __restrict__ pred, const float* __restrict__ img, const float* __restrict__ mask,
+    float* __restrict__ per_patch, float* __restrict__ dpred, const float* __restrict__ gscale_dev,
+    float gscale_host, int norm_pix, int B, int C, int H, int W, int p) {
+    const int lane = threadIdx.x & 63;
+    const int gw = W / p, L = (H / p) * gw, P = C * p * p;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*(L+1)
+    if (row >= (long long)B * (L + 1)) return;
+    const int b = (int)(row / (L + 1)), t = (int)(row % (L + 1));
+    float* dr = dpred ? dpred + (size_t)row * P : nullptr;
+    if (t == 0) {  // cls row: no loss, zero gradient
+        if (dr)
+            for (int k = lane; k < P; k += 64) dr[k] = 0.f;
+        return;
+    }
+    const int l = t - 1, gy = l / gw, gx = l % gw;
+    const float* ib = img + (size_t)b * C * H * W;
+    const float* pr = pred + (size_t)row * P;
+    float tv[NV], pv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = lane + 64 * i;
+        tv[i] = 0.f;
+        pv[i] = 0.f;
+        if (k < P) {
+            const int c = k % C, pix = k / C, py = pix / p, px = pix % p;
+            tv[i] = ib[((size_t)c * H + gy * p + py) * W + gx * p + px];
+            pv[i] = pr[k];
+            s += tv[i];
+        }
+    }
+    if (norm_pix) {
+        const float mean = wave_sum(s) / (float)P;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < P) {
+                const float d = tv[i] - mean;
+                q += d * d;
+            }
+        const float inv = rsqrtf(wave_sum(q) / (float)(P - 1) + 1.0e-6f);  // unbiased var
+#pragma unroll
+        for (int i = 0; i < NV; ++i) tv[i] = (tv[i] - mean) * inv;
+    }
+    const float m = mask[(size_t)b * L + l];
+    float e = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < P) {
+            const float d = pv[i] - tv[i];
+            e += d * d;
+        }
+    e = wave_sum(e) / (float)P;
+    if (per_patch && lane == 0) per_patch[(size_t)b * L + l] = e * m;
+    if (dr) {
+        const float gs = gscale_host * (gscale_dev ? gscale_dev[0] : 1.f) * m * 2.0f / (float)P;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < P) dr[lane + 64 * i] = gs * (pv[i] - tv[i]);
+    }
+}
+extern "C" int ssl4gie_mae_loss(const float* pred, const float* img, const float* mask,
+                                float* per_patch, float* dpred, const float* gscale_dev,
+                                float gscale_host, int norm_pix, int B, int C, int H, int W, int p,
+                                void* stream) {
+    REQUIRE(pred && img && mask && B >= 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0);
+    const int P = C * p * p;
+    REQUIRE(P <= 64 * 16);
+    if (B == 0) return 0;
+    const long long rows = (long long)B * ((H / p) * (W / p) + 1);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (P <= 64 * 4)
+        hipLaunchKernelGGL(mae_loss_kernel<4>, grid, block, 0, st, pred, img, mask, per_patch, dpred,
+                           gscale_dev, gscale_host, norm_pix, B, C, H, W, p);
+    else if (P <= 64 * 12)
+        hipLaunchKernelGGL(mae_loss_kernel<12>, grid, block, 0, st, pred, img, mask, per_patch,
+                           dpred, gscale_dev, gscale_host, norm_pix, B, C, H, W, p);
+    else
+        hipLaunchKernelGGL(mae_loss_kernel<16>, grid, block, 0, st, pred, img, mask, per_patch,
+                           dpred, gscale_dev, gscale_host, norm_pix, B, C, H, W, p);
+    LAUNCH_CHECK();
+    return 0;
+}

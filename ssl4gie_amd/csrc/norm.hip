@@ -1,0 +1,315 @@
+// LayerNorm forward/backward and column reductions (bias gradients) for gfx950.
+//
+// HBM-bound row kernels: one 64-lane wave owns one row, 16-byte vector accesses, statistics in
+// fp32 via wavefront shuffles (no LDS in the forward).  The residual stream is always fp32
+// (reference autocast semantics); the normalised output feeds MFMA GEMMs and
+// is written directly in the GEMM operand type (bf16 or f32) — the cast is fused here.
+//
+// Replaces: torch.nn.LayerNorm(eps=1e-6) at Models/mae/models_mae.py:227, Models/models.py:384,498
+#include "common.h"
+#include "ssl4gie_hip.h"
+#include "internal.h"
+
+#define LN_ROWS_PER_BLOCK 4  // 4 waves / 256 threads
+#define LN_MAX_VEC 8         // up to 64*4*8 = 2048 columns held in registers
+
+template <typename TY, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     TY* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int rows, int cols,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * cols;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            v[i] = ld4(xr + c);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i] = f32x4{0, 0, 0, 0};
+        }
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mu;
+                q += d * d;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+    TY* yr = y + (size_t)row * cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            const f32x4 g = ld4(gamma + c), b = ld4(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+            st4(yr + c, o);
+        }
+    }
+}
+
+// Backward.  dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)).
+// Column sums for dgamma/dbeta: every lane owns fixed columns, accumulates in registers over
+// the rows its wave visits, the 4 waves of a block combine through LDS and write one partial
+// row per block; ln_bwd_finalize reduces the partial rows (deterministic, no atomics).
+template <typename TDY, typename TLP, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ dres, float* __restrict__ dx, TLP* __restrict__ dx_lp,
+    float* __restrict__ partial /*[gridDim.x][2][cols]*/, int rows, int cols) {
+    __shared__ float red[3][2 * 64 * 4 * NV];  // waves 1..3 -> wave 0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 g[NV], ag[NV], ab[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        g[i] = (c < cols) ? ld4(gamma + c) : f32x4{0, 0, 0, 0};
+        ag[i] = f32x4{0, 0, 0, 0};
+        ab[i] = f32x4{0, 0, 0, 0};
+    }
+    for (int row = blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < rows;
+         row += gridDim.x * LN_ROWS_PER_BLOCK) {
+        const float mu = mean[row], rs = rstd[row];
+        const size_t off = (size_t)row * cols;
+        f32x4 d[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < cols) {
+                d[i] = ld4(dy + off + c);
+                const f32x4 xv = ld4(x + off + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][j] = (xv[j] - mu) * rs;
+                    ag[i][j] += d[i][j] * xh[i][j];
+                    ab[i][j] += d[i][j];
+                    const float gd = g[i][j] * d[i][j];
+                    s1 += gd;
+                    s2 += gd * xh[i][j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols;
+        s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < cols) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rs * (g[i][j] * d[i][j] - s1 - xh[i][j] * s2);
+                if (dres) {
+                    const f32x4 r = ld4(dres + off + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += r[j];
+                }
+                if (dx) st4(dx + off + c, o);
+                if (dx_lp) st4(dx_lp + off + c, o);
+            }
+        }
+    }
+    // combine the 4 waves' column sums
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[wave - 1][(i * 4 + j) * 64 + lane] = ag[i][j];
+                red[wave - 1][(NV * 4 + i * 4 + j) * 64 + lane] = ab[i][j];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* pg = partial + (size_t)blockIdx.x * 2 * cols;
+        float* pb = pg + cols;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < cols) {
+                f32x4 og = ag[i], ob = ab[i];
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        og[j] += red[w][(i * 4 + j) * 64 + lane];
+                        ob[j] += red[w][(NV * 4 + i * 4 + j) * 64 + lane];
+                    }
+                st4(pg + c, og);
+                st4(pb + c, ob);
+            }
+        }
+    }
+}
+
+// out[c] (+)= sum_p partial[p][c] ; `n_out` contiguous columns, partial row stride `stride`.
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                       int nparts, int n_out, size_t stride, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_out) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * stride + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// column sums of a [rows, cols] matrix (bias gradient): partial[blockIdx.y][cols]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x,
+                                                             float* __restrict__ partial,
+                                                             int rows, int cols, size_t ld) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    f32x4 acc = {0, 0, 0, 0};
+    if (c < cols) {
+        for (int r = blockIdx.y * 4 + wave; r < rows; r += gridDim.y * 4) {
+            const f32x4 v = ld4(x + (size_t)r * ld + c);
+            acc += v;
+        }
+    }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        acc += red[0][lane];
+        acc += red[1][lane];
+        acc += red[2][lane];
+        st4(partial + (size_t)blockIdx.y * cols + c, acc);
+    }
+}
+
+int ssl4gie_internal_reduce_partials(const float* partial, float* out, int nparts, int n_out,
+                                     size_t stride, int accumulate, hipStream_t st) {
+    const int t = 256;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_out + t - 1) / t), dim3(t), 0, st, partial,
+                       out, nparts, n_out, stride, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static int ln_nv(int cols) { return (cols + 255) / 256; }
+static int ln_bwd_blocks(int rows) {
+    int b = (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+    return b < 1024 ? b : 1024;
+}
+
+extern "C" int ssl4gie_layernorm_fwd(const float* x, const float* gamma, const float* beta,
+                                     void* y, int y_dtype, float* mean, float* rstd, int rows,
+                                     int cols, float eps, void* stream) {
+    REQUIRE(x && gamma && beta && y && rows >= 0 && cols > 0 && cols % 4 == 0);
+    REQUIRE(cols <= 256 * LN_MAX_VEC);
+    REQUIRE(y_dtype == SSL4GIE_F32 || y_dtype == SSL4GIE_BF16);
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK), block(256);
+#define LN_FWD(NV)                                                                              \
+    if (y_dtype == SSL4GIE_BF16)                                                                \
+        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV>), grid, block, 0, st, x, gamma, beta,     \
+                           (bf16_t*)y, mean, rstd, rows, cols, eps);                            \
+    else                                                                                        \
+        hipLaunchKernelGGL((ln_fwd_kernel<float, NV>), grid, block, 0, st, x, gamma, beta,      \
+                           (float*)y, mean, rstd, rows, cols, eps);
+    switch (ln_nv(cols)) {
+        case 1: LN_FWD(1) break;
+        case 2: LN_FWD(2) break;
+        case 3: LN_FWD(3) break;
+        case 4: LN_FWD(4) break;
+        default: LN_FWD(8) break;
+    }
+#undef LN_FWD
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t ssl4gie_layernorm_bwd_workspace_bytes(int rows, int cols) {
+    return (size_t)ln_bwd_blocks(rows) * 2 * cols * sizeof(float);
+}
+
+extern "C" int ssl4gie_layernorm_bwd(const void* dy, int dy_dtype, const float* x,
+                                     const float* gamma, const float* mean, const float* rstd,
+                                     const float* dres, float* dx, void* dx_lp, int lp_dtype,
+                                     float* dgamma, float* dbeta, int accumulate,
+                                     float* workspace, int rows, int cols, void* stream) {
+    REQUIRE(dy && x && gamma && mean && rstd && workspace && rows >= 0 && cols > 0);
+    REQUIRE(cols % 4 == 0 && cols <= 256 * 4);
+    REQUIRE(dy_dtype == SSL4GIE_F32 || dy_dtype == SSL4GIE_BF16);
+    REQUIRE(!dx_lp || lp_dtype == dy_dtype);
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ln_bwd_blocks(rows);
+    dim3 grid(nb), block(256);
+#define LN_BWD(NV)                                                                             \
+    if (dy_dtype == SSL4GIE_BF16)                                                              \
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, NV>), grid, block, 0, st,            \
+                           (const bf16_t*)dy, x, gamma, mean, rstd, dres, dx, (bf16_t*)dx_lp,  \
+                           workspace, rows, cols);                                             \
+    else                                                                                       \
+        hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, block, 0, st,              \
+                           (const float*)dy, x, gamma, mean, rstd, dres, dx, (float*)dx_lp,    \
+                           workspace, rows, cols);
+    switch (ln_nv(cols)) {
+        case 1: LN_BWD(1) break;
+        case 2: LN_BWD(2) break;
+        case 3: LN_BWD(3) break;
+        default: LN_BWD(4) break;
+    }
+#undef LN_BWD
+    LAUNCH_CHECK();
+    if (dgamma && dbeta) {
+        // partial rows are [dgamma | dbeta] of width 2*cols: reduce both halves
+        const int t = 256;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + t - 1) / t), dim3(t), 0, st,
+                           workspace, dgamma, nb, cols, (size_t)2 * cols, accumulate);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + t - 1) / t), dim3(t), 0, st,
+                           workspace + cols, dbeta, nb, cols, (size_t)2 * cols, accumulate);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+static int colsum_parts(int rows) {
+    int p = (rows + 63) / 64;
+    return p < 256 ? (p < 1 ? 1 : p) : 256;
+}
+extern "C" size_t ssl4gie_colsum_workspace_bytes(int rows, int cols) {
+    return (size_t)colsum_parts(rows) * cols * sizeof(float);
+}
+extern "C" int ssl4gie_colsum(const void* x, int dtype, float* out, int accumulate,
+                              float* workspace, int rows, int cols, long long ld, void* stream) {
+    REQUIRE(x && out && workspace && rows >= 0 && cols > 0 && cols % 4 == 0 && ld >= cols);
+    REQUIRE(dtype == SSL4GIE_F32 || dtype == SSL4GIE_BF16);
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = colsum_parts(rows);
+    dim3 grid((cols + 255) / 256, parts), block(256);
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x,
+                           workspace, rows, cols, (size_t)ld);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, block, 0, st, (const float*)x,
+                           workspace, rows, cols, (size_t)ld);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, st,
+                       workspace, out, parts, cols, (size_t)cols, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}

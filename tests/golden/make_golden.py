@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REFERENCE's own classes.
+
+Runs only in the authoring container (needs /root/reference, which never travels to the GPU
+box).  The reference pins timm==0.6.12 without vendoring it, so its `models_mae.py` is imported
+on top of `oracle.timm_restatement` registered under the `timm.*` names.  Weights
+and inputs come from `oracle.synth` (pure functions of key/seed) so fixtures only hold inputs
+that are not reproducible + expected outputs.
+
+    python tests/golden/make_golden.py [--skip-curve]
+
+Fixtures written:
+  g1_masking.npz      random_masking (models_mae.py:123-148) on tie-free noise + crafted-tie row
+  g2_patchify.npz     patchify / unpatchify (models_mae.py:95-121)
+  g3_sincos.npz       fixed sin-cos tables (mae/util/pos_embed.py:20-67)
+  g5_mae_tiny.npz     MaskedAutoencoderViT fwd + all grads, tiny config, norm_pix on/off
+  g5_mae_vitb.npz     MaskedAutoencoderViT ViT-B fwd + grad norms / small grads, B=2
+  g5_curve_tiny.npz   100-step AdamW loss curve, tiny config (B=8)
+  g5_curve_vitb.npz   100-step AdamW loss curve, ViT-B (B=8)  [slow; --skip-curve]
+  g_lr_sched.npz      per-iteration warm-up+cosine LR (mae/util/lr_sched.py:9-21)
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import mae_ref, synth, timm_restatement  # noqa: E402
+
+
+def import_reference_mae():
+    timm_restatement.install_as_timm()
+    np.float = float  # pos_embed.py:56 uses the removed alias
+    sys.path.insert(0, REF)
+    import Models.mae.models_mae as ref_mae  # noqa
+    return ref_mae
+
+
+@contextlib.contextmanager
+def injected_rand(noise: np.ndarray):
+    """random_masking draws torch.rand(N, L) (models_mae.py:129); feed it our noise."""
+    real = torch.rand
+    t = torch.from_numpy(np.asarray(noise, dtype=np.float32))
+
+    def fake(*shape, **kw):
+        shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else shape
+        assert tuple(shp) == tuple(t.shape), (shp, t.shape)
+        return t.clone()
+
+    torch.rand = fake
+    try:
+        yield
+    finally:
+        torch.rand = real
+
+
+def build_ref(ref_mae, cfg: mae_ref.MAEConfig, seed: int):
+    import torch.nn as nn
+    m = ref_mae.MaskedAutoencoderViT(
+        img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans,
+        embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+        decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
+        decoder_num_heads=cfg.decoder_num_heads, mlp_ratio=cfg.mlp_ratio,
+        norm_layer=partial(nn.LayerNorm, eps=cfg.ln_eps), norm_pix_loss=cfg.norm_pix_loss)
+    sd = synth.mae_state_dict(cfg, seed)
+    # the reference's own sincos tables must equal the oracle's before we overwrite them
+    own = m.state_dict()
+    assert set(own) == set(sd), set(own) ^ set(sd)
+    for k in ("pos_embed", "decoder_pos_embed"):
+        np.testing.assert_allclose(own[k].numpy(), sd[k].numpy(), rtol=0, atol=1e-6)
+        sd[k] = own[k].clone()
+    m.load_state_dict(sd, strict=True)
+    return m, sd
+
+
+def g1_masking(ref_mae):
+    cfg = mae_ref.VIT_B
+    m = ref_mae.MaskedAutoencoderViT.__new__(ref_mae.MaskedAutoencoderViT)  # method only
+    noise = synth.synth_noise(8, 196, seed=0)
+    x = torch.arange(8 * 196 * 4, dtype=torch.float32).reshape(8, 196, 4)
+    with injected_rand(noise):
+        xm, mask, ids_restore = ref_mae.MaskedAutoencoderViT.random_masking(m, x, 0.75)
+    ids_shuffle = torch.argsort(torch.from_numpy(noise), dim=1)
+    # crafted ties: expected output is the build's STABLE rule (oracle), not the reference
+    tie = noise[:2].copy()
+    tie[0, 5] = tie[0, 100] = tie[0, 17]
+    tie[1, :] = 0.5
+    o = mae_ref.masking_from_noise(tie, 0.75)
+    np.savez_compressed(os.path.join(HERE, "g1_masking.npz"), noise=noise,
+                        ids_shuffle=ids_shuffle.numpy(), ids_restore=ids_restore.numpy(),
+                        mask=mask.numpy(), x_masked=xm.numpy(), x=x.numpy(),
+                        tie_noise=tie, tie_ids_shuffle=o[0], tie_ids_restore=o[1],
+                        tie_mask=o[3])
+    print("g1 ok: kept/row", int((mask == 0).sum(1)[0]))
+
+
+def g2_patchify(ref_mae):
+    m = types.SimpleNamespace(patch_embed=types.SimpleNamespace(patch_size=(16, 16)))
+    g = torch.Generator().manual_seed(7)
+    imgs = torch.randn(2, 3, 64, 64, generator=g)
+    p = ref_mae.MaskedAutoencoderViT.patchify(m, imgs)
+    u = ref_mae.MaskedAutoencoderViT.unpatchify(m, p)
+    assert torch.equal(u, imgs)
+    big = synth.synth_images(1, mae_ref.VIT_B, seed=3)
+    pb = ref_mae.MaskedAutoencoderViT.patchify(m, big)
+    np.savez_compressed(os.path.join(HERE, "g2_patchify.npz"), imgs=imgs.numpy(),
+                        patches=p.numpy(), big_rows=pb[0, [0, 13, 14, 195]].numpy())
+    print("g2 ok")
+
+
+def g3_sincos():
+    sys.path.insert(0, REF)
+    from Models.mae.util import pos_embed as pe
+    np.float = float
+    out = {f"mae_{d}": pe.get_2d_sincos_pos_embed(d, 14, cls_token=True).astype(np.float32)
+           for d in (768, 512, 192, 128)}
+    out["mae_192_g4"] = pe.get_2d_sincos_pos_embed(192, 4, cls_token=True).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "g3_sincos.npz"), **out)
+    print("g3 ok")
+
+
+def run_fwd_bwd(m, imgs, noise, mask_ratio=0.75):
+    m.zero_grad(set_to_none=True)
+    with injected_rand(noise):
+        loss, pred, mask = m(imgs, mask_ratio=mask_ratio)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    return loss.detach(), pred.detach(), mask.detach(), grads
+
+
+def g5_tiny(ref_mae):
+    out = {}
+    for npl in (False, True):
+        cfg = mae_ref.MAEConfig(**{**mae_ref.TINY.__dict__, "norm_pix_loss": npl})
+        m, sd = build_ref(ref_mae, cfg, seed=1)
+        imgs = synth.synth_images(4, cfg, seed=1)
+        noise = synth.synth_noise(4, cfg.num_patches, seed=1)
+        loss, pred, mask, grads = run_fwd_bwd(m, imgs, noise)
+        tag = "npl" if npl else "raw"
+        out[f"{tag}/loss"] = loss.numpy()
+        out[f"{tag}/pred"] = pred.numpy()
+        out[f"{tag}/mask"] = mask.numpy()
+        for k, g in grads.items():
+            out[f"{tag}/grad/{k}"] = g.numpy()
+        out[f"{tag}/digest"] = np.array(synth.state_dict_digest(sd))
+        # oracle must agree with the reference before anything is written
+        sdo = {k: v.clone().requires_grad_(v.is_floating_point() and "pos_embed" not in k)
+               for k, v in sd.items()}
+        lo, po, mo, _ = mae_ref.mae_forward(sdo, cfg, imgs, noise)
+        np.testing.assert_allclose(lo.detach().numpy(), loss.numpy(), rtol=1e-5)
+        np.testing.assert_allclose(po.detach().numpy(), pred.numpy(), rtol=1e-4, atol=1e-5)
+        print(f"g5 tiny[{tag}] loss={float(loss):.6f} (oracle agrees)")
+    np.savez_compressed(os.path.join(HERE, "g5_mae_tiny.npz"), **out)
+
+
+def g5_vitb(ref_mae):
+    cfg = mae_ref.MAEConfig(**{**mae_ref.VIT_B.__dict__, "norm_pix_loss": True})
+    m, sd = build_ref(ref_mae, cfg, seed=0)
+    imgs = synth.synth_images(2, cfg, seed=0)
+    noise = synth.synth_noise(2, 196, seed=0)
+    loss, pred, mask, grads = run_fwd_bwd(m, imgs, noise)
+    out = {"loss": loss.numpy(), "pred": pred.numpy(), "mask": mask.numpy(),
+           "digest": np.array(synth.state_dict_digest(sd)),
+           "n_tensors": np.array(len(sd)),
+           "n_params": np.array(sum(v.numel() for v in sd.values()))}
+    names = sorted(grads)
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array([float(grads[k].norm()) for k in names], dtype=np.float64)
+    for k in names:
+        g = grads[k]
+        if g.numel() <= 4096:
+            out[f"grad/{k}"] = g.numpy()
+        else:
+            out[f"gslice/{k}"] = g.reshape(g.shape[0], -1)[:8, :64].numpy()
+    np.savez_compressed(os.path.join(HERE, "g5_mae_vitb.npz"), **out)
+    print(f"g5 vitb loss={float(loss):.6f} tensors={len(sd)} params={int(out['n_params'])}")
+
+
+def curve(ref_mae, cfg, b, steps, lr, fname):
+    m, sd = build_ref(ref_mae, cfg, seed=0)
+    from timm.optim import optim_factory
+    groups = optim_factory.add_weight_decay(m, 0.05)  # main_pretrain.py:179
+    opt = torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.95))  # main_pretrain.py:180
+    losses = []
+    for it in range(steps):
+        imgs = synth.synth_images(b, cfg, seed=it % 4)
+        noise = synth.synth_noise(b, cfg.num_patches, seed=100 + it)
+        opt.zero_grad(set_to_none=True)
+        with injected_rand(noise):
+            loss, _, _ = m(imgs, mask_ratio=0.75)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        if it % 10 == 0:
+            print(f"  step {it}: {losses[-1]:.6f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, fname), losses=np.array(losses, dtype=np.float64),
+                        lr=np.array(lr), batch=np.array(b), steps=np.array(steps),
+                        weight_decay=np.array(0.05), betas=np.array([0.9, 0.95]),
+                        digest=np.array(synth.state_dict_digest(sd)))
+    print(fname, "first/last", losses[0], losses[-1])
+
+
+def g_lr_sched():
+    sys.path.insert(0, REF)
+    from Models.mae.util import lr_sched
+    args = types.SimpleNamespace(lr=1.5e-4 * 4096 / 256, min_lr=0.0, warmup_epochs=40, epochs=800)
+    class Opt:  # noqa
+        param_groups = [{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}]
+    epochs = np.concatenate([np.linspace(0, 45, 91), np.linspace(100, 800, 15)])
+    lrs, lrs_scaled = [], []
+    for e in epochs:
+        lr_sched.adjust_learning_rate(Opt, float(e), args)
+        lrs.append(Opt.param_groups[0]["lr"])
+        lrs_scaled.append(Opt.param_groups[1]["lr"])
+    np.savez_compressed(os.path.join(HERE, "g_lr_sched.npz"), epochs=epochs, lr=np.array(lrs),
+                        lr_scaled=np.array(lrs_scaled), base_lr=np.array(args.lr),
+                        min_lr=np.array(0.0), warmup_epochs=np.array(40),
+                        total_epochs=np.array(800))
+    print("lr_sched ok")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-curve", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    ref_mae = import_reference_mae()
+    jobs = {
+        "g1": lambda: g1_masking(ref_mae), "g2": lambda: g2_patchify(ref_mae), "g3": g3_sincos,
+        "g5tiny": lambda: g5_tiny(ref_mae), "g5vitb": lambda: g5_vitb(ref_mae),
+        "lr": g_lr_sched,
+        "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
+            **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
+            "g5_curve_tiny.npz"),
+        "curve_vitb": lambda: curve(ref_mae, mae_ref.MAEConfig(
+            **{**mae_ref.VIT_B.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
+            "g5_curve_vitb.npz"),
+    }
+    for name, fn in jobs.items():
+        if a.only and name not in a.only.split(","):
+            continue
+        if a.skip_curve and name == "curve_vitb":
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()
