@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MAE ViT-B pretraining step (BASELINE.json configs[1]) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = forward + backward of MaskedAutoencoderViT (ViT-B encoder on 25 % of the tokens, 8x512-d
+decoder on all 197, masked-MSE loss with norm_pix_loss) on a fixed synthetic batch of 256 images
+per GPU (N(0,1) pixels, resident in HBM), gradient averaging across ranks (bucketed RCCL all-reduce
+overlapped with backward, ssl4gie_amd.parallel), AdamW(b=(0.9,0.95), wd 0.05) step.  bf16 MFMA
+operands, fp32 accumulate / residual / statistics.  Prints ONE JSON line on rank 0.
+
+Extra objects on the line:
+  roofline      dominant kernel (bf16 NT GEMM, v_mfma_f32_16x16x32_bf16): algorithmic FLOPs (2MNK
+                summed over its launches) / summed launch durations, measured with HIP events on
+                the launch stream by the library's launch profiler over `--prof-steps` further
+                steps of the same workload (kept out of the timed region so that event records do
+                not perturb `value`).  peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (oracle/mae_ref.py: fp32 torch restatement of the reference's
+                MaskedAutoencoderViT step, validated against reference-generated fixtures) timed
+                on this box's host cores at bs=8 (BASELINE.json configs[0]); rank 0, N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "images/sec/GPU (fwd+bwd) ViT-B 224² bs=256 at 1/2/4/8 MI355X; % MFMA peak"
+GFLOP_PER_IMG = 58.69     # MAE ViT-B fwd+bwd, GEMM terms only (SURVEY §8d / BASELINE.md §2)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def param_groups(model, wd=0.05):
+    """timm add_weight_decay semantics used by the reference driver (main_pretrain.py:179)."""
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.ndim <= 1 or n.endswith(".bias")) else decay).append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": wd}]
+
+
+def cpu_baseline(steps=8, warmup=2, b=8):
+    """CPU oracle step (fwd + bwd + AdamW) on the host cores; bounded sample (~10-30 s)."""
+    from oracle import mae_ref, synth
+    cfg = mae_ref.MAEConfig(**{**mae_ref.VIT_B.__dict__, "norm_pix_loss": True})
+    sd = synth.mae_state_dict(cfg, 0)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if "pos_embed" not in k}
+    full = dict(sd)
+    full.update(params)
+    decay = [v for k, v in params.items() if v.ndim > 1 and not k.endswith(".bias")]
+    nodecay = [v for k, v in params.items() if not (v.ndim > 1 and not k.endswith(".bias"))]
+    opt = torch.optim.AdamW([{"params": nodecay, "weight_decay": 0.0},
+                             {"params": decay, "weight_decay": 0.05}], lr=1.5e-4, betas=(0.9, 0.95))
+    imgs = synth.synth_images(b, cfg, seed=0)
+    noise = synth.synth_noise(b, 196, seed=0)
+    t0 = None
+    for it in range(warmup + steps):
+        if it == warmup:
+            t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss, _, _, _ = mae_ref.mae_forward(full, cfg, imgs, noise)
+        loss.backward()
+        opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": round(b * steps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "s_per_step": round(dt / steps, 4),
+            "sample": f"{steps} steps of MAE ViT-B fwd+bwd+AdamW at bs={b}, fp32, "
+                      f"CPU oracle (oracle/mae_ref.py), {warmup} warm-up steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    from ssl4gie_amd import _lib, parallel
+    from ssl4gie_amd.Models.mae import models_mae
+
+    _lib.load()  # the HIP extension is mandatory
+    rank, local, world = parallel.init_from_env()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    torch.manual_seed(0)
+    model = models_mae.mae_vit_base_patch16(norm_pix_loss=True).to(dev).set_precision(a.precision)
+    ddp = parallel.DataParallel(model) if world > 1 else None
+    try:
+        opt = torch.optim.AdamW(param_groups(model), lr=1.5e-4, betas=(0.9, 0.95), fused=True)
+    except Exception:
+        opt = torch.optim.AdamW(param_groups(model), lr=1.5e-4, betas=(0.9, 0.95))
+
+    g = torch.Generator("cpu").manual_seed(0 + rank)  # seed + rank (main_pretrain.py:116)
+    imgs = torch.randn(a.batch, 3, 224, 224, generator=g).pin_memory().to(dev, non_blocking=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _, _ = (ddp or model)(imgs, mask_ratio=0.75)
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    final_loss = float(loss)
+
+    # ---- roofline pass (instrumented; outside the timed region)
+    L = _lib.load()
+    roof = None
+    kinds = ["gemm_bf16_nt", "gemm_bf16_tn", "attn_fwd_bf16", "attn_bwd_bf16", "gemm_generic"]
+    if a.prof_steps > 0:
+        _lib.check(L.ssl4gie_prof_begin(2000 * a.prof_steps), "prof_begin")
+        for _ in range(a.prof_steps):
+            step()
+        ms = (ctypes.c_double * 5)()
+        fl = (ctypes.c_double * 5)()
+        nl = (ctypes.c_longlong * 5)()
+        _lib.check(L.ssl4gie_prof_collect(ms, fl, nl), "prof_collect")
+        L.ssl4gie_prof_end()
+        per = {k: {"launches_per_step": nl[i] // a.prof_steps,
+                   "ms_per_step": round(ms[i] / a.prof_steps, 3),
+                   "avg_launch_us": round(1e3 * ms[i] / max(nl[i], 1), 2),
+                   "tflops": round(fl[i] / max(ms[i], 1e-9) / 1e9, 1)}
+               for i, k in enumerate(kinds) if nl[i]}
+        dom = max(range(5), key=lambda i: ms[i])
+        ach = fl[dom] / max(ms[dom], 1e-9) / 1e9
+        roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": round(ach, 1),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "avg_launch_us": per[kinds[dom]]["avg_launch_us"],
+                "launches_per_step": per[kinds[dom]]["launches_per_step"], "kernels": per}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ips = a.batch * world * a.steps / dt
+        line = {
+            "metric": METRIC, "value": round(ips, 1), "unit": "images/sec", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "ViT-B MAE pretrain (mae_vit_base_patch16, norm_pix_loss, "
+                                   "mask 0.75) fwd+bwd+grad-allreduce+AdamW, 224x224 synthetic "
+                                   "N(0,1) images resident in HBM",
+                       "batch_per_gpu": a.batch, "global_batch": a.batch * world,
+                       "parallelism": f"dp{world}", "optimizer": "AdamW(0.9,0.95) wd 0.05"},
+            "images_per_sec_per_gpu": round(ips / world, 1),
+            "model_mfma_frac": round(ips / world * GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(final_loss, 5),
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,10 @@ int ssl4gie_attn_bwd(const void* qkv, const void* out, const void* dout, const f
 int ssl4gie_cast(const float* src, void* dst, int dst_dtype, long long n, void* stream);
 int ssl4gie_cast_transpose(const float* src, void* dst, int dst_dtype, int rows, int cols,
                            void* stream);
+/* out = a + b (b may be NULL), optionally also written as an operand-type copy out_lp:
+ * plumbing of the fp32 residual-gradient stream (tap gradients, models.py:450-454). n % 4 == 0 */
+int ssl4gie_add_cast(const float* a, const float* b, float* out, void* out_lp, int lp_dtype,
+                     long long n, void* stream);
 
 /* ---------------------------------------------------------------- MAE glue
  * random_masking (models_mae.py:123-148): stable argsort of fp32 noise [B, L] ->
@@ -135,14 +139,15 @@ size_t ssl4gie_decoder_assemble_bwd_workspace_bytes(int B, int L, int D);
 int ssl4gie_decoder_assemble_bwd(const float* dxd, const long long* ids_shuffle, void* dy,
                                  int dy_dtype, float* dmask_token, int accumulate,
                                  float* workspace, int B, int L, int nkeep, int D, void* stream);
-/* forward_loss (models_mae.py:198-214) and its gradient.  pred fp32 [B, 1+L, P] (row 0 of each
- * sample = cls, ignored), img fp32 NCHW, mask [B, L] (1 = removed).
+/* forward_loss (models_mae.py:198-214) and its gradient.  pred fp32 [B, has_cls+L, P] (with
+ * has_cls=1 row 0 of each sample is the cls prediction and is ignored: decoder_pred runs on all
+ * 1+L tokens, models_mae.py:191-194), img fp32 NCHW, mask [B, L] (1 = removed).
  *   per_patch (optional) [B, L] = mask * mean_k (pred - target)^2   (host sums / mask.sum())
- *   dpred (optional) [B, 1+L, P] = gscale_host * gscale_dev[0] * mask * 2 (pred-target) / P,
- *   cls rows zeroed; gscale_dev may be NULL (=1): the upstream scalar gradient on device. */
+ *   dpred (optional, same shape as pred) = gscale_host * gpp[b,l] * mask * 2 (pred-target) / P, cls rows
+ *   zeroed; gpp [B, L] is the upstream gradient of per_patch (NULL = 1). */
 int ssl4gie_mae_loss(const float* pred, const float* img, const float* mask, float* per_patch,
-                     float* dpred, const float* gscale_dev, float gscale_host, int norm_pix,
-                     int B, int C, int H, int W, int p, void* stream);
+                     float* dpred, const float* gpp, float gscale_host, int norm_pix,
+                     int has_cls, int B, int C, int H, int W, int p, void* stream);
 
 /* ---------------------------------------------------------------- transformer-block executor
  * One timm Block: x += proj(attn(norm1(x))); x += fc2(gelu(fc1(norm2(x)))).
@@ -188,6 +193,17 @@ int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* 
                       const float* x_in, const float* dx_out, const void* dx_out_lp,
                       float* dx_in, void* dx_in_lp, int accumulate, void* workspace,
                       void* stream);
+
+/* ---------------------------------------------------------------- launch profiler (bench.py)
+ * HIP events on the launch stream around every launch of the heavy kernels, used for the
+ * `roofline` object of the bench line.  Process-global, not thread-safe, off by default.
+ * kinds: 0 bf16 NT GEMM, 1 bf16 TN GEMM (kernel only, not its slab reduction), 2 fused attention
+ * fwd, 3 fused attention bwd, 4 generic f32-MFMA GEMM.  flops are algorithmic (2MNK; attention
+ * 4 B H N^2 hd forward, 10 B H N^2 hd backward). */
+#define SSL4GIE_PROF_KINDS 5
+int ssl4gie_prof_begin(int max_launches);
+int ssl4gie_prof_collect(double* ms, double* flops, long long* launches);
+int ssl4gie_prof_end(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,201 @@
+"""Finetune model zoo on the MI355X engine — mirrors the constructor API of the reference's
+`Models/models.py` for the ViT-B backbones:
+
+    ViT_from_MAE(weight_path, head, num_classes, frozen, dense, det, fixed_size, embed_dim, depth,
+                 num_heads, out_token)                                  reference :360-475
+    VisionTransformer_from_Any(head, num_classes, frozen, dense, det, fixed_size, embed_dim, depth,
+                 num_heads, out_token, ImageNet_weights=False)          reference :262-356
+    ViT_from_MoCoV3(weight_path, head, num_classes, frozen, dense, det, fixed_size, embed_dim,
+                 out_token)                                             reference :478-578
+
+state_dict keys are the reference's (`cls_token, pos_embed, patch_embed.proj.*, blocks.i.*, norm.*,
+lin_head.*`; ViT_from_MAE keeps `decoder_pos_embed`, reference :395-399).  The un-masked trunk
+(patch-embed GEMM, cls/pos assembly, 12 blocks with taps after blocks 2/5/8/11, final LayerNorm,
+linear head) runs on libssl4gie_hip.so.
+
+Scope of this round: `dense=None, det=False` is complete; with `dense`
+set, `forward_features` returns the four tap tensors (the DPT_decoder head is the next §8 row) and
+`det=True` (windowed attention + ViTDet FPN, §8f rank 1) raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from ..engine import EngineModule, PatchEmbedFn
+from .mae.util.pos_embed import get_2d_sincos_pos_embed
+from .vit_layers import Block, PatchEmbed
+
+TAP_BLOCKS = (2, 5, 8, 11)  # reference models.py:453
+
+
+class _ViTBackbone(EngineModule):
+    """Shared trunk: patch-embed -> [cls | tokens] + pos -> blocks (-> taps) -> norm -> readout."""
+
+    def _build_trunk(self, embed_dim, depth, num_heads, img_size=224, patch_size=16, in_chans=3,
+                     mlp_ratio=4.0):
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        n = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, embed_dim))
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=True,
+                                           norm_layer=norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+
+    def _finish(self, head, num_classes, frozen, dense, det, fixed_size, out_token):
+        if det:
+            raise NotImplementedError("det=True (WindowedAttention + ViTDet_FPN, reference "
+                                      "models.py:155-259) is a later §8(f) row of this build")
+        if dense:
+            raise NotImplementedError("dense heads (DPT_decoder, reference DPT_decoder.py:315) are "
+                                      "the next §8 row of this build; use forward_features for "
+                                      "the four tap tensors")
+        self.head_flag = head
+        if head:
+            self.lin_head = nn.Linear(self.embed_dim, num_classes)
+        self.frozen = frozen
+        self.dense = dense
+        self.det = det
+        self.out_token = out_token
+
+    def _trunk(self, imgs, dense):
+        self._prepare()
+        p = self.patch_embed.patch_size[0]
+        assert imgs.shape[2:] == tuple(self.patch_embed.img_size), "input size mismatch"
+        tok = PatchEmbedFn.apply(imgs.float(), self.patch_embed.proj.weight,
+                                 self.patch_embed.proj.bias, self.cls_token, self.pos_embed, None,
+                                 self.patch_embed.num_patches, p, self.dtype_, self.sink(), self._lp)
+        taps = TAP_BLOCKS if dense else ()
+        tok, tap_out = self._blocks(self.blocks, tok, self.num_heads, self.norm.eps, taps=taps)
+        if dense:
+            return tap_out  # fp32 [B, 1+L, D] each; final norm skipped (reference :456)
+        return self._ln(tok, self.norm, out_dtype=torch.float32)
+
+    def _readout(self, x):
+        if self.out_token == "cls":
+            x = x[:, 0]
+        elif self.out_token == "spatial":
+            x = x[:, 1:].mean(1)
+        if self.head_flag:
+            x = self._linear(x.to(self.dtype_).contiguous(), self.lin_head, out_dtype=torch.float32)
+        return x
+
+    def forward_features(self, x, dense=None):
+        return self._trunk(x, self.dense if dense is None else dense)
+
+    def forward(self, imgs):
+        if self.frozen:
+            with torch.no_grad():
+                x = self.forward_features(imgs)
+        else:
+            x = self.forward_features(imgs)
+        return self._readout(x)
+
+
+class ViT_from_MAE(_ViTBackbone):
+    def __init__(self, weight_path, head, num_classes, frozen, dense, det, fixed_size, embed_dim,
+                 depth, num_heads, out_token):
+        super().__init__()
+        self._build_trunk(embed_dim, depth, num_heads)
+        n = self.patch_embed.num_patches
+        # MAE leftovers that stay in the state_dict (reference deletes the decoder modules but not
+        # decoder_pos_embed, models.py:395-399) and fixed sin-cos tables
+        self.pos_embed.requires_grad = False
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, n + 1, 512), requires_grad=False)
+        grid = int(n ** .5)
+        with torch.no_grad():
+            self.pos_embed.copy_(torch.from_numpy(
+                get_2d_sincos_pos_embed(embed_dim, grid, cls_token=True)).float()[None])
+            self.decoder_pos_embed.copy_(torch.from_numpy(
+                get_2d_sincos_pos_embed(512, grid, cls_token=True)).float()[None])
+            w = self.patch_embed.proj.weight
+            nn.init.xavier_uniform_(w.view(w.shape[0], -1))
+            nn.init.normal_(self.cls_token, std=.02)
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.xavier_uniform_(m.weight)
+                    nn.init.zeros_(m.bias)
+        if weight_path is not None:
+            weights = torch.load(weight_path, map_location="cpu")["model"]
+            self.load_my_state_dict(weights)
+        self._finish(head, num_classes, frozen, dense, det, fixed_size, out_token)
+
+    def load_my_state_dict(self, state_dict):
+        """Copy every tensor whose name we own; ignore the rest (reference :417-425)."""
+        own = self.state_dict()
+        hits = 0
+        with torch.no_grad():
+            for name, value in state_dict.items():
+                if name in own:
+                    own[name].copy_(value)
+                    hits += 1
+        print(f"Successfully loaded params for {hits} items")
+
+    def forward_encoder(self, x):
+        return self.forward_features(x)
+
+
+class VisionTransformer_from_Any(_ViTBackbone):
+    def __init__(self, head, num_classes, frozen, dense, det, fixed_size, embed_dim, depth,
+                 num_heads, out_token, ImageNet_weights=False):
+        super().__init__()
+        if ImageNet_weights:
+            raise RuntimeError("ImageNet augreg weights are downloaded by the reference "
+                               "(models.py:286-290); no network here — load a state_dict instead")
+        self._build_trunk(embed_dim, depth, num_heads)
+        with torch.no_grad():  # timm default init
+            nn.init.trunc_normal_(self.pos_embed, std=.02, a=-2.0, b=2.0)
+            nn.init.normal_(self.cls_token, std=1e-6)
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.trunc_normal_(m.weight, std=.02, a=-2.0, b=2.0)
+                    nn.init.zeros_(m.bias)
+        self._finish(head, num_classes, frozen, dense, det, fixed_size, out_token)
+
+
+class ViT_from_MoCoV3(_ViTBackbone):
+    def __init__(self, weight_path, head, num_classes, frozen, dense, det, fixed_size, embed_dim,
+                 out_token):
+        super().__init__()
+        self._build_trunk(embed_dim, 12, 12)
+        self.pos_embed.requires_grad = False
+        with torch.no_grad():
+            self.pos_embed.copy_(moco_sincos_pos_embed(embed_dim, self.patch_embed.grid_size))
+            # MoCo-v3 init (reference Models/moco_v3/vits.py:31-47)
+            for name, m in self.named_modules():
+                if isinstance(m, nn.Linear):
+                    if "qkv" in name:
+                        val = math.sqrt(6. / float(m.weight.shape[0] // 3 + m.weight.shape[1]))
+                        nn.init.uniform_(m.weight, -val, val)
+                    else:
+                        nn.init.xavier_uniform_(m.weight)
+                    nn.init.zeros_(m.bias)
+            nn.init.normal_(self.cls_token, std=1e-6)
+            ps = self.patch_embed.patch_size
+            val = math.sqrt(6. / float(3 * ps[0] * ps[1] + embed_dim))
+            nn.init.uniform_(self.patch_embed.proj.weight, -val, val)
+            nn.init.zeros_(self.patch_embed.proj.bias)
+        if weight_path is not None:
+            self.load_state_dict(torch.load(weight_path, map_location="cpu"))
+        self._finish(head, num_classes, frozen, dense, det, fixed_size, out_token)
+
+
+def moco_sincos_pos_embed(embed_dim, grid_size, temperature=10000.):
+    """Reference Models/moco_v3/vits.py:53-69: fp32, channels [sin w | cos w | sin h | cos h] with
+    the first grid axis slowest (ij meshgrid), zero cls row."""
+    h, w = grid_size
+    gw, gh = torch.meshgrid(torch.arange(w, dtype=torch.float32),
+                            torch.arange(h, dtype=torch.float32), indexing="ij")
+    assert embed_dim % 4 == 0
+    pd = embed_dim // 4
+    omega = 1. / (temperature ** (torch.arange(pd, dtype=torch.float32) / pd))
+    ow = gw.flatten()[:, None] * omega[None]
+    oh = gh.flatten()[:, None] * omega[None]
+    emb = torch.cat([ow.sin(), ow.cos(), oh.sin(), oh.cos()], dim=1)[None]
+    return torch.cat([torch.zeros(1, 1, embed_dim), emb], dim=1)

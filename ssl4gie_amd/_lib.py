@@ -1,0 +1,120 @@
+"""ctypes binding of libssl4gie_hip.so (the C ABI declared in include/ssl4gie_hip.h).
+
+The library is built in-tree by `ssl4gie_amd/csrc/Makefile` (see `__graft_entry__.build()`).  There
+is NO fallback: if the shared object is missing or a call fails, we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssl4gie_hip.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU = range(5)
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", i32), ("N", i32), ("K", i32), ("batch1", i32), ("batch2", i32),
+        ("A", vp), ("sAm", i64), ("sAk", i64), ("sAb1", i64), ("sAb2", i64),
+        ("B", vp), ("sBk", i64), ("sBn", i64), ("sBb1", i64), ("sBb2", i64),
+        ("C", vp), ("ldc", i64), ("sCb1", i64), ("sCb2", i64),
+        ("dtype_ab", i32), ("dtype_c", i32), ("alpha", f32), ("epilogue", i32),
+        ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("out2", vp),
+        ("accumulate", i32),
+    ]
+
+
+_W_F32 = ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "bqkv", "bproj", "bfc1", "bfc2")
+_W_LP = ("wqkv", "wproj", "wfc1", "wfc2", "wqkv_t", "wproj_t", "wfc1_t", "wfc2_t")
+_G_ALL = _W_F32 + ("wqkv", "wproj", "wfc1", "wfc2")
+_ACT = ("mean1", "rstd1", "mean2", "rstd2", "h1", "qkv", "attn", "lse", "xmid", "h2", "u", "g")
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, vp) for n in _W_F32 + _W_LP]
+
+
+class BlockGrads(C.Structure):
+    _fields_ = [(n, vp) for n in _G_ALL]
+
+
+class BlockAct(C.Structure):
+    _fields_ = [(n, vp) for n in _ACT]
+
+
+class BlockDims(C.Structure):
+    _fields_ = [("B", i32), ("N", i32), ("D", i32), ("H", i32), ("F", i32), ("dtype", i32),
+                ("eps", f32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/ssl4gie_hip.h
+PROTOTYPES = {
+    "ssl4gie_abi_version": (i32, []),
+    "ssl4gie_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp]),
+    "ssl4gie_layernorm_bwd_workspace_bytes": (sz, [i32, i32]),
+    "ssl4gie_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp,
+                                    i32, i32, vp]),
+    "ssl4gie_colsum_workspace_bytes": (sz, [i32, i32]),
+    "ssl4gie_colsum": (i32, [vp, i32, vp, i32, vp, i32, i32, i64, vp]),
+    "ssl4gie_gemm_workspace_bytes": (sz, [C.POINTER(GemmDesc)]),
+    "ssl4gie_gemm": (i32, [C.POINTER(GemmDesc), vp, sz, vp]),
+    "ssl4gie_attn_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "ssl4gie_attn_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "ssl4gie_attn_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "ssl4gie_cast": (i32, [vp, vp, i32, i64, vp]),
+    "ssl4gie_cast_transpose": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ssl4gie_add_cast": (i32, [vp, vp, vp, vp, i32, i64, vp]),
+    "ssl4gie_mask_argsort": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ssl4gie_patch_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp]),
+    "ssl4gie_tokens_assemble": (i32, [vp, i32, vp, vp, vp, i64, vp, i32, i32, i32, vp]),
+    "ssl4gie_tokens_assemble_bwd": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_decoder_assemble": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_decoder_assemble_bwd_workspace_bytes": (sz, [i32, i32, i32]),
+    "ssl4gie_decoder_assemble_bwd": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_mae_loss": (i32, [vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_prof_begin": (i32, [i32]),
+    "ssl4gie_prof_collect": (i32, [vp, vp, vp]),
+    "ssl4gie_prof_end": (i32, []),
+    "ssl4gie_block_workspace_bytes": (sz, [C.POINTER(BlockDims)]),
+    "ssl4gie_block_fwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockWeights),
+                                C.POINTER(BlockAct), vp, vp, vp, vp]),
+    "ssl4gie_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockWeights),
+                                C.POINTER(BlockAct), C.POINTER(BlockGrads), vp, vp, vp, vp, vp,
+                                i32, vp, vp]),
+}
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object (once).  Raises HipExtensionMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: build it with `make -C ssl4gie_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "ssl4gie_amd has no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = "invalid argument" if rc == 1000 else f"hipError_t {rc}"
+        raise RuntimeError(f"libssl4gie_hip: {what} failed ({kind})")

@@ -21,6 +21,7 @@
 // strided-batched f32-MFMA GEMM + row softmax kernels below (exact fp32).
 #include "common.h"
 #include "ssl4gie_hip.h"
+#include "prof.h"
 
 #include <math.h>
 #include <string.h>
@@ -82,7 +83,7 @@ DEVI float group_sum(float v) {
 
 // ------------------------------------------------------------------ forward
 template <int HD, int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                             bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int N, int H,
                                                             float scale) {
@@ -370,6 +371,7 @@ static int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int 
     auto k = attn_fwd_bf16_kernel<HD, NKT>;
     if (lds > 65536)
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * HD, st);
     hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse,
                        N, H, scale);
     LAUNCH_CHECK();
@@ -382,6 +384,7 @@ static int launch_bwd(const void* qkv, const void* out, const void* dout, const 
     auto k = attn_bwd_bf16_kernel<HD, NKT>;
     if (lds > 65536)
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * HD, st);
     hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
     LAUNCH_CHECK();

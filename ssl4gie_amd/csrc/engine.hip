@@ -15,8 +15,51 @@
 #include "ssl4gie_hip.h"
 
 #include <string.h>
+#include <stdlib.h>
+#include "prof.h"
 
 extern "C" int ssl4gie_abi_version(void) { return 1; }
+
+// ---- launch profiler (bench only; see prof.h)
+ProfState g_prof = {false, 0, 0, nullptr, nullptr, nullptr};
+
+extern "C" int ssl4gie_prof_begin(int max_launches) {
+    REQUIRE(max_launches > 0 && !g_prof.ev);
+    g_prof.ev = (hipEvent_t*)calloc((size_t)2 * max_launches, sizeof(hipEvent_t));
+    g_prof.kind = (int*)calloc(max_launches, sizeof(int));
+    g_prof.flops = (double*)calloc(max_launches, sizeof(double));
+    REQUIRE(g_prof.ev && g_prof.kind && g_prof.flops);
+    for (int i = 0; i < 2 * max_launches; ++i) HIP_RET(hipEventCreate(&g_prof.ev[i]));
+    g_prof.cap = max_launches;
+    g_prof.n = 0;
+    g_prof.on = true;
+    return 0;
+}
+// Synchronises the device, sums elapsed ms / flops / launch counts per kernel kind
+// (arrays of SSL4GIE_PROF_KINDS entries), resets the record list; profiling stays on.
+extern "C" int ssl4gie_prof_collect(double* ms, double* flops, long long* launches) {
+    REQUIRE(g_prof.ev && ms && flops && launches);
+    HIP_RET(hipDeviceSynchronize());
+    for (int k = 0; k < PROF_KINDS; ++k) { ms[k] = 0; flops[k] = 0; launches[k] = 0; }
+    for (int i = 0; i < g_prof.n; ++i) {
+        float t = 0.f;
+        HIP_RET(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+        ms[g_prof.kind[i]] += t;
+        flops[g_prof.kind[i]] += g_prof.flops[i];
+        launches[g_prof.kind[i]] += 1;
+    }
+    g_prof.n = 0;
+    return 0;
+}
+extern "C" int ssl4gie_prof_end(void) {
+    g_prof.on = false;
+    if (g_prof.ev) {
+        for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+        free(g_prof.ev); free(g_prof.kind); free(g_prof.flops);
+    }
+    g_prof = ProfState{false, 0, 0, nullptr, nullptr, nullptr};
+    return 0;
+}
 
 namespace {
 

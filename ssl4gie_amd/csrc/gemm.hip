@@ -20,6 +20,7 @@
 // sites Models/mae/models_mae.py:39-41,47,53-55,59 and Models/models.py:171-173.
 #include "common.h"
 #include "ssl4gie_hip.h"
+#include "prof.h"
 
 struct EpiArgs {
     float alpha;
@@ -206,6 +207,26 @@ DEVI void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Same LDS-DMA issued from inline asm: invisible to hipcc's waitcnt pass, which otherwise puts a
+// conservative `s_waitcnt vmcnt(0)` in front of the ds_read_b64_tr_b16 stream (the prefetch would
+// then serialise with the MFMAs).  The caller owns the vmcnt accounting.  M0 is saved/restored
+// inside the statement (cdna_hip_programming.md §5.7).
+DEVI void glds16_asm(const void* gsrc, unsigned lds_wave_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_wave_addr)
+        : "memory");
+}
+DEVI unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 // ---- NT --------------------------------------------------------------------------------
 // LDS image of an operand tile: 128 rows x 128 B; the 16-B chunk at position p of row r holds
 // global chunk p ^ ((r>>1)&7)  (swizzle applied on the glds SOURCE address and again on the
@@ -280,13 +301,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
 
     const int nk = K / BT_K;
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int kt = 0; kt < nk - 1; ++kt) {
         stage(cur ^ 1, kt + 1);  // LDS-DMA of the next tile flies under this tile's MFMAs
         compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
     }
@@ -351,17 +372,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(
         acol[i] = ca * 8;
         bcol[i] = cb * 8;
     }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 4096);
     auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * BT_STAGE_BYTES + wave * 4096;
+        const unsigned base = lds0 + buf * BT_STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int gk = kt * BT_K + krow[i]; gk = gk < K ? gk : K - 1;
-            glds16(At + (size_t)gk * ldat + acol[i], base + i * 1024);
+            glds16_asm(At + (size_t)gk * ldat + acol[i], base + i * 1024);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int gk = kt * BT_K + krow[i]; gk = gk < K ? gk : K - 1;
-            glds16(Bt + (size_t)gk * ldbt + bcol[i], base + BT_TILE_BYTES + i * 1024);
+            glds16_asm(Bt + (size_t)gk * ldbt + bcol[i], base + BT_TILE_BYTES + i * 1024);
         }
     };
     // zero the k-rows of a tail tile that lie beyond K (sources were clamped)
@@ -406,13 +428,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(
 
     if (kt0 < kt1) {
         stage(0, kt0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int cur = 0;
         for (int kt = kt0; kt < kt1 - 1; ++kt) {
             stage(cur ^ 1, kt + 1);
             compute(cur);  // tiles before the last are always full
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             cur ^= 1;
         }
@@ -510,6 +532,7 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     if (nt_ok(d)) {
         const int tm = (d->M + BT_M - 1) / BT_M, tn = (d->N + BT_N - 1) / BT_N;
         dim3 grid(tm * tn), block(256);
+        ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
         if (d->dtype_c == SSL4GIE_BF16)
             hipLaunchKernelGGL(gemm_bf16_nt_kernel<bf16_t>, grid, block, BT_LDS_BYTES, st,
                                (const bf16_t*)d->A, d->sAm, (const bf16_t*)d->B, d->sBn,
@@ -527,6 +550,7 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
         if (splits > 1)
             REQUIRE(workspace && workspace_bytes >= (size_t)splits * d->M * d->N * sizeof(float));
         dim3 grid(tm * tn * splits), block(256);
+        ProfScope prof(PROF_GEMM_TN, 2.0 * d->M * d->N * d->K, st);
         hipLaunchKernelGGL(gemm_bf16_tn_kernel, grid, block, BT_LDS_BYTES, st,
                            (const bf16_t*)d->A, d->sAk, (const bf16_t*)d->B, d->sBk,
                            (float*)d->C, d->ldc, (float*)workspace, d->M, d->N, d->K, tn,
@@ -551,6 +575,7 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     dim3 grid((d->N + GT_N - 1) / GT_N, (d->M + GT_M - 1) / GT_M, d->batch1 * d->batch2);
     dim3 block(256);
     REQUIRE(grid.y <= 65535 && grid.z <= 65535);
+    ProfScope prof(PROF_GEMM_GENERIC, 2.0 * d->M * d->N * d->K * d->batch1 * d->batch2, st);
     if (d->dtype_ab == SSL4GIE_F32 && d->dtype_c == SSL4GIE_F32)
         hipLaunchKernelGGL((gemm_generic_kernel<float, float>), grid, block, 0, st, g);
     else if (d->dtype_ab == SSL4GIE_BF16 && d->dtype_c == SSL4GIE_BF16)

@@ -67,6 +67,32 @@ extern "C" int ssl4gie_cast_transpose(const float* src, void* dst, int dst_dtype
     return 0;
 }
 
+// out = a (+ b); optional operand-type copy (residual-gradient stream plumbing)
+template <typename T>
+__global__ void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                float* __restrict__ out, T* __restrict__ out_lp, long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 v = ld4(a + i);
+    if (b) v += ld4(b + i);
+    if (out) st4(out + i, v);
+    if (out_lp) st4(out_lp + i, v);
+}
+extern "C" int ssl4gie_add_cast(const float* a, const float* b, float* out, void* out_lp,
+                                int lp_dtype, long long n, void* stream) {
+    REQUIRE(a && n >= 0 && n % 4 == 0 && (out || out_lp));
+    REQUIRE(!out_lp || lp_dtype == SSL4GIE_F32 || lp_dtype == SSL4GIE_BF16);
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((n / 4 + 255) / 256);
+    if (out_lp && lp_dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(add_cast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, a, b, out, (bf16_t*)out_lp, n);
+    else
+        hipLaunchKernelGGL(add_cast_kernel<float>, dim3(blocks), dim3(256), 0, st, a, b, out, (float*)out_lp, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------ random masking (integer)
 // Stable ascending argsort by counting: rank(i) = #{j : x_j < x_i  or (x_j == x_i and j < i)}.
 // ids_restore[i] = rank(i), ids_shuffle[rank(i)] = i, mask[i] = rank(i) >= len_keep.
@@ -326,20 +352,20 @@ extern "C" int ssl4gie_decoder_assemble_bwd(const float* dxd, const long long* i
 template <int NV>
 __global__ __launch_bounds__(256) void mae_loss_kernel(
     const float* __restrict__ pred, const float* __restrict__ img, const float* __restrict__ mask,
-    float* __restrict__ per_patch, float* __restrict__ dpred, const float* __restrict__ gscale_dev,
-    float gscale_host, int norm_pix, int B, int C, int H, int W, int p) {
+    float* __restrict__ per_patch, float* __restrict__ dpred, const float* __restrict__ gpp,
+    float gscale_host, int norm_pix, int has_cls, int B, int C, int H, int W, int p) {
     const int lane = threadIdx.x & 63;
-    const int gw = W / p, L = (H / p) * gw, P = C * p * p;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*(L+1)
-    if (row >= (long long)B * (L + 1)) return;
-    const int b = (int)(row / (L + 1)), t = (int)(row % (L + 1));
+    const int gw = W / p, L = (H / p) * gw, P = C * p * p, R = L + has_cls;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*R
+    if (row >= (long long)B * R) return;
+    const int b = (int)(row / R), t = (int)(row % R);
     float* dr = dpred ? dpred + (size_t)row * P : nullptr;
-    if (t == 0) {  // cls row: no loss, zero gradient
+    if (has_cls && t == 0) {  // cls row: no loss, zero gradient
         if (dr)
             for (int k = lane; k < P; k += 64) dr[k] = 0.f;
         return;
     }
-    const int l = t - 1, gy = l / gw, gx = l % gw;
+    const int l = t - has_cls, gy = l / gw, gx = l % gw;
     const float* ib = img + (size_t)b * C * H * W;
     const float* pr = pred + (size_t)row * P;
     float tv[NV], pv[NV];
@@ -380,32 +406,33 @@ __global__ __launch_bounds__(256) void mae_loss_kernel(
     e = wave_sum(e) / (float)P;
     if (per_patch && lane == 0) per_patch[(size_t)b * L + l] = e * m;
     if (dr) {
-        const float gs = gscale_host * (gscale_dev ? gscale_dev[0] : 1.f) * m * 2.0f / (float)P;
+        const float gs = gscale_host * (gpp ? gpp[(size_t)b * L + l] : 1.f) * m * 2.0f / (float)P;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (lane + 64 * i < P) dr[lane + 64 * i] = gs * (pv[i] - tv[i]);
     }
 }
 extern "C" int ssl4gie_mae_loss(const float* pred, const float* img, const float* mask,
-                                float* per_patch, float* dpred, const float* gscale_dev,
-                                float gscale_host, int norm_pix, int B, int C, int H, int W, int p,
-                                void* stream) {
+                                float* per_patch, float* dpred, const float* gpp,
+                                float gscale_host, int norm_pix, int has_cls, int B, int C, int H,
+                                int W, int p, void* stream) {
     REQUIRE(pred && img && mask && B >= 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0);
+    REQUIRE(has_cls == 0 || has_cls == 1);
     const int P = C * p * p;
     REQUIRE(P <= 64 * 16);
     if (B == 0) return 0;
-    const long long rows = (long long)B * ((H / p) * (W / p) + 1);
+    const long long rows = (long long)B * ((H / p) * (W / p) + has_cls);
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (P <= 64 * 4)
         hipLaunchKernelGGL(mae_loss_kernel<4>, grid, block, 0, st, pred, img, mask, per_patch, dpred,
-                           gscale_dev, gscale_host, norm_pix, B, C, H, W, p);
+                           gpp, gscale_host, norm_pix, has_cls, B, C, H, W, p);
     else if (P <= 64 * 12)
         hipLaunchKernelGGL(mae_loss_kernel<12>, grid, block, 0, st, pred, img, mask, per_patch,
-                           dpred, gscale_dev, gscale_host, norm_pix, B, C, H, W, p);
+                           dpred, gpp, gscale_host, norm_pix, has_cls, B, C, H, W, p);
     else
         hipLaunchKernelGGL(mae_loss_kernel<16>, grid, block, 0, st, pred, img, mask, per_patch,
-                           dpred, gscale_dev, gscale_host, norm_pix, B, C, H, W, p);
+                           dpred, gpp, gscale_host, norm_pix, has_cls, B, C, H, W, p);
     LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,511 @@
+"""Host-side execution engine: parameter arena, operand-copy cache, and the autograd glue that
+hands whole sub-graphs (a stack of transformer blocks, patch embedding, token assembly, loss) to
+the native HIP library.  torch supplies device memory, streams and the autograd tape only.
+
+Precision modes (module attribute `engine_dtype`):
+  torch.bfloat16  production: bf16 MFMA operands, fp32 accumulate, fp32 residual stream / LN /
+                  softmax statistics  (the reference runs fp16 autocast: SURVEY Appendix E)
+  torch.float32   parity: every product on the exact-fp32 MFMA path; matches the reference's CPU
+                  fp32 results to ~1e-5 and is what the golden-vector tests run.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import weakref
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import BlockAct, BlockDims, BlockGrads, BlockWeights
+
+
+def default_dtype():
+    v = os.environ.get("SSL4GIE_PRECISION", "bf16").lower()
+    return torch.float32 if v in ("fp32", "f32", "float32") else torch.bfloat16
+
+
+def _align(n, a=256):
+    return (n + a - 1) // a * a
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter / gradient arena
+# ------------------------------------------------------------------------------------------------
+class ParamArena:
+    """All parameters of a model as views of ONE flat fp32 buffer (registration order) and all
+    gradients as views of a second one: gradient buckets for the data-parallel all-reduce are
+    contiguous slices, no flatten/unflatten copies (see parallel.py)."""
+
+    def __init__(self, params: Sequence[nn.Parameter]):
+        params = [p for p in params]
+        assert params, "no parameters"
+        dev = params[0].device
+        self.params = params
+        self.offsets = []
+        off = 0
+        for p in params:
+            assert p.dtype == torch.float32 and p.device == dev
+            self.offsets.append(off)
+            off += _align(p.numel(), 64)  # 256-byte aligned slices
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._index = {}
+        with torch.no_grad():
+            for p, o in zip(params, self.offsets):
+                v = self.data[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                self._index[id(p)] = o
+        self.device = dev
+
+    def owns(self, p) -> bool:
+        o = self._index.get(id(p))
+        return o is not None and p.data_ptr() == self.data.data_ptr() + 4 * o
+
+    def intact(self) -> bool:
+        return all(self.owns(p) for p in self.params)
+
+    def grad_view(self, p) -> torch.Tensor:
+        o = self._index[id(p)]
+        return self.grad[o:o + p.numel()].view(p.shape)
+
+    def span(self, params: Sequence[nn.Parameter]):
+        """[start, end) element range of the grad arena covering `params`."""
+        os_ = [self._index[id(p)] for p in params]
+        ends = [self._index[id(p)] + _align(p.numel(), 64) for p in params]
+        return min(os_), max(ends)
+
+
+# ------------------------------------------------------------------------------------------------
+# operand-type weight copies
+# ------------------------------------------------------------------------------------------------
+class LPCache:
+    """bf16 copies W[out,in] and W^T[in,out] of fp32 master weights, refreshed when the parameter's
+    version counter or storage changes (optimizer.step / load_state_dict bump it)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, p: torch.Tensor, dtype, need_t: bool = True):
+        w2d = p.detach()
+        w2d = w2d.view(w2d.shape[0], -1)
+        if dtype == torch.float32:
+            return w2d, None
+        key = id(p)
+        ver = (p._version, p.data_ptr(), dtype)
+        ent = self._c.get(key)
+        if ent is None or ent[0] != ver or ent[3]() is not p:
+            w = ops.cast(w2d, dtype)
+            wt = ops.cast_transpose(w2d, dtype)
+            ent = (ver, w, wt, weakref.ref(p))
+            self._c[key] = ent
+        return ent[1], ent[2]
+
+
+_GLOBAL_LP = LPCache()
+
+
+# ------------------------------------------------------------------------------------------------
+# gradient sinks: where a backward writes parameter gradients
+# ------------------------------------------------------------------------------------------------
+class GradSink:
+    """Decides, per backward call, where parameter gradients are written and what is handed back
+    to autograd.  With an arena: kernels write straight into the arena slice and the slice view is
+    returned (autograd then just points p.grad at it); if p.grad already aliases the slice
+    (gradient accumulation) kernels accumulate in place and None is returned."""
+
+    def __init__(self, arena: Optional[ParamArena]):
+        self.arena = arena
+
+    def plan(self, params: Sequence[Optional[torch.Tensor]]):
+        """-> (targets, accumulate, returns) ; targets[i] is the tensor the kernel writes."""
+        live = [p for p in params if p is not None and p.requires_grad]
+        arena = self.arena
+        if arena is not None and all(arena.owns(p) for p in live):
+            views = {id(p): arena.grad_view(p) for p in live}
+            has = [p.grad is not None for p in live]
+            if live and all(has):
+                if not all(p.grad.data_ptr() == views[id(p)].data_ptr() for p in live):
+                    raise RuntimeError("p.grad was replaced by a tensor outside the gradient arena")
+                tg = [views[id(p)] if (p is not None and p.requires_grad) else None for p in params]
+                return tg, True, [None] * len(params)
+            if any(has):
+                raise RuntimeError("mixed .grad state (some None, some set) is not supported")
+            tg = [views[id(p)] if (p is not None and p.requires_grad) else None for p in params]
+            return tg, False, list(tg)
+        tg = [torch.empty_like(p) if (p is not None and p.requires_grad) else None for p in params]
+        return tg, False, list(tg)
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer-block stack
+# ------------------------------------------------------------------------------------------------
+BLOCK_PARAM_ORDER = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias",
+                     "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias",
+                     "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+_NP = len(BLOCK_PARAM_ORDER)
+
+
+@dataclass
+class StackCfg:
+    heads: int
+    eps: float
+    dtype: torch.dtype
+    taps: tuple            # block indices whose outputs are returned as well
+    need_bwd: bool
+    sink: GradSink
+    lp: LPCache
+    on_block_grads: Optional[Callable[[int], None]] = None  # DDP overlap hook (parallel.py)
+
+
+def _block_params(blk):
+    return [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
+            blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
+            blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
+
+
+def _weights_struct(ps, cfg: StackCfg) -> tuple:
+    n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, wfc1, bfc1, wfc2, bfc2 = ps
+    keep = []
+    w = BlockWeights()
+    w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b = (ops.ptr(t) for t in (n1w, n1b, n2w, n2b))
+    w.bqkv, w.bproj, w.bfc1, w.bfc2 = (ops.ptr(t) for t in (bqkv, bproj, bfc1, bfc2))
+    for name, p in (("wqkv", wqkv), ("wproj", wproj), ("wfc1", wfc1), ("wfc2", wfc2)):
+        a, at = cfg.lp.get(p, cfg.dtype)
+        keep += [a, at]
+        setattr(w, name, ops.ptr(a))
+        setattr(w, name + "_t", ops.ptr(at))
+    return w, keep
+
+
+class _ActArena:
+    """Saved activations of one block, carved out of one byte buffer."""
+
+    def __init__(self, B, N, D, H, F, es):
+        T = B * N
+        self.sizes = [("mean1", T * 4), ("rstd1", T * 4), ("mean2", T * 4), ("rstd2", T * 4),
+                      ("h1", T * D * es), ("qkv", T * 3 * D * es), ("attn", T * D * es),
+                      ("lse", B * H * N * 4), ("xmid", T * D * 4), ("h2", T * D * es),
+                      ("u", T * F * es), ("g", T * F * es)]
+        self.total = sum(_align(s) for _, s in self.sizes)
+
+    def struct(self, base_ptr: int) -> BlockAct:
+        a = BlockAct()
+        off = 0
+        for name, s in self.sizes:
+            setattr(a, name, base_ptr + off)
+            off += _align(s)
+        return a
+
+
+class BlockStackFn(torch.autograd.Function):
+    """x -> blocks[depth-1](...blocks[0](x)); also returns the tap outputs.  inputs: x, cfg,
+    12*depth parameters in BLOCK_PARAM_ORDER."""
+
+    @staticmethod
+    def forward(ctx, x, cfg: StackCfg, *params):
+        L = _lib.load()
+        depth = len(params) // _NP
+        B, N, D = x.shape
+        F = params[8].shape[0]
+        assert x.dtype == torch.float32 and x.is_cuda
+        assert D % cfg.heads == 0 and params[2].shape == (3 * D, D)
+        x = x.contiguous()
+        es = 2 if cfg.dtype == torch.bfloat16 else 4
+        dims = BlockDims(B, N, D, cfg.heads, F, ops.code(cfg.dtype), float(cfg.eps))
+        wsb = L.ssl4gie_block_workspace_bytes(C.byref(dims))
+        assert wsb > 0
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+        layout = _ActArena(B, N, D, cfg.heads, F, es)
+        nact = depth if cfg.need_bwd else 1
+        acts = torch.empty(nact * layout.total, dtype=torch.uint8, device=x.device)
+        xs = [x]
+        keepalive = []
+        wstructs = []
+        st = ops.stream()
+        for i in range(depth):
+            w, keep = _weights_struct(params[i * _NP:(i + 1) * _NP], cfg)
+            keepalive += keep
+            wstructs.append(w)
+            a = layout.struct(acts.data_ptr() + (i if cfg.need_bwd else 0) * layout.total)
+            xo = torch.empty_like(x)
+            _lib.check(L.ssl4gie_block_fwd(C.byref(dims), C.byref(w), C.byref(a), xs[-1].data_ptr(),
+                                           xo.data_ptr(), ws.data_ptr(), st), f"block_fwd[{i}]")
+            xs.append(xo)
+        outs = [xs[depth]] + [xs[t + 1] for t in cfg.taps]
+        if cfg.need_bwd:
+            ctx.cfg, ctx.dims, ctx.layout = cfg, dims, layout
+            ctx.acts, ctx.xs, ctx.ws = acts, xs, ws
+            ctx.wstructs, ctx.keepalive = wstructs, keepalive
+            ctx.params = params
+            ctx.depth = depth
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        L = _lib.load()
+        cfg, dims, layout, depth = ctx.cfg, ctx.dims, ctx.layout, ctx.depth
+        x0 = ctx.xs[0]
+        lp = cfg.dtype if cfg.dtype != torch.float32 else None
+        tap_g = {t: g for t, g in zip(cfg.taps, gouts[1:]) if g is not None}
+        st = ops.stream()
+        targets, accumulate, returns = cfg.sink.plan(ctx.params)
+        dx = gouts[0]
+        if dx is None:
+            dx = torch.zeros_like(x0)
+        dx = dx.contiguous()
+        pending_tap = tap_g.pop(depth - 1, None)
+        dx, dx_lp = ops.add_cast(dx, pending_tap, want_f32=True, lp_dtype=lp)
+        for i in range(depth - 1, -1, -1):
+            if i != depth - 1 and i in tap_g:
+                dx, dx_lp = ops.add_cast(dx, tap_g[i].contiguous(), want_f32=True, lp_dtype=lp)
+            g = BlockGrads()
+            tg = targets[i * _NP:(i + 1) * _NP]
+            scratch = []
+            for name, t, p in zip(("ln1_g", "ln1_b", "wqkv", "bqkv", "wproj", "bproj", "ln2_g",
+                                   "ln2_b", "wfc1", "bfc1", "wfc2", "bfc2"), tg,
+                                  ctx.params[i * _NP:(i + 1) * _NP]):
+                if t is None:  # frozen parameter: the executor still needs somewhere to write
+                    t = torch.empty_like(p)
+                    scratch.append(t)
+                setattr(g, name, t.data_ptr())
+            a = layout.struct(ctx.acts.data_ptr() + i * layout.total)
+            dxn = torch.empty_like(x0)
+            dxn_lp = torch.empty(x0.shape, dtype=lp, device=x0.device) if lp else None
+            _lib.check(L.ssl4gie_block_bwd(C.byref(dims), C.byref(ctx.wstructs[i]), C.byref(a),
+                                           C.byref(g), ctx.xs[i].data_ptr(), dx.data_ptr(),
+                                           ops.ptr(dx_lp), dxn.data_ptr(), ops.ptr(dxn_lp),
+                                           int(accumulate), ctx.ws.data_ptr(), st),
+                       f"block_bwd[{i}]")
+            dx, dx_lp = dxn, dxn_lp
+            if cfg.on_block_grads is not None:
+                cfg.on_block_grads(i)
+        ctx.acts = ctx.xs = ctx.ws = ctx.keepalive = None
+        return (dx, None) + tuple(returns)
+
+
+def run_blocks(blocks: Sequence[nn.Module], x: torch.Tensor, heads: int, eps: float, dtype,
+               sink: GradSink, taps: Sequence[int] = (), lp: LPCache = None,
+               on_block_grads=None):
+    """Run a list of Block parameter-holders; returns (x_out, [tap outputs])."""
+    params: List[torch.Tensor] = []
+    for b in blocks:
+        params += _block_params(b)
+    need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    cfg = StackCfg(heads=heads, eps=eps, dtype=dtype, taps=tuple(taps), need_bwd=need, sink=sink,
+                   lp=lp or _GLOBAL_LP, on_block_grads=on_block_grads)
+    outs = BlockStackFn.apply(x, cfg, *params)
+    return outs[0], list(outs[1:])
+
+
+# ------------------------------------------------------------------------------------------------
+# single-op autograd nodes
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    """fp32 residual stream -> normalised rows in the MFMA operand type."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_dtype, sink):
+        x = x.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x, gamma.detach(), beta.detach(), eps, out_dtype)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.sink = sink
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        (tg, tb), acc, rets = ctx.sink.plan([gamma, beta])
+        if tg is None or tb is None:  # frozen affine: scratch
+            tg = tg if tg is not None else torch.empty_like(gamma)
+            tb = tb if tb is not None else torch.empty_like(beta)
+        dx, _, _, _ = ops.layernorm_bwd(dy.contiguous(), x, gamma.detach(), mean, rstd,
+                                        dgamma=tg, dbeta=tb, accumulate=acc)
+        return dx, rets[0], rets[1], None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on operand-type activations; y in `out_dtype`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dtype, out_dtype, sink, lp):
+        shp = x.shape
+        x2 = x.contiguous().view(-1, shp[-1])
+        assert x2.dtype == dtype
+        w, wt = lp.get(weight, dtype)
+        y = ops.linear_fwd(x2, w, bias.detach() if bias is not None else None, out_dtype=out_dtype)
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.wlp, ctx.wt, ctx.sink, ctx.dtype, ctx.shp = w, wt, sink, dtype, shp
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, dy.shape[-1])
+        if dy2.dtype != ctx.dtype:  # fp32 output (decoder_pred): operand copy for the GEMMs
+            _, dy2 = ops.add_cast(dy2, None, want_f32=False, lp_dtype=ctx.dtype)
+        (tw, tb), acc, rets = ctx.sink.plan([weight, bias])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_bwd_data(dy2, ctx.wlp, ctx.wt).view(ctx.shp)
+        if tw is not None:
+            ops.linear_bwd_weight(dy2, x2, out=tw, accumulate=acc)
+        if tb is not None:
+            ops.colsum(dy2, out=tb, accumulate=acc)
+        return dx, rets[0], rets[1], None, None, None, None
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """PatchEmbed conv (k=s=p) as gather + GEMM, + pos-embed add + cls concat, computed ONLY for the
+    patches that survive masking (`ids[:, :nsel]`): identical per-row arithmetic to embedding all
+    patches and gathering afterwards (models_mae.py:152-163), a quarter of the work."""
+
+    @staticmethod
+    def forward(ctx, imgs, weight, bias, cls, pos, ids, nsel, p, dtype, sink, lp):
+        B = imgs.shape[0]
+        imgs = imgs.contiguous()
+        cols = ops.patch_gather(imgs, p, ids=ids, nsel=nsel, out_dtype=dtype)
+        w, _ = lp.get(weight, dtype)
+        y = ops.linear_fwd(cols, w, bias.detach(), out_dtype=dtype)
+        nsel_eff = cols.shape[0] // B
+        x = ops.tokens_assemble(y, cls.detach().contiguous().view(-1),
+                                pos.detach().contiguous().view(-1, pos.shape[-1]), B, nsel_eff,
+                                ids=ids)
+        ctx.save_for_backward(cols, weight, bias, cls)
+        ctx.sink, ctx.dtype = sink, dtype
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        cols, weight, bias, cls = ctx.saved_tensors
+        (tw, tb, tc), acc, rets = ctx.sink.plan([weight, bias, cls])
+        dy = ops.tokens_assemble_bwd(dx.contiguous(), ctx.dtype, dcls_out=tc, accumulate=acc)
+        if tw is not None:
+            ops.linear_bwd_weight(dy, cols, out=tw, accumulate=acc)
+        if tb is not None:
+            ops.colsum(dy, out=tb, accumulate=acc)
+        return (None, rets[0], rets[1], rets[2]) + (None,) * 7
+
+
+class DecoderAssembleFn(torch.autograd.Function):
+    """append mask tokens, un-shuffle, add decoder pos-embed (models_mae.py:177-183)."""
+
+    @staticmethod
+    def forward(ctx, y, mask_token, dpos, ids_restore, ids_shuffle, nkeep, sink):
+        xd = ops.decoder_assemble(y.contiguous(), mask_token.detach().contiguous().view(-1),
+                                  dpos.detach().contiguous().view(-1, dpos.shape[-1]),
+                                  ids_restore, nkeep)
+        ctx.save_for_backward(mask_token, ids_shuffle)
+        ctx.nkeep, ctx.sink, ctx.ydtype = nkeep, sink, y.dtype
+        return xd
+
+    @staticmethod
+    def backward(ctx, dxd):
+        mask_token, ids_shuffle = ctx.saved_tensors
+        (tm,), acc, rets = ctx.sink.plan([mask_token])
+        if tm is None:
+            tm = torch.empty_like(mask_token)
+        dy = ops.decoder_assemble_bwd(dxd.contiguous(), ids_shuffle, ctx.nkeep, ctx.ydtype,
+                                      dmask_out=tm, accumulate=acc)
+        return dy, rets[0], None, None, None, None, None
+
+
+class MaeLossFn(torch.autograd.Function):
+    """per-patch masked MSE against (optionally normalised) pixels (models_mae.py:198-212)."""
+
+    @staticmethod
+    def forward(ctx, pred_full, imgs, mask, p, norm_pix):
+        pred_full = pred_full.contiguous()
+        per_patch = ops.mae_loss_fwd(pred_full, imgs, mask, p, norm_pix)
+        ctx.save_for_backward(pred_full, imgs, mask)
+        ctx.p, ctx.norm_pix = p, norm_pix
+        return per_patch
+
+    @staticmethod
+    def backward(ctx, gpp):
+        pred_full, imgs, mask = ctx.saved_tensors
+        dpred = ops.mae_loss_bwd(pred_full, imgs, mask, ctx.p, ctx.norm_pix, gpp.contiguous())
+        return dpred, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# base class for the model mirrors
+# ------------------------------------------------------------------------------------------------
+class EngineModule(nn.Module):
+    """nn.Module whose forward runs on the HIP engine.  Builds the parameter arena lazily on the
+    first forward on a device (and again if .to()/.cuda() moved the parameters)."""
+
+    engine_dtype = None  # torch dtype; None -> default_dtype()
+
+    def __init__(self):
+        super().__init__()
+        self._arena: Optional[ParamArena] = None
+        self._lp = LPCache()
+        self._sink = None
+        self._grad_hook = None  # set by parallel.DataParallel
+
+    def set_precision(self, name_or_dtype):
+        if isinstance(name_or_dtype, str):
+            name_or_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32,
+                             "f32": torch.float32}[name_or_dtype.lower()]
+        assert name_or_dtype in (torch.bfloat16, torch.float32)
+        self.engine_dtype = name_or_dtype
+        return self
+
+    @property
+    def dtype_(self):
+        return self.engine_dtype or default_dtype()
+
+    def arena(self) -> ParamArena:
+        ps = list(self.parameters())
+        a = self._arena
+        if a is None or len(a.params) != len(ps) or any(x is not y for x, y in zip(a.params, ps)) \
+                or not a.intact():
+            if not ps[0].is_cuda:
+                raise RuntimeError("ssl4gie_amd models run on the HIP device only: call .cuda() "
+                                   "first (there is no CPU fallback)")
+            old = {id(p): p.grad for p in ps}
+            self._arena = a = ParamArena(ps)
+            self._sink = GradSink(a)
+            for p in ps:  # gradients that existed before a rebuild are carried over
+                g = old[id(p)]
+                if g is not None:
+                    v = a.grad_view(p)
+                    v.copy_(g)
+                    p.grad = v
+        return a
+
+    def _prepare(self):
+        """Call once at the top of forward(): validates the arena (cheap pointer checks)."""
+        _lib.load()
+        self.arena()
+
+    def sink(self) -> GradSink:
+        if self._arena is None:
+            self.arena()
+        return self._sink
+
+    # helpers used by the model mirrors -----------------------------------------------------
+    def _ln(self, x, norm: nn.LayerNorm, out_dtype=None):
+        return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps, out_dtype or self.dtype_,
+                                 self.sink())
+
+    def _linear(self, x, lin: nn.Linear, out_dtype=None):
+        return LinearFn.apply(x, lin.weight, lin.bias, self.dtype_, out_dtype or self.dtype_,
+                              self.sink(), self._lp)
+
+    def _blocks(self, blocks, x, heads, eps, taps=()):
+        return run_blocks(blocks, x, heads, eps, self.dtype_, self.sink(), taps=taps, lp=self._lp,
+                          on_block_grads=self._grad_hook_for(blocks))
+
+    def _grad_hook_for(self, blocks):
+        h = self._grad_hook
+        if h is None:
+            return None
+        blocks = list(blocks)
+        return lambda i: h(blocks[i])

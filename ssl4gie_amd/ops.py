@@ -1,0 +1,387 @@
+"""Host-side wrappers of the single-op C-ABI entry points (raw device pointers + current stream).
+
+Every wrapper validates shapes / dtypes / contiguity on the host before the launch — a kernel is
+never started on operands whose layout it does not assume.  Tensors are only containers for
+device memory here; no torch arithmetic happens in this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, GemmDesc
+
+_TORCH2CODE = {torch.float32: F32, torch.bfloat16: BF16}
+_CODE2TORCH = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def code(dtype) -> int:
+    try:
+        return _TORCH2CODE[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dtype}; the HIP path computes in fp32 or bf16")
+
+
+def torch_dtype(c: int):
+    return _CODE2TORCH[c]
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("ssl4gie_amd ops need tensors on the HIP device (no CPU fallback)")
+        if not t.is_contiguous():
+            raise RuntimeError("ssl4gie_amd ops need contiguous tensors")
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError(f"expected float32, got {t.dtype}")
+
+
+# ------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, eps, out_dtype, save_stats=True):
+    _dev(x, gamma, beta)
+    _f32(x, gamma, beta)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    assert gamma.numel() == cols and beta.numel() == cols and cols % 4 == 0
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    L = _lib.load()
+    _lib.check(L.ssl4gie_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), code(out_dtype),
+                                       ptr(mean), ptr(rstd), rows, cols, float(eps), stream()),
+               "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, want_lp=False, dgamma=None, dbeta=None,
+                  accumulate=False):
+    _dev(dy, x, gamma, mean, rstd, dres, dgamma, dbeta)
+    _f32(x, gamma, mean, rstd, dres, dgamma, dbeta)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    assert dy.shape == x.shape and mean.numel() == rows and rstd.numel() == rows
+    assert dres is None or dres.shape == x.shape
+    L = _lib.load()
+    dx = torch.empty_like(x)
+    dx_lp = torch.empty(x.shape, dtype=dy.dtype, device=x.device) if want_lp else None
+    if dgamma is None:
+        dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.ssl4gie_layernorm_bwd_workspace_bytes(rows, cols), dtype=torch.uint8,
+                     device=x.device)
+    _lib.check(L.ssl4gie_layernorm_bwd(ptr(dy), code(dy.dtype), ptr(x), ptr(gamma), ptr(mean),
+                                       ptr(rstd), ptr(dres), ptr(dx), ptr(dx_lp), code(dy.dtype),
+                                       ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), rows,
+                                       cols, stream()), "layernorm_bwd")
+    return dx, dx_lp, dgamma, dbeta
+
+
+def colsum(x2d, out=None, accumulate=False):
+    _dev(x2d, out)
+    rows, cols = x2d.shape
+    L = _lib.load()
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x2d.device)
+    assert out.numel() == cols and out.dtype == torch.float32
+    ws = torch.empty(max(1, L.ssl4gie_colsum_workspace_bytes(rows, cols)), dtype=torch.uint8,
+                     device=x2d.device)
+    _lib.check(L.ssl4gie_colsum(ptr(x2d), code(x2d.dtype), ptr(out), int(accumulate), ptr(ws),
+                                rows, cols, cols, stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm_raw(desc: GemmDesc, device):
+    L = _lib.load()
+    nbytes = L.ssl4gie_gemm_workspace_bytes(C.byref(desc))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
+    _lib.check(L.ssl4gie_gemm(C.byref(desc), ptr(ws), nbytes, stream()), "gemm")
+
+
+def _desc(M, N, K, dt_ab, dt_c):
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch1, d.batch2 = M, N, K, 1, 1
+    d.dtype_ab, d.dtype_c, d.alpha, d.epilogue = dt_ab, dt_c, 1.0, _lib.EPI_NONE
+    return d
+
+
+def linear_fwd(x2d, w, bias=None, out_dtype=None, epilogue=None, residual=None):
+    """y[T, n_out] = x2d[T, k_in] @ w[n_out, k_in]^T (+bias | +bias+residual | gelu pair)."""
+    _dev(x2d, w, bias, residual)
+    T, k_in = x2d.shape
+    n_out, k2 = w.shape
+    assert k2 == k_in and x2d.dtype == w.dtype, (x2d.shape, w.shape, x2d.dtype, w.dtype)
+    out_dtype = out_dtype or x2d.dtype
+    d = _desc(T, n_out, k_in, code(x2d.dtype), code(out_dtype))
+    d.A, d.sAm, d.sAk = ptr(x2d), k_in, 1
+    d.B, d.sBk, d.sBn = ptr(w), 1, k_in
+    y = torch.empty(T, n_out, dtype=out_dtype, device=x2d.device)
+    d.C, d.ldc = ptr(y), n_out
+    out2 = None
+    if epilogue is None:
+        epilogue = _lib.EPI_BIAS if bias is not None else _lib.EPI_NONE
+    d.epilogue = epilogue
+    if bias is not None:
+        _f32(bias)
+        assert bias.numel() == n_out
+        d.bias = ptr(bias)
+    if epilogue == _lib.EPI_BIAS_RESIDUAL:
+        _f32(residual)
+        assert residual.shape == (T, n_out)
+        d.residual, d.ldr = ptr(residual), n_out
+    if epilogue == _lib.EPI_BIAS_GELU:
+        out2 = torch.empty_like(y)
+        d.out2 = ptr(out2)
+    gemm_raw(d, x2d.device)
+    return (y, out2) if out2 is not None else y
+
+
+def linear_bwd_data(dy2d, w, w_t=None, out_dtype=None, dgelu_aux=None):
+    """dx[T, k_in] = dy[T, n_out] @ w[n_out, k_in]; uses w_t[k_in, n_out] (NT fast path) if given."""
+    _dev(dy2d, w, w_t, dgelu_aux)
+    T, n_out = dy2d.shape
+    k_in = w.shape[1]
+    assert w.shape[0] == n_out
+    out_dtype = out_dtype or dy2d.dtype
+    d = _desc(T, k_in, n_out, code(dy2d.dtype), code(out_dtype))
+    d.A, d.sAm, d.sAk = ptr(dy2d), n_out, 1
+    if w_t is not None:
+        assert w_t.shape == (k_in, n_out) and w_t.dtype == dy2d.dtype
+        d.B, d.sBk, d.sBn = ptr(w_t), 1, n_out
+    else:
+        assert w.dtype == dy2d.dtype
+        d.B, d.sBk, d.sBn = ptr(w), k_in, 1
+    dx = torch.empty(T, k_in, dtype=out_dtype, device=dy2d.device)
+    d.C, d.ldc = ptr(dx), k_in
+    if dgelu_aux is not None:
+        assert dgelu_aux.shape == dx.shape and dgelu_aux.dtype == out_dtype
+        d.epilogue, d.aux = _lib.EPI_DGELU, ptr(dgelu_aux)
+    gemm_raw(d, dy2d.device)
+    return dx
+
+
+def linear_bwd_weight(dy2d, x2d, out=None, accumulate=False):
+    """dW[n_out, k_in] = dy[T, n_out]^T @ x[T, k_in]  (fp32 output)."""
+    _dev(dy2d, x2d, out)
+    T, n_out = dy2d.shape
+    T2, k_in = x2d.shape
+    assert T == T2 and dy2d.dtype == x2d.dtype
+    if out is None:
+        out = torch.empty(n_out, k_in, dtype=torch.float32, device=x2d.device)
+    assert out.dtype == torch.float32 and out.numel() == n_out * k_in
+    d = _desc(n_out, k_in, T, code(dy2d.dtype), F32)
+    d.A, d.sAm, d.sAk = ptr(dy2d), 1, n_out
+    d.B, d.sBk, d.sBn = ptr(x2d), k_in, 1
+    d.C, d.ldc = ptr(out), k_in
+    d.accumulate = int(accumulate)
+    gemm_raw(d, x2d.device)
+    return out
+
+
+# ------------------------------------------------------------------ attention
+def attn_fwd(qkv, B, N, H, hd):
+    _dev(qkv)
+    D = H * hd
+    assert qkv.numel() == B * N * 3 * D
+    L = _lib.load()
+    out = torch.empty(B, N, D, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    nb = L.ssl4gie_attn_workspace_bytes(code(qkv.dtype), B, N, H, hd)
+    ws = torch.empty(nb, dtype=torch.uint8, device=qkv.device) if nb else None
+    _lib.check(L.ssl4gie_attn_fwd(ptr(qkv), ptr(out), ptr(lse), code(qkv.dtype), B, N, H, hd,
+                                  ptr(ws), stream()), "attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, N, H, hd):
+    _dev(qkv, out, dout, lse)
+    assert out.dtype == qkv.dtype and dout.dtype == qkv.dtype and lse.dtype == torch.float32
+    assert out.numel() == B * N * H * hd and dout.numel() == out.numel()
+    L = _lib.load()
+    dqkv = torch.empty_like(qkv)
+    nb = L.ssl4gie_attn_workspace_bytes(code(qkv.dtype), B, N, H, hd)
+    ws = torch.empty(nb, dtype=torch.uint8, device=qkv.device) if nb else None
+    _lib.check(L.ssl4gie_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv),
+                                  code(qkv.dtype), B, N, H, hd, ptr(ws), stream()), "attn_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------ casts
+def cast(src, dtype, out=None):
+    _dev(src, out)
+    _f32(src)
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    assert out.numel() == src.numel() and out.dtype == dtype
+    _lib.check(_lib.load().ssl4gie_cast(ptr(src), ptr(out), code(dtype), src.numel(), stream()),
+               "cast")
+    return out
+
+
+def cast_transpose(src2d, dtype, out=None):
+    _dev(src2d, out)
+    _f32(src2d)
+    r, c = src2d.shape
+    if out is None:
+        out = torch.empty(c, r, dtype=dtype, device=src2d.device)
+    assert out.numel() == r * c and out.dtype == dtype
+    _lib.check(_lib.load().ssl4gie_cast_transpose(ptr(src2d), ptr(out), code(dtype), r, c,
+                                                  stream()), "cast_transpose")
+    return out
+
+
+def add_cast(a, b=None, want_f32=True, lp_dtype=None):
+    """out = a + b on the fp32 gradient stream; optionally also its operand-type copy."""
+    _dev(a, b)
+    _f32(a, b)
+    assert b is None or b.shape == a.shape
+    out = torch.empty_like(a) if want_f32 else None
+    out_lp = torch.empty(a.shape, dtype=lp_dtype, device=a.device) if lp_dtype is not None else None
+    _lib.check(_lib.load().ssl4gie_add_cast(ptr(a), ptr(b), ptr(out), ptr(out_lp),
+                                            code(lp_dtype) if lp_dtype is not None else 0,
+                                            a.numel(), stream()), "add_cast")
+    return out, out_lp
+
+
+# ------------------------------------------------------------------ MAE glue
+def mask_argsort(noise, len_keep):
+    _dev(noise)
+    _f32(noise)
+    B, Lp = noise.shape
+    ids_shuffle = torch.empty(B, Lp, dtype=torch.int64, device=noise.device)
+    ids_restore = torch.empty_like(ids_shuffle)
+    mask = torch.empty(B, Lp, dtype=torch.float32, device=noise.device)
+    _lib.check(_lib.load().ssl4gie_mask_argsort(ptr(noise), ptr(ids_shuffle), ptr(ids_restore),
+                                                ptr(mask), B, Lp, int(len_keep), stream()),
+               "mask_argsort")
+    return ids_shuffle, ids_restore, mask
+
+
+def patch_gather(img, p, ids=None, nsel=None, out_dtype=torch.float32, order=0):
+    _dev(img, ids)
+    _f32(img)
+    B, Cc, H, W = img.shape
+    npatch = (H // p) * (W // p)
+    if ids is not None:
+        assert ids.dtype == torch.int64 and ids.shape[0] == B and ids.dim() == 2
+        ids_stride = ids.shape[1]
+        nsel = nsel if nsel is not None else ids.shape[1]
+        assert nsel <= ids.shape[1]
+    else:
+        ids_stride, nsel = 0, npatch
+    out = torch.empty(B * nsel, Cc * p * p, dtype=out_dtype, device=img.device)
+    _lib.check(_lib.load().ssl4gie_patch_gather(ptr(img), ptr(ids), ptr(out), code(out_dtype), B,
+                                                Cc, H, W, p, nsel, ids_stride, order, stream()),
+               "patch_gather")
+    return out
+
+
+def tokens_assemble(y2d, cls, pos, B, nsel, ids=None):
+    _dev(y2d, cls, pos, ids)
+    _f32(cls, pos)
+    D = y2d.shape[1]
+    assert y2d.shape[0] == B * nsel and cls.numel() == D and pos.shape[-1] == D
+    ids_stride = 0
+    if ids is not None:
+        assert ids.dtype == torch.int64 and ids.shape[0] == B and ids.shape[1] >= nsel
+        ids_stride = ids.shape[1]
+        assert pos.numel() // D >= 1 + ids.shape[1]
+    else:
+        assert pos.numel() // D >= 1 + nsel
+    x = torch.empty(B, nsel + 1, D, dtype=torch.float32, device=y2d.device)
+    _lib.check(_lib.load().ssl4gie_tokens_assemble(ptr(y2d), code(y2d.dtype), ptr(cls), ptr(pos),
+                                                   ptr(ids), ids_stride, ptr(x), B, nsel, D,
+                                                   stream()), "tokens_assemble")
+    return x
+
+
+def tokens_assemble_bwd(dx, lp_dtype, dcls_out=None, accumulate=False):
+    """dy[b*nsel+j] = dx[b,1+j] (operand type); dcls_out (+)= sum_b dx[b,0] if given."""
+    _dev(dx, dcls_out)
+    _f32(dx, dcls_out)
+    B, n1, D = dx.shape
+    assert dcls_out is None or dcls_out.numel() == D
+    dy = torch.empty(B * (n1 - 1), D, dtype=lp_dtype, device=dx.device)
+    _lib.check(_lib.load().ssl4gie_tokens_assemble_bwd(ptr(dx), ptr(dy), code(lp_dtype),
+                                                       ptr(dcls_out), int(accumulate), B, n1 - 1,
+                                                       D, stream()), "tokens_assemble_bwd")
+    return dy
+
+
+def decoder_assemble(y, mask_token, dpos, ids_restore, nkeep):
+    _dev(y, mask_token, dpos, ids_restore)
+    _f32(mask_token, dpos)
+    B, Lp = ids_restore.shape
+    D = y.shape[-1]
+    assert y.numel() == B * (nkeep + 1) * D and mask_token.numel() == D
+    assert dpos.numel() == (Lp + 1) * D and ids_restore.dtype == torch.int64
+    xd = torch.empty(B, Lp + 1, D, dtype=torch.float32, device=y.device)
+    _lib.check(_lib.load().ssl4gie_decoder_assemble(ptr(y), code(y.dtype), ptr(mask_token),
+                                                    ptr(dpos), ptr(ids_restore), ptr(xd), B, Lp,
+                                                    nkeep, D, stream()), "decoder_assemble")
+    return xd
+
+
+def decoder_assemble_bwd(dxd, ids_shuffle, nkeep, lp_dtype, dmask_out, accumulate=False):
+    _dev(dxd, ids_shuffle, dmask_out)
+    _f32(dxd, dmask_out)
+    B, L1, D = dxd.shape
+    Lp = L1 - 1
+    assert ids_shuffle.shape == (B, Lp) and ids_shuffle.dtype == torch.int64
+    assert dmask_out.numel() == D
+    L = _lib.load()
+    dy = torch.empty(B, nkeep + 1, D, dtype=lp_dtype, device=dxd.device)
+    ws = torch.empty(L.ssl4gie_decoder_assemble_bwd_workspace_bytes(B, Lp, D), dtype=torch.uint8,
+                     device=dxd.device)
+    _lib.check(L.ssl4gie_decoder_assemble_bwd(ptr(dxd), ptr(ids_shuffle), ptr(dy), code(lp_dtype),
+                                              ptr(dmask_out), int(accumulate), ptr(ws), B, Lp,
+                                              nkeep, D, stream()), "decoder_assemble_bwd")
+    return dy
+
+
+def _loss_geom(pred, img, mask, p):
+    B, Cc, H, W = img.shape
+    Lp = (H // p) * (W // p)
+    assert mask.shape == (B, Lp) and pred.dim() == 3 and pred.shape[0] == B
+    assert pred.shape[2] == Cc * p * p and pred.shape[1] in (Lp, Lp + 1)
+    return B, Cc, H, W, int(pred.shape[1] == Lp + 1)
+
+
+def mae_loss_fwd(pred, img, mask, p, norm_pix):
+    """per_patch[B, L] = mask * mean((pred - target)^2); pred is [B, L, P] or [B, 1+L, P]."""
+    _dev(pred, img, mask)
+    _f32(pred, img, mask)
+    B, Cc, H, W, has_cls = _loss_geom(pred, img, mask, p)
+    per_patch = torch.empty_like(mask)
+    _lib.check(_lib.load().ssl4gie_mae_loss(ptr(pred), ptr(img), ptr(mask), ptr(per_patch), 0, 0,
+                                            1.0, int(norm_pix), has_cls, B, Cc, H, W, p, stream()),
+               "mae_loss")
+    return per_patch
+
+
+def mae_loss_bwd(pred, img, mask, p, norm_pix, gpp, gscale_host=1.0):
+    _dev(pred, img, mask, gpp)
+    _f32(pred, img, mask, gpp)
+    assert gpp is None or gpp.shape == mask.shape
+    B, Cc, H, W, has_cls = _loss_geom(pred, img, mask, p)
+    dpred = torch.empty_like(pred)
+    _lib.check(_lib.load().ssl4gie_mae_loss(ptr(pred), ptr(img), ptr(mask), 0, ptr(dpred),
+                                            ptr(gpp), float(gscale_host), int(norm_pix), has_cls,
+                                            B, Cc, H, W, p, stream()), "mae_loss(bwd)")
+    return dpred

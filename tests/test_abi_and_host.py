@@ -1,0 +1,134 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ssl4gie_hip.h declares (no compute
+calls), and host-side logic (state_dict schema, pos tables, arena, gradient sink, LDS swizzles)."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import ROOT, load_golden
+
+from ssl4gie_amd import _lib, engine
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ssl4gie_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssl4gie_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared_symbols()
+    assert len(names) >= 25
+    assert os.path.exists(_lib.LIB_PATH), "build with __graft_entry__.build()"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ssl4gie_hip.h but not exported"
+    assert set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
+    assert _lib.load().ssl4gie_abi_version() == 1
+
+
+def test_workspace_queries_need_no_gpu():
+    L = _lib.load()
+    assert L.ssl4gie_layernorm_bwd_workspace_bytes(50432, 512) == 1024 * 2 * 512 * 4
+    d = _lib.BlockDims(256, 197, 512, 16, 2048, _lib.BF16, 1e-6)
+    assert L.ssl4gie_block_workspace_bytes(ctypes.byref(d)) > 0
+    assert L.ssl4gie_attn_workspace_bytes(_lib.BF16, 8, 197, 12, 64) == 0
+    assert L.ssl4gie_attn_workspace_bytes(_lib.F32, 2, 50, 12, 64) == 2 * 2 * 12 * 50 * 50 * 4
+
+
+def test_ops_refuse_cpu_tensors():
+    from ssl4gie_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layernorm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), 1e-6, torch.float32)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libssl4gie_hip.so")
+    with pytest.raises(_lib.HipExtensionMissing):
+        _lib.load()
+
+
+def test_mae_state_dict_schema_matches_reference():
+    from oracle import mae_ref, synth
+    from ssl4gie_amd.Models.mae import models_mae
+    m = models_mae.mae_vit_base_patch16(norm_pix_loss=True)
+    sd = m.state_dict()
+    ref = synth.mae_shapes(mae_ref.VIT_B)
+    assert set(sd) == set(ref)
+    assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    g = load_golden("g5_mae_vitb.npz")
+    assert len(sd) == int(g["n_tensors"]) and sum(v.numel() for v in sd.values()) == int(g["n_params"])
+    assert sorted(n for n, p in m.named_parameters() if p.requires_grad) == sorted(g["grad_names"])
+
+
+def test_pos_tables_match_reference_fixture():
+    from ssl4gie_amd.Models.mae.util.pos_embed import get_2d_sincos_pos_embed
+    g = load_golden("g3_sincos.npz")
+    for d in (768, 512, 192, 128):
+        np.testing.assert_allclose(get_2d_sincos_pos_embed(d, 14, True).astype(np.float32),
+                                   g[f"mae_{d}"], rtol=0, atol=1e-6)
+    from oracle import mae_ref
+    from ssl4gie_amd.Models.models import moco_sincos_pos_embed
+    assert torch.equal(moco_sincos_pos_embed(768, (14, 14)), mae_ref.sincos_2d_moco(768, 14))
+
+
+def test_finetune_factories_keep_reference_signatures():
+    from ssl4gie_amd import utils
+    v = utils.get_MAE_backbone(None, True, 6, False, None, False)
+    keys = set(v.state_dict())
+    assert {"cls_token", "pos_embed", "decoder_pos_embed", "patch_embed.proj.weight",
+            "blocks.11.mlp.fc2.bias", "norm.weight", "lin_head.weight"} <= keys
+    assert not any(k.startswith("decoder_blocks") or k.startswith("mask_token") for k in keys)
+    assert len(keys) == 153
+    v2 = utils.get_ImageNet_or_random_ViT(False, None, False, None, False, False)
+    assert len(v2.state_dict()) == 150
+    v3 = utils.get_MoCoV3_backbone(None, "vit_b", True, 12, False, None, False)
+    assert v3.lin_head.weight.shape == (12, 768) and not v3.pos_embed.requires_grad
+
+
+def test_param_arena_and_grad_sink_cpu():
+    lin = nn.Sequential(nn.Linear(8, 16), nn.LayerNorm(16), nn.Linear(16, 4))
+    ps = list(lin.parameters())
+    before = [p.detach().clone() for p in ps]
+    a = engine.ParamArena(ps)
+    assert a.intact() and all(torch.equal(p, b) for p, b in zip(ps, before))
+    assert all(p.data_ptr() % 256 == a.data.data_ptr() % 256 for p in ps)
+    lo, hi = a.span(list(lin[2].parameters()))
+    assert hi == a.numel and lo == a.span([ps[4]])[0]
+    sink = engine.GradSink(a)
+    tg, acc, rets = sink.plan(ps)
+    assert not acc and all(t.data_ptr() == a.grad_view(p).data_ptr() for t, p in zip(tg, ps))
+    for p, t in zip(ps, rets):
+        p.grad = t
+    tg2, acc2, rets2 = sink.plan(ps)
+    assert acc2 and all(r is None for r in rets2)
+    ps[0].grad = None
+    with pytest.raises(RuntimeError, match="mixed"):
+        sink.plan(ps)
+    ps[1].requires_grad = False
+    for p in ps:
+        p.grad = None
+    tg3, _, rets3 = sink.plan(ps)
+    assert tg3[1] is None and rets3[1] is None and tg3[0] is not None
+
+
+def test_lds_swizzles_are_conflict_free():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_bank_sim as sim
+    nt = lambda r: (r >> 1) & 7
+    assert all(sim.b128_cycles(sim.row_read_addrs(128, nt, c0, r0)) == 4
+               for c0 in (0, 4) for r0 in (0, 16, 64, 112))
+    tn = lambda k: ((k & 3) | ((k >> 1) & 4)) << 1
+    assert all(sim.tr_b16_cycles(sim.tr_read_addrs(256, tn, k0, x0, s)) == 2
+               for k0 in (0, 32) for x0 in range(0, 128, 16) for s in (False, True))
+    for rb, swz, nch in ((128, lambda r: r & 6, 8), (64, lambda r: (r >> 1) & 2, 4)):
+        assert all(sim.b128_cycles(sim.row_read_addrs(rb, swz, c0, r0)) == 4
+                   for c0 in range(0, nch, 4) for r0 in (0, 16, 208))
+        assert all(sim.tr_b16_cycles(sim.attn_tr_read_addrs(rb, swz, k0, d0, s)) == 2
+                   for k0 in (0, 32, 192) for d0 in range(0, nch * 8, 16) for s in (False, True))

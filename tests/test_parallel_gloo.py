@@ -1,0 +1,85 @@
+"""CPU, world_size 2 over gloo: the bucketed arena all-reduce of ssl4gie_amd.parallel averages
+gradients exactly like DDP (reference train_depth.py:226-229) and overlap bookkeeping is sound."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Toy(nn.Module):
+    """Stands in for an EngineModule: parameters in registration order, arena, _grad_hook."""
+
+    def __init__(self):
+        super().__init__()
+        self.stem = nn.Linear(8, 32)
+        self.blocks = nn.ModuleList([nn.Linear(32, 32) for _ in range(6)])
+        self.head = nn.Linear(32, 4)
+        self._grad_hook = None
+        self._a = None
+
+    def arena(self):
+        from ssl4gie_amd.engine import ParamArena
+        if self._a is None:
+            self._a = ParamArena(list(self.parameters()))
+        return self._a
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssl4gie_amd.parallel import DataParallel
+    torch.manual_seed(1234 + rank)  # different initial weights per rank: broadcast must fix it
+    m = _Toy()
+    ddp = DataParallel(m, bucket_bytes=4 * 2000, overlap=True)
+    a = m.arena()
+    w0 = a.data.clone()
+    gather = [torch.empty_like(w0) for _ in range(world)]
+    dist.all_gather(gather, w0)
+    same_weights = all(torch.equal(gather[0], g) for g in gather)
+    # emulate a backward that fills the arena from the end (head first, stem last)
+    gen = torch.Generator().manual_seed(77 + rank)
+    local = torch.randn(a.grad.numel(), generator=gen)
+    a.grad.copy_(local)
+    for blk in reversed(m.blocks):
+        m._grad_hook(blk)
+    fired_during_backward = ddp.n_collectives
+    ddp.finish()
+    expect = sum(torch.randn(a.grad.numel(), generator=torch.Generator().manual_seed(77 + r))
+                 for r in range(world)) / world
+    ok = torch.allclose(a.grad, expect, rtol=0, atol=1e-6)
+    loss_mean = ddp.all_reduce_mean(torch.tensor([float(rank + 1)]))
+    q.put((rank, same_weights, bool(ok), fired_during_backward, ddp.n_collectives,
+           float(loss_mean)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_bucketed_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, same_w, ok, during, total, lm in res:
+        assert same_w, "rank-0 parameter broadcast"
+        assert ok, "gradient average"
+        assert during >= 2, "buckets must be launched while backward is still running"
+        assert total == during + 1
+        assert abs(lm - 1.5) < 1e-6
