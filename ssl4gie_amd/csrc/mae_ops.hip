@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256) void mask_argsort_kernel(const float* __restri
 extern "C" int ssl4gie_mask_argsort(const float* noise, long long* ids_shuffle,
                                     long long* ids_restore, float* mask, int B, int L,
                                     int len_keep, void* stream) {
-    REQUIRE(noise && B >= 0 && L > 0 && L <= 16384 && len_keep >= 0 && len_keep <= L);
+    REQUIRE(B >= 0 && L > 0 && L <= 16384 && len_keep >= 0 && len_keep <= L);
     if (B == 0) return 0;
+    REQUIRE(noise);
     hipLaunchKernelGGL(mask_argsort_kernel, dim3(B), dim3(256), L * sizeof(float),
                        (hipStream_t)stream, noise, ids_shuffle, ids_restore, mask, L, len_keep);
     LAUNCH_CHECK();

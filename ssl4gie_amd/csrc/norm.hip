@@ -163,14 +163,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     }
 }
 
-// out[c] (+)= sum_p partial[p][c] ; `n_out` contiguous columns, partial row stride `stride`.
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                       int nparts, int n_out, size_t stride, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_out) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * stride + c];
-    out[c] = accumulate ? out[c] + s : s;
+// out[c] (+)= sum_p partial[p*stride + c].  One 64-column strip per block, 16 waves: wave w sums
+// parts w, w+16, ... (independent 256-B coalesced loads kept in flight), LDS combines the 16 partial
+// strips.  Columns >= split go to out1 (LayerNorm: [dgamma | dbeta] in one launch).
+#define RP_WAVES 16
+__global__ __launch_bounds__(64 * RP_WAVES) void reduce_partials_kernel(
+    const float* __restrict__ partial, float* __restrict__ out0, float* __restrict__ out1,
+    int split, int nparts, int n_out, size_t stride, int accumulate) {
+    __shared__ float red[RP_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < n_out) {
+        int p = wave;
+        for (; p + 3 * RP_WAVES < nparts; p += 4 * RP_WAVES) {
+            s0 += partial[(size_t)p * stride + c];
+            s1 += partial[(size_t)(p + RP_WAVES) * stride + c];
+            s2 += partial[(size_t)(p + 2 * RP_WAVES) * stride + c];
+            s3 += partial[(size_t)(p + 3 * RP_WAVES) * stride + c];
+        }
+        for (; p < nparts; p += RP_WAVES) s0 += partial[(size_t)p * stride + c];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && c < n_out) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < RP_WAVES; ++w) s += red[w][lane];
+        float* o = (c < split) ? out0 + c : out1 + (c - split);
+        *o = accumulate ? *o + s : s;
+    }
 }
 
 // column sums of a [rows, cols] matrix (bias gradient): partial[blockIdx.y][cols]
@@ -200,11 +222,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 
 int ssl4gie_internal_reduce_partials(const float* partial, float* out, int nparts, int n_out,
                                      size_t stride, int accumulate, hipStream_t st) {
-    const int t = 256;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_out + t - 1) / t), dim3(t), 0, st, partial,
-                       out, nparts, n_out, stride, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_out + 63) / 64), dim3(64 * RP_WAVES), 0, st,
+                       partial, out, out, n_out, nparts, n_out, stride, accumulate);
     LAUNCH_CHECK();
     return 0;
+}
+
+// any column count (e.g. the 6/12-class linear head): one column per thread
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_scalar_kernel(const T* __restrict__ x,
+                                                                    float* __restrict__ partial,
+                                                                    int rows, int cols, size_t ld) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float acc = 0.f;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) acc += Elem<T>::ld(x + (size_t)r * ld + c);
+    partial[(size_t)blockIdx.y * cols + c] = acc;
 }
 
 static int ln_nv(int cols) { return (cols + 255) / 256; }
@@ -276,12 +309,10 @@ extern "C" int ssl4gie_layernorm_bwd(const void* dy, int dy_dtype, const float* 
 #undef LN_BWD
     LAUNCH_CHECK();
     if (dgamma && dbeta) {
-        // partial rows are [dgamma | dbeta] of width 2*cols: reduce both halves
-        const int t = 256;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + t - 1) / t), dim3(t), 0, st,
-                           workspace, dgamma, nb, cols, (size_t)2 * cols, accumulate);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + t - 1) / t), dim3(t), 0, st,
-                           workspace + cols, dbeta, nb, cols, (size_t)2 * cols, accumulate);
+        // partial rows are [dgamma | dbeta] of width 2*cols: one launch, two destinations
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * cols + 63) / 64), dim3(64 * RP_WAVES),
+                           0, st, workspace, dgamma, dbeta, cols, nb, 2 * cols, (size_t)2 * cols,
+                           accumulate);
         LAUNCH_CHECK();
     }
     return 0;
@@ -296,20 +327,27 @@ extern "C" size_t ssl4gie_colsum_workspace_bytes(int rows, int cols) {
 }
 extern "C" int ssl4gie_colsum(const void* x, int dtype, float* out, int accumulate,
                               float* workspace, int rows, int cols, long long ld, void* stream) {
-    REQUIRE(x && out && workspace && rows >= 0 && cols > 0 && cols % 4 == 0 && ld >= cols);
+    REQUIRE(x && out && workspace && rows >= 0 && cols > 0 && ld >= cols);
     REQUIRE(dtype == SSL4GIE_F32 || dtype == SSL4GIE_BF16);
     hipStream_t st = (hipStream_t)stream;
     const int parts = colsum_parts(rows);
     dim3 grid((cols + 255) / 256, parts), block(256);
-    if (dtype == SSL4GIE_BF16)
-        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x,
-                           workspace, rows, cols, (size_t)ld);
-    else
-        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, block, 0, st, (const float*)x,
-                           workspace, rows, cols, (size_t)ld);
+    const bool vec = (cols % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+    if (dtype == SSL4GIE_BF16) {
+        if (vec)
+            hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x,
+                               workspace, rows, cols, (size_t)ld);
+        else
+            hipLaunchKernelGGL(colsum_partial_scalar_kernel<bf16_t>, grid, block, 0, st,
+                               (const bf16_t*)x, workspace, rows, cols, (size_t)ld);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, block, 0, st, (const float*)x,
+                               workspace, rows, cols, (size_t)ld);
+        else
+            hipLaunchKernelGGL(colsum_partial_scalar_kernel<float>, grid, block, 0, st,
+                               (const float*)x, workspace, rows, cols, (size_t)ld);
+    }
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, st,
-                       workspace, out, parts, cols, (size_t)cols, accumulate);
-    LAUNCH_CHECK();
-    return 0;
+    return ssl4gie_internal_reduce_partials(workspace, out, parts, cols, (size_t)cols, accumulate, st);
 }

@@ -68,6 +68,8 @@ def test_colsum():
         xs = x.to(dt)
         out = ops.colsum(xs.to(DEV))
         assert rel_err(out, xs.double().sum(0)) < tol
+        odd = xs[:37, :6].contiguous()  # 6-class head: not a multiple of 4 columns
+        assert rel_err(ops.colsum(odd.to(DEV)), odd.double().sum(0)) < tol
 
 
 # ------------------------------------------------------------------ generic f32 GEMM
