@@ -78,6 +78,21 @@ DEVI float dgelu_f(float x) {
     return cdf + x * pdf;
 }
 
+// bf16-path variants: erf by Abramowitz-Stegun 7.1.26 (|err| < 2e-7 + fast-exp error), sharing
+// exp(-x^2/2) between the cdf and the pdf; ~3x fewer VALU ops than erff.  Outputs are rounded to
+// bf16 (rel 4e-3) anyway.  The fp32 parity path keeps the exact erff forms above.
+DEVI void gelu_parts_fast(float x, float& cdf, float& xpdf) {
+    const float e = __expf(-0.5f * x * x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678118654752440f * fabsf(x));
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t
+                        + 0.254829592f) * t;
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f + 0.5f * copysignf(erf_abs, x);
+    xpdf = x * e * 0.39894228040143267794f;
+}
+DEVI float gelu_fast(float x) { float c, p; gelu_parts_fast(x, c, p); return x * c; }
+DEVI float dgelu_fast(float x) { float c, p; gelu_parts_fast(x, c, p); return c + p; }
+
 // XCD-aware bijective block remap (cdna_hip_programming.md §5 / T1): consecutive logical
 // tile ids land on the same XCD (blocks b and b+8 share an XCD under round-robin dispatch).
 DEVI int xcd_remap(int bid, int nwg) {

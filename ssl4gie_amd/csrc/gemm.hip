@@ -21,6 +21,7 @@
 #include "common.h"
 #include "ssl4gie_hip.h"
 #include "prof.h"
+#include <stdlib.h>
 
 struct EpiArgs {
     float alpha;
@@ -45,7 +46,7 @@ struct GemmArgs {
 };
 
 // acc = 4 consecutive columns n..n+3 of row m
-template <typename TC, bool VEC>
+template <typename TC, bool VEC, bool FAST = false>
 DEVI void epi_store4(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m, int n, int M,
                      int N, f32x4 acc) {
     if (m >= M || n >= N) return;
@@ -61,7 +62,7 @@ DEVI void epi_store4(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m,
                 st4(C + off, v);
                 f32x4 g;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = gelu_f(v[j]);
+                for (int j = 0; j < 4; ++j) g[j] = FAST ? gelu_fast(v[j]) : gelu_f(v[j]);
                 st4((TC*)e.out2 + off, g);
                 return;
             }
@@ -72,7 +73,7 @@ DEVI void epi_store4(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m,
             case SSL4GIE_EPI_DGELU: {
                 const f32x4 u = ld4((const TC*)e.aux + off);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= dgelu_f(u[j]);
+                for (int j = 0; j < 4; ++j) v[j] *= FAST ? dgelu_fast(u[j]) : dgelu_f(u[j]);
                 break;
             }
             default:
@@ -106,6 +107,58 @@ DEVI void epi_store4(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m,
             }
             Elem<TC>::st(C + off + j, v);
         }
+    }
+}
+
+// vector epilogue with the mode resolved at compile time (bf16 fast paths; fast GELU forms)
+template <typename TC, int MODE>
+DEVI void epi_vec(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m, int n, int M, int N,
+                  f32x4 acc) {
+    if (m >= M || n >= N) return;
+    const size_t off = (size_t)m * ldc + n;
+    f32x4 v = acc * e.alpha;
+    if (MODE == SSL4GIE_EPI_BIAS) {
+        v += ld4(e.bias + n);
+    } else if (MODE == SSL4GIE_EPI_BIAS_GELU) {
+        if (e.bias) v += ld4(e.bias + n);
+        st4(C + off, v);
+        f32x4 g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = gelu_fast(v[j]);
+        st4((TC*)e.out2 + off, g);
+        return;
+    } else if (MODE == SSL4GIE_EPI_BIAS_RESIDUAL) {
+        if (e.bias) v += ld4(e.bias + n);
+        v += ld4(e.residual + (size_t)m * e.ldr + n);
+    } else if (MODE == SSL4GIE_EPI_DGELU) {
+        const f32x4 u = ld4((const TC*)e.aux + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= dgelu_fast(u[j]);
+    } else {
+        if (e.accumulate) v += ld4(C + off);
+    }
+    st4(C + off, v);
+}
+// a wave's 64x64 sub-tile (4x4 accumulators): rows m_base + 16i + (l&15), cols n_base + 16j + 4(l>>4)
+template <typename TC, int MODE>
+DEVI void epi_wave_tile(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m_base, int n_base,
+                        int M, int N, f32x4 (&acc)[4][4], int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            epi_vec<TC, MODE>(e, C, ldc, m_base + i * 16 + (lane & 15), n_base + j * 16 + 4 * (lane >> 4),
+                              M, N, acc[i][j]);
+}
+template <typename TC>
+DEVI void epi_wave_tile_dispatch(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m_base,
+                                 int n_base, int M, int N, f32x4 (&acc)[4][4], int lane) {
+    switch (e.mode) {
+        case SSL4GIE_EPI_BIAS: epi_wave_tile<TC, SSL4GIE_EPI_BIAS>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
+        case SSL4GIE_EPI_BIAS_GELU: epi_wave_tile<TC, SSL4GIE_EPI_BIAS_GELU>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
+        case SSL4GIE_EPI_BIAS_RESIDUAL: epi_wave_tile<TC, SSL4GIE_EPI_BIAS_RESIDUAL>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
+        case SSL4GIE_EPI_DGELU: epi_wave_tile<TC, SSL4GIE_EPI_DGELU>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
+        default: epi_wave_tile<TC, SSL4GIE_EPI_NONE>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
     }
 }
 
@@ -198,6 +251,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
 #define BT_TILE_BYTES (128 * 64 * 2)            // one operand tile (16 KiB)
 #define BT_STAGE_BYTES (2 * BT_TILE_BYTES)      // A + B
 #define BT_LDS_BYTES (2 * BT_STAGE_BYTES)       // double buffered: 64 KiB -> 2 workgroups / CU
+#define NT_MAX_WGS 512                          // persistent NT grid: 2 workgroups x 256 CUs
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -233,29 +287,95 @@ DEVI unsigned lds_addr(const void* p) {
 // ds_read_b128 address; makes the 16 rows a lane group touches hit 16 distinct 16-B bank slots).
 DEVI int nt_swz(int r) { return (r >> 1) & 7; }
 
-template <typename TC>
+// ---- LDS-staged epilogue for bf16 outputs -------------------------------------------------------
+// Accumulator fragments give a lane 4 consecutive columns (8 B in bf16) of 16 different rows: a
+// direct store writes 32-byte row fragments, which caps the store stream at ~1.5 TB/s (measured on
+// the 4D-wide MLP outputs).  Instead the finished 128x128 bf16 tile is staged in the K-tile buffer
+// that has just been consumed (exactly 32 KiB) and written out as whole 256-byte rows, 16 B/lane.
+// LDS image: row r at r*256, 16-B chunk c stored at position c ^ (r & 15)  (ds_write_b64 2-way,
+// ds_read_b128 conflict-free).
+template <bool GELU>
+DEVI void tile_lds_write(char* buf, int row_base, int col_base, const f32x4 (&v)[4][4], int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = row_base + 16 * i + (lane & 15);
+            const int col = col_base + 16 * j + 4 * (lane >> 4);
+            const int c = col >> 3;
+            f32x4 x = v[i][j];
+            if (GELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = gelu_fast(x[q]);
+            }
+            u32x2 pk;
+            pk[0] = pack_bf2(x[0], x[1]);
+            pk[1] = pack_bf2(x[2], x[3]);
+            *(u32x2*)(buf + row * 256 + ((c ^ (row & 15)) << 4) + ((col & 4) << 1)) = pk;
+            if (GELU) __builtin_amdgcn_sched_barrier(0);
+        }
+}
+DEVI void tile_lds_store(const char* buf, bf16_t* __restrict__ C, long long ldc, int m0, int n0, int M,
+                         int N, int wave, int lane) {
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int row = wave * 32 + it * 4 + (lane >> 4), c = lane & 15;
+        const u32x4 v = *(const u32x4*)(buf + row * 256 + ((c ^ (row & 15)) << 4));
+        const int gm = m0 + row, gn = n0 + c * 8;
+        if (gm < M && gn < N) __builtin_nontemporal_store(v, (u32x4*)(C + (size_t)gm * ldc + gn));
+    }
+}
+// whole-tile epilogue (all 4 waves; contains workgroup barriers -> call uniformly)
+// stage the (already transformed) 128x128 tile and store whole rows; `gelu2` adds the second,
+// GELU-activated output.  Contains workgroup barriers -> call uniformly.
+template <bool GELU2>
+DEVI void tile_out_lds(char* buf, bf16_t* __restrict__ C, bf16_t* __restrict__ C2, long long ldc, int m0,
+                       int n0, int wm, int wn, int M, int N, f32x4 (&acc)[4][4], int wave, int lane) {
+    __builtin_amdgcn_s_barrier();  // every wave has finished reading this K-tile buffer
+    tile_lds_write<false>(buf, wm, wn, acc, lane);
+    __syncthreads();
+    tile_lds_store(buf, C, ldc, m0, n0, M, N, wave, lane);
+    if (GELU2) {
+        __syncthreads();
+        tile_lds_write<true>(buf, wm, wn, acc, lane);
+        __syncthreads();
+        tile_lds_store(buf, C2, ldc, m0, n0, M, N, wave, lane);
+    }
+}
+
+// Persistent: gridDim.x = min(#tiles, 2 per CU) workgroups walk tiles pos, pos+G, ... and the
+// LDS-DMA stream never drains at a tile boundary — the first K-tile of the next output tile is
+// already in flight while the epilogue (bias / GELU / residual, vector stores) of the current one
+// runs.  With K = 512..768 a tile is only 8-12 K-steps long, so fill/drain would otherwise be a
+// large fraction of its life.
+template <typename TC, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
     const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
-    TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, EpiArgs e) {
+    TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int nwg = gridDim.x;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int m0 = (tile / tiles_n) * BT_M, n0 = (tile % tiles_n) * BT_N;
+    const int G = gridDim.x;
+    const int pos = xcd_remap(blockIdx.x, G);  // consecutive positions share an XCD (L2 reuse)
+    const int my_tiles = (ntiles - pos + G - 1) / G;
+    const int nk = K / BT_K;
 
-    // per-lane global source pointers for the 4 A and 4 B LDS-DMA pieces this wave issues
+    // per-lane global source pointers of the 4 A and 4 B LDS-DMA pieces this wave issues per K-tile
     const bf16_t* asrc[4];
     const bf16_t* bsrc[4];
+    auto point_at = [&](int ti) {
+        const int tile = pos + ti * G;
+        const int sm0 = (tile / tiles_n) * BT_M, sn0 = (tile % tiles_n) * BT_N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + (lane >> 3);  // tile row
-        const int c = (lane & 7) ^ nt_swz(r);            // global chunk stored at position lane&7
-        int ga = m0 + r; ga = ga < M ? ga : M - 1;
-        int gb = n0 + r; gb = gb < N ? gb : N - 1;
-        asrc[i] = A + (size_t)ga * lda + c * 8;
-        bsrc[i] = B + (size_t)gb * ldb + c * 8;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave * 4 + i) * 8 + (lane >> 3);  // tile row
+            const int c = (lane & 7) ^ nt_swz(r);            // global chunk stored at position lane&7
+            int ga = sm0 + r; ga = ga < M ? ga : M - 1;
+            int gb = sn0 + r; gb = gb < N ? gb : N - 1;
+            asrc[i] = A + (size_t)ga * lda + c * 8;
+            bsrc[i] = B + (size_t)gb * ldb + c * 8;
+        }
+    };
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * BT_STAGE_BYTES + wave * 4096;
 #pragma unroll
@@ -299,28 +419,320 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
         }
     };
 
-    const int nk = K / BT_K;
+    constexpr bool PRE_RES = false;  // measured: prefetching the fp32 residual tile does not pay
+    constexpr bool PRE_AUX = (MODE == SSL4GIE_EPI_DGELU) && (sizeof(TC) == 2);
+    f32x4 pre_res[PRE_RES ? 4 : 1][4];
+    u32x2 pre_aux[PRE_AUX ? 4 : 1][4];
+    (void)pre_res; (void)pre_aux;
+
+    point_at(0);
     stage(0, 0);
+    int st_ti = 0, st_kt = 1;  // next K-tile to stage
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int cur = 0;
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        stage(cur ^ 1, kt + 1);  // LDS-DMA of the next tile flies under this tile's MFMAs
-        compute(cur);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        cur ^= 1;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const int tile = pos + ti * G;
+        const int m0 = (tile / tiles_n) * BT_M, n0 = (tile % tiles_n) * BT_N;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (st_kt == nk) { st_kt = 0; ++st_ti; if (st_ti < my_tiles) point_at(st_ti); }
+            if (st_ti < my_tiles) { stage(cur ^ 1, st_kt); ++st_kt; }
+            if (kt == nk - 1) {
+                // epilogue operands (fp32 residual tile / bf16 pre-activation tile) are requested
+                // BEFORE the last K-step's MFMAs so their HBM latency hides under them
+                if constexpr (PRE_RES) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int m = m0 + wm + i * 16 + (lane & 15);
+                            const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
+                            pre_res[i][j] = (m < M && n < N) ? ld4(e.residual + (size_t)m * e.ldr + n)
+                                                             : f32x4{0, 0, 0, 0};
+                        }
+                }
+                if constexpr (PRE_AUX) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int m = m0 + wm + i * 16 + (lane & 15);
+                            const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
+                            pre_aux[i][j] = (m < M && n < N)
+                                ? *(const u32x2*)((const bf16_t*)e.aux + (size_t)m * ldc + n) : u32x2{0, 0};
+                        }
+                }
+            }
+            compute(cur);
+            if (kt == nk - 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
+                        acc[i][j] *= e.alpha;
+                        if constexpr (MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
+                                      MODE == SSL4GIE_EPI_BIAS_RESIDUAL) {
+                            if (e.bias && n < N) acc[i][j] += ld4(e.bias + n);
+                        }
+                        if constexpr (PRE_RES) acc[i][j] += pre_res[i][j];
+                        if constexpr (PRE_AUX) {
+                            const u32x2 r = pre_aux[i][j];
+                            acc[i][j][0] *= dgelu_fast(__uint_as_float(r[0] << 16));
+                            acc[i][j][1] *= dgelu_fast(__uint_as_float(r[0] & 0xffff0000u));
+                            acc[i][j][2] *= dgelu_fast(__uint_as_float(r[1] << 16));
+                            acc[i][j][3] *= dgelu_fast(__uint_as_float(r[1] & 0xffff0000u));
+                        }
+                    }
+                if constexpr (sizeof(TC) == 2 && MODE != SSL4GIE_EPI_BIAS_RESIDUAL) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    tile_out_lds<MODE == SSL4GIE_EPI_BIAS_GELU>(smem + cur * BT_STAGE_BYTES, (bf16_t*)C,
+                                                                (bf16_t*)e.out2, ldc, m0, n0, wm, wn, M,
+                                                                N, acc, wave, lane);
+                } else if constexpr (MODE == SSL4GIE_EPI_BIAS_RESIDUAL) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int m = m0 + wm + i * 16 + (lane & 15);
+                            const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
+                            if (m < M && n < N) {
+                                acc[i][j] += ld4(e.residual + (size_t)m * e.ldr + n);
+                                st4(C + (size_t)m * ldc + n, acc[i][j]);
+                            }
+                        }
+                } else {
+                    EpiArgs e2 = e;  // alpha / bias already applied above
+                    e2.alpha = 1.f;
+                    e2.bias = nullptr;
+                    constexpr int REST = (MODE == SSL4GIE_EPI_BIAS) ? SSL4GIE_EPI_NONE : MODE;
+                    epi_wave_tile<TC, REST>(e2, C, ldc, m0 + wm, n0 + wn, M, N, acc, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
     }
-    compute(cur);
+}
 
+// ---- NT, deep pipeline ---------------------------------------------------------------------
+// The 2-stage kernel above keeps only one 32-KiB K-tile in flight per workgroup, and measured
+// K-iterations are bound by the L2/MALL round trip (Little's law: 64 KiB per CU in flight / ~2.5 us
+// = 26 GB/s per CU), not by MFMA issue.  This variant trades K-tile depth for pipeline depth:
+// BK = 32 (16-KiB stages), a ring of 4 stages with THREE in flight behind counted `s_waitcnt
+// vmcnt(N)` (LDS-DMA issued from inline asm so hipcc's conservative vmcnt(0) never drains the
+// ring), one raw s_barrier per K-step, and a dedicated 16-KiB epilogue staging area.  80 KiB of LDS
+// per workgroup -> still 2 workgroups per CU (all 160 KiB used).  Persistent over tiles: the ring
+// keeps streaming across tile boundaries.
+//
+// vmcnt bookkeeping (per wave): 4 LDS-DMA per stage.  Before consuming stage `it` the wave allows
+// 4*min(2, stages issued after it) younger LDS-DMA to remain outstanding, plus the E epilogue
+// stores that were queued behind them during the 3 iterations that follow a tile's epilogue
+// (CDNA4 counts loads, stores and LDS-DMA in one in-order queue).
+#define N3_BK 32
+#define N3_STAGES 4
+#define N3_STAGE_BYTES 16384
+#define N3_LDS_BYTES (N3_STAGES * N3_STAGE_BYTES + 16384)
+DEVI int n3_swz(int r) { return (r >> 1) & 2; }  // 64-B rows: chunk ^= 2*bit2(row); conflict-free b128
+
+template <int N> DEVI void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+DEVI void n3_wait(int ahead, int extra) {  // ahead in 0..2 stages, extra in {0, 8, 16} stores
+    switch (ahead * 3 + (extra >> 3)) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<8>(); break;
+        case 2: wait_vmcnt<16>(); break;
+        case 3: wait_vmcnt<4>(); break;
+        case 4: wait_vmcnt<12>(); break;
+        case 5: wait_vmcnt<20>(); break;
+        case 6: wait_vmcnt<8>(); break;
+        case 7: wait_vmcnt<16>(); break;
+        default: wait_vmcnt<24>(); break;
+    }
+}
+// half-tile (64 rows x 128 cols bf16 = 16 KiB) images for the coalesced output stores
+DEVI void half_lds_write(char* buf, int row_in_half0, int col_base, const f32x4 (&v)[4][4], int lane,
+                         bool gelu) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm + i * 16 + (lane & 15);
-            const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
-            epi_store4<TC, true>(e, C, ldc, m, n, M, N, acc[i][j]);
+            const int row = row_in_half0 + 16 * i + (lane & 15);
+            const int col = col_base + 16 * j + 4 * (lane >> 4);
+            const int c = col >> 3;
+            f32x4 x = v[i][j];
+            if (gelu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = gelu_fast(x[q]);
+            }
+            u32x2 pk;
+            pk[0] = pack_bf2(x[0], x[1]);
+            pk[1] = pack_bf2(x[2], x[3]);
+            *(u32x2*)(buf + row * 256 + ((c ^ (row & 15)) << 4) + ((col & 4) << 1)) = pk;
+            __builtin_amdgcn_sched_barrier(0);
         }
+}
+DEVI void tile_store_2half(const char* h0, const char* h1, bf16_t* __restrict__ C, long long ldc, int m0,
+                           int n0, int M, int N, int wave, int lane) {
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int row = wave * 32 + it * 4 + (lane >> 4), c = lane & 15;
+        const char* src = (row < 64 ? h0 : h1) + (row & 63) * 256 + ((c ^ (row & 15)) << 4);
+        const u32x4 v = *(const u32x4*)src;
+        const int gm = m0 + row, gn = n0 + c * 8;
+        if (gm < M && gn < N) __builtin_nontemporal_store(v, (u32x4*)(C + (size_t)gm * ldc + gn));
+    }
+}
+
+template <typename TC, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt3_kernel(
+    const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
+    TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool LDS_EPI = (sizeof(TC) == 2) && (MODE != SSL4GIE_EPI_BIAS_RESIDUAL);
+    constexpr int ESTORES = LDS_EPI ? (MODE == SSL4GIE_EPI_BIAS_GELU ? 16 : 8) : 0;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int G = gridDim.x;
+    const int pos = xcd_remap(blockIdx.x, G);
+    const int my_tiles = (ntiles - pos + G - 1) / G;
+    const int nk = K / N3_BK;
+    const int total = my_tiles * nk;
+    char* epi_buf = smem + N3_STAGES * N3_STAGE_BYTES;
+
+    // this lane's source rows/chunks for the 2 A and 2 B pieces (16 rows each) its wave stages
+    const bf16_t* asrc[2];
+    const bf16_t* bsrc[2];
+    auto point_at = [&](int ti) {
+        const int tile = pos + ti * G;
+        const int sm0 = (tile / tiles_n) * BT_M, sn0 = (tile % tiles_n) * BT_N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (wave * 2 + i) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ n3_swz(r);
+            int ga = sm0 + r; ga = ga < M ? ga : M - 1;
+            int gb = sn0 + r; gb = gb < N ? gb : N - 1;
+            asrc[i] = A + (size_t)ga * lda + c * 8;
+            bsrc[i] = B + (size_t)gb * ldb + c * 8;
+        }
+    };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 2048);
+    int st_ti = 0, st_kt = 0;  // next (tile, k-step) to stage
+    auto stage_next = [&](int buf) {
+        const unsigned base = lds0 + buf * N3_STAGE_BYTES;
+        const size_t ko = (size_t)st_kt * N3_BK;
+        glds16_asm(asrc[0] + ko, base);
+        glds16_asm(asrc[1] + ko, base + 1024);
+        glds16_asm(bsrc[0] + ko, base + 8192);
+        glds16_asm(bsrc[1] + ko, base + 8192 + 1024);
+        if (++st_kt == nk) {
+            st_kt = 0;
+            if (++st_ti < my_tiles) point_at(st_ti);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wm + i * 16 + (lane & 15), rb = wn + i * 16 + (lane & 15);
+        a_off[i] = ra * 64 + (((lane >> 4) ^ n3_swz(ra)) << 4);
+        b_off[i] = 8192 + rb * 64 + (((lane >> 4) ^ n3_swz(rb)) << 4);
+    }
+
+    point_at(0);
+    int issued = 0;
+    for (; issued < N3_STAGES - 1 && issued < total; ++issued) stage_next(issued);
+
+    int since_epi = 1 << 20;  // iterations since the last epilogue (stores queued behind DMA)
+    int kt = 0, ti = 0;
+    for (int it = 0; it < total; ++it) {
+        const int ahead = issued - it - 1;  // stages issued after stage `it` (0..2)
+        n3_wait(ahead, since_epi < N3_STAGES - 1 ? ESTORES : 0);
+        __builtin_amdgcn_s_barrier();
+        if (issued < total) { stage_next(issued % N3_STAGES); ++issued; }
+        ++since_epi;
+        {
+            const char* base = smem + (it % N3_STAGES) * N3_STAGE_BYTES;
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *(const bf16x8*)(base + a_off[i]);
+                bfr[i] = *(const bf16x8*)(base + b_off[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (++kt == nk) {
+            kt = 0;
+            const int tile = pos + ti * G;
+            ++ti;
+            const int m0 = (tile / tiles_n) * BT_M, n0 = (tile % tiles_n) * BT_N;
+            if constexpr (LDS_EPI) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] *= e.alpha;
+                        const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
+                        if (MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU) {
+                            if (e.bias && n < N) acc[i][j] += ld4(e.bias + n);
+                        } else if (MODE == SSL4GIE_EPI_DGELU) {
+                            const int m = m0 + wm + i * 16 + (lane & 15);
+                            if (m < M && n < N) {
+                                const f32x4 u = ld4((const bf16_t*)e.aux + (size_t)m * ldc + n);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) acc[i][j][q] *= dgelu_fast(u[q]);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // rows 0-63 -> dedicated area, rows 64-127 -> the stage buffer just consumed
+                char* h0 = epi_buf;
+                char* h1 = smem + (it % N3_STAGES) * N3_STAGE_BYTES;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // all waves are done reading this stage
+                half_lds_write(wm ? h1 : h0, 0, wn, acc, lane, false);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                tile_store_2half(h0, h1, (bf16_t*)C, ldc, m0, n0, M, N, wave, lane);
+                if (MODE == SSL4GIE_EPI_BIAS_GELU) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    half_lds_write(wm ? h1 : h0, 0, wn, acc, lane, true);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    tile_store_2half(h0, h1, (bf16_t*)e.out2, ldc, m0, n0, M, N, wave, lane);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // the store allowance is exact only if no store instruction was skipped (full tile)
+                since_epi = (m0 + BT_M <= M && n0 + BT_N <= N) ? 0 : (1 << 20);
+            } else {
+                epi_wave_tile<TC, MODE>(e, C, ldc, m0 + wm, n0 + wn, M, N, acc, lane);
+                since_epi = 1 << 20;  // compiler-visible loads/stores: keep the conservative count
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        }
+    }
 }
 
 // ---- TN --------------------------------------------------------------------------------
@@ -446,14 +858,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(
     const long long ldo = (splits == 1) ? ldc : N;
     EpiArgs es = e;
     if (splits != 1) { es.mode = SSL4GIE_EPI_NONE; es.accumulate = 0; es.alpha = 1.f; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm + i * 16 + (lane & 15);
-            const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
-            epi_store4<float, true>(es, out, ldo, m, n, M, N, acc[i][j]);
-        }
+    epi_wave_tile<float, SSL4GIE_EPI_NONE>(es, out, ldo, m0 + wm, n0 + wn, M, N, acc, lane);
 }
 
 // C[m, n] (+)= alpha * sum_s slabs[s][m][n]   (N % 4 == 0)
@@ -476,6 +881,13 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
 // =====================================================================================
 // dispatch
 // =====================================================================================
+// kernel selection knob for A/B measurements (tools/gemm_bench.py): SSL4GIE_NT_DEEP=1 selects the
+// 4-stage BK=32 ring, default is the 2-stage BK=64 kernel (faster on every shape measured).
+static bool nt_use_deep() {
+    static int v = -1;
+    if (v < 0) { const char* s = getenv("SSL4GIE_NT_DEEP"); v = (s && s[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
 static bool is16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static bool nt_ok(const ssl4gie_gemm_desc* d) {
@@ -484,7 +896,10 @@ static bool nt_ok(const ssl4gie_gemm_desc* d) {
            d->sBn % 8 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && is16(d->A) && is16(d->B) &&
            is16(d->C) && (!d->residual || (d->ldr % 4 == 0 && is16(d->residual))) &&
            (!d->bias || is16(d->bias)) && (!d->aux || is16(d->aux)) &&
-           (!d->out2 || is16(d->out2)) && d->M > 0 && d->N > 0;
+           (!d->out2 || is16(d->out2)) && d->M > 0 && d->N > 0 &&
+           // bf16 outputs leave through the LDS-staged 16-byte row stores
+           (d->dtype_c == SSL4GIE_F32 || d->epilogue == SSL4GIE_EPI_BIAS_RESIDUAL ||
+            (d->N % 8 == 0 && d->ldc % 8 == 0 && !d->accumulate));
 }
 static bool tn_ok(const ssl4gie_gemm_desc* d) {
     return d->dtype_ab == SSL4GIE_BF16 && d->dtype_c == SSL4GIE_F32 &&
@@ -531,16 +946,40 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
 
     if (nt_ok(d)) {
         const int tm = (d->M + BT_M - 1) / BT_M, tn = (d->N + BT_N - 1) / BT_N;
-        dim3 grid(tm * tn), block(256);
+        const int ntiles = tm * tn;
+        dim3 grid(ntiles < NT_MAX_WGS ? ntiles : NT_MAX_WGS), block(256);
         ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
-        if (d->dtype_c == SSL4GIE_BF16)
-            hipLaunchKernelGGL(gemm_bf16_nt_kernel<bf16_t>, grid, block, BT_LDS_BYTES, st,
-                               (const bf16_t*)d->A, d->sAm, (const bf16_t*)d->B, d->sBn,
-                               (bf16_t*)d->C, d->ldc, d->M, d->N, d->K, tn, e);
-        else
-            hipLaunchKernelGGL(gemm_bf16_nt_kernel<float>, grid, block, BT_LDS_BYTES, st,
-                               (const bf16_t*)d->A, d->sAm, (const bf16_t*)d->B, d->sBn,
-                               (float*)d->C, d->ldc, d->M, d->N, d->K, tn, e);
+#define NT_LAUNCH(TC_, MODE_)                                                                      \
+    do {                                                                                           \
+        if (nt_use_deep()) {                                                                       \
+            auto kfn = gemm_bf16_nt3_kernel<TC_, MODE_>;                                           \
+            static bool attr_set = false; /* idempotent; a benign race only repeats the call */    \
+            if (!attr_set) {                                                                       \
+                HIP_RET(hipFuncSetAttribute((const void*)kfn,                                      \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                            N3_LDS_BYTES));                                        \
+                attr_set = true;                                                                   \
+            }                                                                                      \
+            hipLaunchKernelGGL(kfn, grid, block, N3_LDS_BYTES, st, (const bf16_t*)d->A, d->sAm,    \
+                               (const bf16_t*)d->B, d->sBn, (TC_*)d->C, d->ldc, d->M, d->N, d->K,  \
+                               tn, ntiles, e);                                                     \
+        } else {                                                                                   \
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<TC_, MODE_>), grid, block, BT_LDS_BYTES, st,   \
+                               (const bf16_t*)d->A, d->sAm, (const bf16_t*)d->B, d->sBn,           \
+                               (TC_*)d->C, d->ldc, d->M, d->N, d->K, tn, ntiles, e);               \
+        }                                                                                          \
+    } while (0)
+#define NT_MODES(TC_)                                                                    \
+    switch (d->epilogue) {                                                               \
+        case SSL4GIE_EPI_BIAS: NT_LAUNCH(TC_, SSL4GIE_EPI_BIAS); break;                  \
+        case SSL4GIE_EPI_BIAS_GELU: NT_LAUNCH(TC_, SSL4GIE_EPI_BIAS_GELU); break;        \
+        case SSL4GIE_EPI_BIAS_RESIDUAL: NT_LAUNCH(TC_, SSL4GIE_EPI_BIAS_RESIDUAL); break; \
+        case SSL4GIE_EPI_DGELU: NT_LAUNCH(TC_, SSL4GIE_EPI_DGELU); break;                \
+        default: NT_LAUNCH(TC_, SSL4GIE_EPI_NONE); break;                                \
+    }
+        if (d->dtype_c == SSL4GIE_BF16) { NT_MODES(bf16_t) } else { NT_MODES(float) }
+#undef NT_MODES
+#undef NT_LAUNCH
         LAUNCH_CHECK();
         return 0;
     }
