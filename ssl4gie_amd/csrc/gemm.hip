@@ -18,21 +18,9 @@
 //
 // Replaces the cuBLAS calls behind nn.Linear in timm Block — reference call
 // sites Models/mae/models_mae.py:39-41,47,53-55,59 and Models/models.py:171-173.
-#include "common.h"
-#include "ssl4gie_hip.h"
+#include "gemm_internal.h"
 #include "prof.h"
 #include <stdlib.h>
-
-struct EpiArgs {
-    float alpha;
-    int mode;
-    const float* bias;
-    const float* residual;
-    long long ldr;
-    const void* aux;
-    void* out2;
-    int accumulate;
-};
 
 struct GemmArgs {
     int M, N, K, batch2;
@@ -945,6 +933,7 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate};
 
     if (nt_ok(d)) {
+        if (ssl4gie_internal_nt256_ok(d)) return ssl4gie_internal_nt256_launch(d, st);
         const int tm = (d->M + BT_M - 1) / BT_M, tn = (d->N + BT_N - 1) / BT_N;
         const int ntiles = tm * tn;
         dim3 grid(ntiles < NT_MAX_WGS ? ntiles : NT_MAX_WGS), block(256);

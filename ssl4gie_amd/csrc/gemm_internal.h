@@ -1,0 +1,21 @@
+// Internal GEMM plumbing shared by gemm.hip and gemm_nt256.hip (not part of the C ABI).
+#pragma once
+#include "common.h"
+#include "ssl4gie_hip.h"
+
+struct EpiArgs {
+    float alpha;
+    int mode;
+    const float* bias;
+    const float* residual;
+    long long ldr;
+    const void* aux;
+    void* out2;
+    int accumulate;
+};
+
+// 256x256x64 ping-pong NT kernel (gemm_nt256.hip): C[M,N] = A[M,K] B[N,K]^T with the fused
+// epilogues.  `nt256_ok` says whether the descriptor (already known to satisfy the NT fast-path
+// layout rules) is worth / able to run on it; `nt256_launch` enqueues it.
+bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d);
+int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st);

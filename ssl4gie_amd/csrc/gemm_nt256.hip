@@ -1,0 +1,439 @@
+// 256x256x64 "ping-pong" bf16 NT GEMM for gfx950:  C[M,N] = epilogue(A[M,K] * B[N,K]^T).
+//
+// Why a second NT kernel: a 128x128 tile moves 32 KiB of operands per 2.1 MFLOP (64 FLOP/B), so at
+// the MFMA rate of one CU it asks the XCD's L2 for ~150 GB/s per CU = 38 TB/s chip-wide — more
+// than the L2s deliver (MI355X_MICROARCH.md: ~34 TB/s).  A 256x256 tile halves that.  One
+// workgroup of 8 waves per CU (2 waves per SIMD), wave grid 2 (M) x 4 (N), wave tile 128 x 64 =
+// 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16 (128 VGPRs).
+//
+// Schedule (cdna_hip_programming.md §5 "8-phase" structure, own derivation):
+//  * a K-tile (64 deep) is split into 4 "half-tiles" of 128 rows x 128 B = 16 KiB, in the order
+//    they are needed: B_h0, A_h0, B_h1, A_h1, where A_h{q} holds rows {128 wr + 64 q + 0..63} of
+//    both wave rows and B_h{q} holds columns {64 wc + 32 q + 0..31} of all four wave columns.
+//    Two K-tile buffers (128 KiB) + 8 x 4 KiB wave-private epilogue staging = all 160 KiB of LDS;
+//  * the K-tile is computed in 4 phases of 16 MFMAs per wave (one 64x32 quadrant each):
+//        P0: read B_h0 (4 ds_read_b128) then A_h0 (8)  -> quadrant (0,0)
+//        P1: read B_h1 (4)                              -> quadrant (0,1)
+//        P2: read A_h1 (8)                              -> quadrant (1,1)
+//        P3: no LDS reads                               -> quadrant (1,0)
+//    Every phase is {LOAD: ds_reads + 2 LDS-DMA of a later half-tile; s_barrier; MMA: 16 MFMAs;
+//    s_barrier}.  The wr=1 waves run one barrier behind the wr=0 waves, so on every SIMD one wave
+//    is in its MMA segment while its partner is in its LOAD segment (matrix beside memory);
+//  * the LDS-DMA stream (global_load_lds_dwordx4 issued from inline asm, so hipcc never drains it)
+//    runs 7 half-tiles ahead of consumption and is waited for ONCE per K-tile with a counted
+//    s_waitcnt vmcnt(6) (3 half-tiles stay in flight across the barriers).  It is continuous across
+//    output tiles (persistent workgroups), so the short K of this workload (8-48 K-tiles) never
+//    pays a pipeline fill per tile.
+// Hazard bookkeeping (g = global phase index; interval I_n = between barriers n-1 and n; the wr=0
+// group runs LOAD(g) in I_2g and MMA(g) in I_2g+1, the wr=1 group one interval later):
+//   RAW: half-tile s is first read in phase need(s) >= wait_phase(s)+1 — every wave waited for
+//        its own DMA of s before a barrier that precedes the reading interval of either group;
+//   WAR: the half-tile issued in phase g overwrites the one read in phase g-2 (reads complete
+//        at the lgkmcnt wait that opens MMA(g-2), two barriers earlier for either group), except
+//        B_h0, issued in P1 and read in P0: its 4 reads are issued first and retired by
+//        s_waitcnt lgkmcnt(8) BEFORE P0's first barrier.
+//
+// Epilogue: bf16 outputs are transposed through the wave-private LDS staging area and leave as
+// whole 128-byte row segments (16 B per lane); fp32 outputs (residual stream) are stored from the
+// accumulator layout (4 consecutive columns per lane).
+//
+// Replaces the cuBLAS calls behind nn.Linear in timm Block / MAE decoder (reference
+// call sites Models/mae/models_mae.py:39-41,47,53-55,59; Models/models.py:171-173).
+#include "gemm_internal.h"
+#include "prof.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+#define P_BM 256
+#define P_BN 256
+#define P_BK 64
+#define P_HALF 16384
+#define P_BUF 65536
+#define P_STG_WAVE 4096
+#define P_LDS_BYTES (2 * P_BUF + 8 * P_STG_WAVE)  // 163840 = all of the CU's LDS
+
+DEVI int p_swz(int r) { return (r >> 1) & 7; }
+
+DEVI unsigned p_lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// two LDS-DMA pieces (1 KiB each) of one half-tile: wave-uniform 64-bit base in SGPRs, per-lane
+// 32-bit byte offsets, wave-uniform LDS destinations l0 and l0 + 1024.  M0 is saved / restored
+// inside the statement (cdna_hip_programming.md §5.7); nothing here is visible to hipcc's waitcnt
+// bookkeeping — the caller counts vmcnt by hand.
+DEVI void p_glds2(const void* sbase, unsigned v0, unsigned v1, unsigned l0, unsigned l1) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %1\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(sbase), "v"(v0), "v"(v1), "s"(l0), "s"(l1)
+        : "memory");
+}
+
+#define P_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// ---- epilogue of one wave's 128 x 64 sub-tile ---------------------------------------------------
+// acc[mt][nt]: rows rbase + 16 mt + (l & 15), columns cbase + 16 nt + 4 (l >> 4) + 0..3
+template <typename TC, int MODE, bool FULL>
+DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
+                     const float* __restrict__ bias, const float* __restrict__ residual,
+                     const long long ldr, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out2,
+                     const int accumulate, TC* __restrict__ C, long long ldc, int rbase, int cbase,
+                     int M, int N, int lane) {
+    const int r16 = lane & 15, g4 = lane >> 4;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = cbase + 16 * nt + 4 * g4;
+        bias4[nt] = f32x4{0, 0, 0, 0};
+        if constexpr (MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
+                      MODE == SSL4GIE_EPI_BIAS_RESIDUAL) {
+            if (bias && (FULL || n < N)) bias4[nt] = ld4(bias + n);
+        }
+    }
+    if constexpr (sizeof(TC) == 2) {
+        // bf16: stage 16 rows x 64 columns (2 KiB), chunk c of row r at position c ^ (r & 7)
+        const int R0 = lane >> 3, Cc = lane & 7;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int grow = rbase + 16 * mt + r16;
+            f32x4 v[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                v[nt] = acc[mt][nt] * alpha + bias4[nt];
+                if constexpr (MODE == SSL4GIE_EPI_DGELU) {
+                    const int n = cbase + 16 * nt + 4 * g4;
+                    if (FULL || (grow < M && n < N)) {
+                        const f32x4 u = ld4(aux + (size_t)grow * ldc + n);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[nt][q] *= dgelu_fast(u[q]);
+                    }
+                }
+            }
+            auto emit = [&](bf16_t* __restrict__ dst, auto gelu_c) {
+                constexpr bool GELU = decltype(gelu_c)::value;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4 x = v[nt];
+                    if constexpr (GELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] = gelu_fast(x[q]);
+                    }
+                    u32x2 pk;
+                    pk[0] = pack_bf2(x[0], x[1]);
+                    pk[1] = pack_bf2(x[2], x[3]);
+                    const int c = nt * 2 + (g4 >> 1);
+                    *(u32x2*)(stg + r16 * 128 + ((c ^ (r16 & 7)) << 4) + ((g4 & 1) << 3)) = pk;
+                }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int R = R0 + 8 * hh;
+                    const u32x4 w = *(const u32x4*)(stg + R * 128 + ((Cc ^ (R & 7)) << 4));
+                    const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
+                    if (FULL || (gm < M && gn < N)) *(u32x4*)(dst + (size_t)gm * ldc + gn) = w;
+                }
+            };
+            emit((bf16_t*)C, std::false_type{});
+            if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU) emit(out2, std::true_type{});
+        }
+    } else {
+        // fp32 outputs straight from the accumulator layout (16 B per lane)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int grow = rbase + 16 * mt + r16;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = cbase + 16 * nt + 4 * g4;
+                if (FULL || (grow < M && n < N)) {
+                    f32x4 v = acc[mt][nt] * alpha + bias4[nt];
+                    float* c = (float*)C + (size_t)grow * ldc + n;
+                    if constexpr (MODE == SSL4GIE_EPI_BIAS_RESIDUAL)
+                        v += ld4(residual + (size_t)grow * ldr + n);
+                    if constexpr (MODE == SSL4GIE_EPI_NONE) {
+                        if (accumulate) v += ld4(c);
+                    }
+                    st4(c, v);
+                }
+            }
+        }
+    }
+}
+
+template <typename TC, int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
+    const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
+    TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int G = gridDim.x;
+    const int pos = xcd_remap(blockIdx.x, G);
+    const int my_tiles = (ntiles - pos + G - 1) / G;
+    const int nk = K / P_BK;
+    const int total_kt = my_tiles * nk;
+    // epilogue arguments as plain scalars (a by-reference struct ends up on the stack)
+    const float e_alpha = e.alpha;
+    const float* e_bias = e.bias;
+    const float* e_residual = e.residual;
+    const long long e_ldr = e.ldr;
+    const bf16_t* e_aux = (const bf16_t*)e.aux;
+    bf16_t* e_out2 = (bf16_t*)e.out2;
+    const int e_accumulate = e.accumulate;
+
+    // ------------------------------------------------------------------ LDS-DMA stream state
+    // this lane's source byte offsets: v<item>_<piece> for the 4 half-tiles x 2 pieces (named
+    // scalars on purpose: an indexed array can end up in scratch, and a scratch reload is a VMEM
+    // load whose compiler-inserted wait would drain the LDS-DMA stream)
+    unsigned v0_0 = 0, v0_1 = 0, v1_0 = 0, v1_1 = 0, v2_0 = 0, v2_1 = 0, v3_0 = 0, v3_1 = 0;
+    auto point_at = [&](int ti) {
+        const int tile = pos + ti * G;
+        const int sm0 = (tile / tiles_n) * P_BM, sn0 = (tile % tiles_n) * P_BN;
+        auto offs = [&](int i, int h, bool is_a) -> unsigned {
+            const int lr = (wave * 2 + i) * 8 + (lane >> 3);  // local row of the half-tile
+            const int c = (lane & 7) ^ p_swz(lr);             // global chunk kept at position l&7
+            if (is_a) {
+                int ra = sm0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+                ra = ra < M ? ra : M - 1;
+                return (unsigned)(((long long)ra * lda + c * 8) * 2);
+            }
+            int rb = sn0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+            rb = rb < N ? rb : N - 1;
+            return (unsigned)(((long long)rb * ldb + c * 8) * 2);
+        };
+        v0_0 = offs(0, 0, false); v0_1 = offs(1, 0, false);  // B_h0
+        v1_0 = offs(0, 0, true);  v1_1 = offs(1, 0, true);   // A_h0
+        v2_0 = offs(0, 1, false); v2_1 = offs(1, 1, false);  // B_h1
+        v3_0 = offs(0, 1, true);  v3_1 = offs(1, 1, true);   // A_h1
+    };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + wave * 2048);
+    int s_ktg = 0, s_kt = 0, s_ti = 0;  // stream cursor: global K-tile, K-tile in tile, tile
+    // issue half-tile J (0 B_h0, 1 A_h0, 2 B_h1, 3 A_h1) of the stream's current K-tile
+    auto issue = [&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        if (s_ktg < total_kt) {
+            const unsigned dst = lds0 + (s_ktg & 1) * P_BUF + J * P_HALF;
+            const bf16_t* base = ((J & 1) ? A : B) + (size_t)s_kt * P_BK;
+            const unsigned va = J == 0 ? v0_0 : J == 1 ? v1_0 : J == 2 ? v2_0 : v3_0;
+            const unsigned vb = J == 0 ? v0_1 : J == 1 ? v1_1 : J == 2 ? v2_1 : v3_1;
+            p_glds2(base, va, vb, dst, dst + 1024);
+        }
+        if (J == 3) {
+            ++s_ktg;
+            if (++s_kt == nk) {
+                s_kt = 0;
+                if (++s_ti < my_tiles) point_at(s_ti);
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // ------------------------------------------------------------------ fragment reads
+    const int l15 = lane & 15, lg = lane >> 4;
+    // lane-dependent parts of the LDS addresses (the swizzle only depends on l15: tile-local rows
+    // are l15 + multiples of 16)
+    const int sw = p_swz(l15);
+    const int offA = (wr * 64 + l15) * 128, offB = (wc * 32 + l15) * 128;
+    const int ch0 = ((0 * 4 + lg) ^ sw) << 4, ch1 = ((1 * 4 + lg) ^ sw) << 4;
+    auto ldA = [&](int buf, int h, int mi, int ks) -> bf16x8 {
+        return *(const bf16x8*)(smem + buf * P_BUF + (h ? 3 : 1) * P_HALF + offA + mi * 2048 +
+                                (ks ? ch1 : ch0));
+    };
+    auto ldB = [&](int buf, int h, int ni, int ks) -> bf16x8 {
+        return *(const bf16x8*)(smem + buf * P_BUF + (h ? 2 : 0) * P_HALF + offB + ni * 2048 +
+                                (ks ? ch1 : ch0));
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    bf16x8 a[4][2], b0[2][2], b1[2][2];
+
+    auto mma = [&](auto QMc, auto QNc, bf16x8 (&bb)[2][2]) {
+        constexpr int QM = decltype(QMc)::value, QN = decltype(QNc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[QM * 4 + mi][QN * 2 + ni] =
+                        P_MFMA(bb[ni][ks], a[mi][ks], acc[QM * 4 + mi][QN * 2 + ni]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ------------------------------------------------------------------ prologue
+    point_at(0);
+    issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
+    issue(I0{}); issue(I1{}); issue(I2{});
+    if (total_kt >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
+
+    int c_kt = 0, c_ti = 0;
+    for (int T = 0; T < total_kt; ++T) {
+        const int cb = T & 1;
+        // ---------------- P0
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = ldB(cb, 0, ni, ks);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 0, mi, ks);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(I3{});
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // B_h0 reads retired (WAR, see header)
+        __builtin_amdgcn_s_barrier();
+        mma(I0{}, I0{}, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- P1
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = ldB(cb, 1, ni, ks);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(I0{});
+        __builtin_amdgcn_s_barrier();
+        mma(I0{}, I1{}, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- P2
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 1, mi, ks);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(I1{});
+        __builtin_amdgcn_s_barrier();
+        mma(I1{}, I1{}, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- P3
+        issue(I2{});
+        // K-tile T+1 must have landed before the next phase reads it; the three half-tiles issued
+        // in P1..P3 (of K-tile T+2) may stay in flight
+        if (T + 2 < total_kt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mma(I1{}, I0{}, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++c_kt == nk) {
+            // Output tile finished.  The wr=0 group ends its MMA interval first and runs its
+            // epilogue in the next one, where the wr=1 group (one barrier behind) runs its own: the
+            // two epilogues overlap instead of costing two MFMA-idle intervals per tile.
+            c_kt = 0;
+            const int tile = pos + c_ti * G;
+            ++c_ti;
+            const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * P_BN;
+            if (wr == 0) __builtin_amdgcn_s_barrier();
+            char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
+            if (m0 + P_BM <= M && n0 + P_BN <= N)
+                p_epilogue<TC, MODE, true>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                                           e_out2, e_accumulate, C, ldc, m0 + wr * 128,
+                                           n0 + wc * 64, M, N, lane);
+            else
+                p_epilogue<TC, MODE, false>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                                            e_out2, e_accumulate, C, ldc, m0 + wr * 128,
+                                            n0 + wc * 64, M, N, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+            if (wr == 1) __builtin_amdgcn_s_barrier();
+        } else {
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // every wave executes the same number of barriers
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+static int nt256_mode() {  // SSL4GIE_NT256: "0" never, "1" whenever possible, unset = heuristic
+    static int v = -2;
+    if (v == -2) {
+        const char* s = getenv("SSL4GIE_NT256");
+        v = !s ? -1 : (s[0] == '0' ? 0 : 1);
+    }
+    return v;
+}
+
+bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
+    const int mode = nt256_mode();
+    if (mode == 0) return false;
+    // 32-bit per-lane byte offsets; whole K-tiles; 16-byte row segments on the output
+    if ((long long)d->M * d->sAm * 2 >= (1LL << 32) || (long long)d->N * d->sBn * 2 >= (1LL << 32))
+        return false;
+    if (d->K % P_BK != 0 || d->N % 8 != 0 || d->ldc % 8 != 0) return false;
+    const int ep = d->epilogue;
+    if (d->dtype_c == SSL4GIE_BF16) {
+        if (ep == SSL4GIE_EPI_BIAS_RESIDUAL || d->accumulate) return false;
+    } else {
+        if (ep == SSL4GIE_EPI_BIAS_GELU || ep == SSL4GIE_EPI_DGELU) return false;
+    }
+    if (mode == 1) return true;
+    // heuristic: enough 256x256 tiles to fill most of the chip
+    const long long tiles = (long long)((d->M + P_BM - 1) / P_BM) * ((d->N + P_BN - 1) / P_BN);
+    return tiles >= 128;
+}
+
+int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
+    const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + P_BN - 1) / P_BN;
+    const int ntiles = tm * tn;
+    dim3 grid(ntiles < 256 ? ntiles : 256), block(512);
+    EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate};
+    ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
+#define P_LAUNCH(TC_, MODE_)                                                                       \
+    do {                                                                                           \
+        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_>;                                             \
+        static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
+        if (!attr_set) {                                                                           \
+            HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES)); \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAm,         \
+                           (const bf16_t*)d->B, d->sBn, (TC_*)d->C, d->ldc, d->M, d->N, d->K, tn,  \
+                           ntiles, e);                                                             \
+    } while (0)
+    if (d->dtype_c == SSL4GIE_BF16) {
+        switch (d->epilogue) {
+            case SSL4GIE_EPI_BIAS: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS); break;
+            case SSL4GIE_EPI_BIAS_GELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU); break;
+            case SSL4GIE_EPI_DGELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_DGELU); break;
+            case SSL4GIE_EPI_NONE: P_LAUNCH(bf16_t, SSL4GIE_EPI_NONE); break;
+            default: return ARG_ERR;
+        }
+    } else {
+        switch (d->epilogue) {
+            case SSL4GIE_EPI_BIAS: P_LAUNCH(float, SSL4GIE_EPI_BIAS); break;
+            case SSL4GIE_EPI_BIAS_RESIDUAL: P_LAUNCH(float, SSL4GIE_EPI_BIAS_RESIDUAL); break;
+            case SSL4GIE_EPI_NONE: P_LAUNCH(float, SSL4GIE_EPI_NONE); break;
+            default: return ARG_ERR;
+        }
+    }
+#undef P_LAUNCH
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -110,7 +110,10 @@ def test_gemm_generic_batched():
 
 # ------------------------------------------------------------------ bf16 NT GEMM
 NT_SHAPES = [(128, 128, 64), (400, 768, 768), (1576, 1536, 512), (130, 132, 128), (12, 2048, 512),
-             (1000, 512, 2048)]
+             (1000, 512, 2048),
+             # large enough for the 256x256 ping-pong kernel's heuristic (>= 128 tiles), with ragged
+             # M / N edges and 1, 2 and several K-tiles
+             (4096, 2048, 64), (4000, 2056, 128), (8192, 1024, 512), (3000, 3072, 768)]
 
 
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
@@ -125,7 +128,8 @@ def test_gemm_bf16_nt_exact_integers(M, N, K):
     assert torch.equal(y.cpu().double(), ref), f"max diff {(y.cpu().double() - ref).abs().max()}"
 
 
-@pytest.mark.parametrize("M,N,K", [(400, 768, 768), (1576, 2048, 512)])
+@pytest.mark.parametrize("M,N,K", [(400, 768, 768), (1576, 2048, 512), (4352, 2048, 512),
+                                   (4100, 2040, 256)])
 def test_gemm_bf16_nt_epilogues(M, N, K):
     from ssl4gie_amd import _lib, ops
     x = (torch.randn(M, K, generator=G(1)) * 0.5).to(BF)
