@@ -909,7 +909,7 @@ static int tn_splits(const ssl4gie_gemm_desc* d) {
 extern "C" size_t ssl4gie_gemm_workspace_bytes(const ssl4gie_gemm_desc* d) {
     if (!d) return 0;
     if (d->dtype_ab == SSL4GIE_BF16 && !nt_ok(d) && tn_ok(d)) {
-        const int s = tn_splits(d);
+        const int s = ssl4gie_internal_tn256_ok(d) ? ssl4gie_internal_tn256_splits(d) : tn_splits(d);
         return s > 1 ? (size_t)s * d->M * d->N * sizeof(float) : 0;
     }
     return 0;
@@ -974,16 +974,24 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     }
     if (tn_ok(d)) {
         const int tm = (d->M + BT_M - 1) / BT_M, tn = (d->N + BT_N - 1) / BT_N;
-        const int splits = tn_splits(d);
+        const bool big = ssl4gie_internal_tn256_ok(d);
+        const int splits = big ? ssl4gie_internal_tn256_splits(d) : tn_splits(d);
         if (splits > 1)
             REQUIRE(workspace && workspace_bytes >= (size_t)splits * d->M * d->N * sizeof(float));
-        dim3 grid(tm * tn * splits), block(256);
-        ProfScope prof(PROF_GEMM_TN, 2.0 * d->M * d->N * d->K, st);
-        hipLaunchKernelGGL(gemm_bf16_tn_kernel, grid, block, BT_LDS_BYTES, st,
-                           (const bf16_t*)d->A, d->sAk, (const bf16_t*)d->B, d->sBk,
-                           (float*)d->C, d->ldc, (float*)workspace, d->M, d->N, d->K, tn,
-                           tm * tn, splits, e);
-        LAUNCH_CHECK();
+        {
+            ProfScope prof(PROF_GEMM_TN, 2.0 * d->M * d->N * d->K, st);
+            if (big) {
+                const int rc = ssl4gie_internal_tn256_launch(d, workspace, st);
+                if (rc) return rc;
+            } else {
+                dim3 grid(tm * tn * splits), block(256);
+                hipLaunchKernelGGL(gemm_bf16_tn_kernel, grid, block, BT_LDS_BYTES, st,
+                                   (const bf16_t*)d->A, d->sAk, (const bf16_t*)d->B, d->sBk,
+                                   (float*)d->C, d->ldc, (float*)workspace, d->M, d->N, d->K, tn,
+                                   tm * tn, splits, e);
+                LAUNCH_CHECK();
+            }
+        }
         if (splits > 1) {
             const size_t total4 = (size_t)d->M * d->N / 4;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)),

@@ -1,0 +1,77 @@
+// Shared pieces of the 256x256x64 ping-pong GEMM kernels (gemm_nt256.hip, gemm_tn256.hip): tile
+// constants, the inline-asm LDS-DMA issue, and the fp32 epilogue that transposes accumulators
+// through the wave-private LDS staging area so that global accesses are whole 256-byte rows.
+#pragma once
+#include "gemm_internal.h"
+
+#define P_BM 256
+#define P_BN 256
+#define P_BK 64
+#define P_HALF 16384
+#define P_BUF 65536
+#define P_STG_WAVE 4096
+#define P_LDS_BYTES (2 * P_BUF + 8 * P_STG_WAVE)  // 163840 = all of the CU's LDS
+
+DEVI int p_swz(int r) { return (r >> 1) & 7; }
+
+DEVI unsigned p_lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// two LDS-DMA pieces (1 KiB each) of one half-tile: wave-uniform 64-bit base in SGPRs, per-lane
+// 32-bit byte offsets, wave-uniform LDS destinations l0 and l0 + 1024.  M0 is saved / restored
+// inside the statement (cdna_hip_programming.md §5.7); nothing here is visible to hipcc's waitcnt
+// bookkeeping — the caller counts vmcnt by hand.
+DEVI void p_glds2(const void* sbase, unsigned v0, unsigned v1, unsigned l0, unsigned l1) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %1\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(sbase), "v"(v0), "v"(v1), "s"(l0), "s"(l1)
+        : "memory");
+}
+
+#define P_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// fp32 outputs of one wave's 128 x 64 sub-tile.  acc[mt][nt]: rows rbase + 16 mt + (l & 15),
+// columns cbase + 16 nt + 4 (l >> 4) + 0..3.  Each 16 x 64 block goes through `stg` (4 KiB,
+// wave-private: LDS executes one wave's instructions in order, so no barrier is needed) and comes
+// back with a lane holding 16 B of a row and 16 lanes covering 256 contiguous bytes; the residual /
+// accumulate operand is read in that same layout.  Staging image: 16-B chunk c of row r at position
+// c ^ r (ds_write_b128 and ds_read_b128 conflict-free, tools/lds_bank_sim.py).
+template <bool FULL, bool RESID>
+DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f32x4 (&bias4)[4],
+                      const float* __restrict__ residual, const long long ldr, const bool accumulate,
+                      float* __restrict__ C, const long long ldc, int rbase, int cbase, int M, int N,
+                      int lane) {
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int R0 = lane >> 4, Cc = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 v = acc[mt][nt] * alpha + bias4[nt];
+            const int c = nt * 4 + g4;
+            *(f32x4*)(stg + r16 * 256 + ((c ^ r16) << 4)) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = R0 + 4 * q;
+            f32x4 w = *(const f32x4*)(stg + R * 256 + ((Cc ^ R) << 4));
+            const int gm = rbase + 16 * mt + R, gn = cbase + 4 * Cc;
+            if (FULL || (gm < M && gn < N)) {
+                float* c = C + (size_t)gm * ldc + gn;
+                if constexpr (RESID) w += ld4(residual + (size_t)gm * ldr + gn);
+                if (accumulate) w += ld4(c);
+                st4(c, w);
+            }
+        }
+    }
+}

@@ -19,3 +19,8 @@ struct EpiArgs {
 // layout rules) is worth / able to run on it; `nt256_launch` enqueues it.
 bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d);
 int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st);
+
+// 256x256x64 ping-pong TN kernel (gemm_tn256.hip): weight-gradient product with split-K slabs.
+bool ssl4gie_internal_tn256_ok(const ssl4gie_gemm_desc* d);
+int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d);
+int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, void* workspace, hipStream_t st);

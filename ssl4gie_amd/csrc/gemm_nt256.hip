@@ -33,53 +33,17 @@
 //        B_h0, issued in P1 and read in P0: its 4 reads are issued first and retired by
 //        s_waitcnt lgkmcnt(8) BEFORE P0's first barrier.
 //
-// Epilogue: bf16 outputs are transposed through the wave-private LDS staging area and leave as
-// whole 128-byte row segments (16 B per lane); fp32 outputs (residual stream) are stored from the
-// accumulator layout (4 consecutive columns per lane).
+// Epilogue: outputs are transposed through the wave-private LDS staging area and leave as whole
+// 128-byte (bf16) / 256-byte (fp32) row segments, 16 B per lane; the fp32 residual is read in that
+// same coalesced layout.
 //
 // Replaces the cuBLAS calls behind nn.Linear in timm Block / MAE decoder (reference
 // call sites Models/mae/models_mae.py:39-41,47,53-55,59; Models/models.py:171-173).
-#include "gemm_internal.h"
+#include "gemm256.h"
 #include "prof.h"
 
 #include <stdlib.h>
 #include <type_traits>
-
-#define P_BM 256
-#define P_BN 256
-#define P_BK 64
-#define P_HALF 16384
-#define P_BUF 65536
-#define P_STG_WAVE 4096
-#define P_LDS_BYTES (2 * P_BUF + 8 * P_STG_WAVE)  // 163840 = all of the CU's LDS
-
-DEVI int p_swz(int r) { return (r >> 1) & 7; }
-
-DEVI unsigned p_lds_addr(const void* p) {
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-}
-
-// two LDS-DMA pieces (1 KiB each) of one half-tile: wave-uniform 64-bit base in SGPRs, per-lane
-// 32-bit byte offsets, wave-uniform LDS destinations l0 and l0 + 1024.  M0 is saved / restored
-// inside the statement (cdna_hip_programming.md §5.7); nothing here is visible to hipcc's waitcnt
-// bookkeeping — the caller counts vmcnt by hand.
-DEVI void p_glds2(const void* sbase, unsigned v0, unsigned v1, unsigned l0, unsigned l1) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %1\n\t"
-        "s_mov_b32 m0, %5\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(sbase), "v"(v0), "v"(v1), "s"(l0), "s"(l1)
-        : "memory");
-}
-
-#define P_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // ---- epilogue of one wave's 128 x 64 sub-tile ---------------------------------------------------
 // acc[mt][nt]: rows rbase + 16 mt + (l & 15), columns cbase + 16 nt + 4 (l >> 4) + 0..3
@@ -146,25 +110,9 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
             if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU) emit(out2, std::true_type{});
         }
     } else {
-        // fp32 outputs straight from the accumulator layout (16 B per lane)
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int grow = rbase + 16 * mt + r16;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = cbase + 16 * nt + 4 * g4;
-                if (FULL || (grow < M && n < N)) {
-                    f32x4 v = acc[mt][nt] * alpha + bias4[nt];
-                    float* c = (float*)C + (size_t)grow * ldc + n;
-                    if constexpr (MODE == SSL4GIE_EPI_BIAS_RESIDUAL)
-                        v += ld4(residual + (size_t)grow * ldr + n);
-                    if constexpr (MODE == SSL4GIE_EPI_NONE) {
-                        if (accumulate) v += ld4(c);
-                    }
-                    st4(c, v);
-                }
-            }
-        }
+        p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL>(
+            acc, stg, alpha, bias4, residual, ldr, MODE == SSL4GIE_EPI_NONE && accumulate, (float*)C,
+            ldc, rbase, cbase, M, N, lane);
     }
 }
 

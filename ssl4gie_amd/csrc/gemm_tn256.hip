@@ -1,0 +1,253 @@
+// 256x256x64 ping-pong bf16 TN GEMM for gfx950:  C[M,N] = alpha * At[K,M]^T Bt[K,N]  (fp32 out).
+//
+// The weight-gradient product dW[out,in] = dY[T,out]^T X[T,in]: the contraction runs over tokens
+// (K = T = 12 800 / 50 432 in the MAE step) while M, N are the small layer widths, so the work is
+// split along K across workgroups (fp32 slabs + deterministic slab reduction, no atomics).
+//
+// Same schedule as gemm_nt256.hip (4 phases per K-tile, two staggered wave rows, LDS-DMA half-tile
+// stream 7 ahead behind a counted vmcnt) — see the header there for the hazard bookkeeping.  What
+// differs is the operand image: both operands are k-major in memory, so a half-tile is 64 k-rows x
+// 256 B (128 m- or n-values), staged by 4-row LDS-DMA pieces, and MFMA fragments are gathered
+// with ds_read_b64_tr_b16 (hardware transpose, two reads per fragment).  Image: 16-B chunk c of
+// k-row r at position c ^ tn_swz(r) (same swizzle as the 128x128 TN kernel, conflict-free for the
+// transposed reads; tools/lds_bank_sim.py).  P0 issues 8 + 16 transposed reads; lgkmcnt is a
+// 4-bit counter, so the early retire of the B_h0 reads is s_waitcnt lgkmcnt(15) (oldest 9 done).
+//
+// Replaces the autograd weight-gradient GEMMs of nn.Linear in timm Block / MAE decoder (SURVEY
+// §2.2 "bwd adds dW = X^T dY"; reference modules Models/mae/models_mae.py:39-41,47,53-55,59).
+#include "gemm256.h"
+#include "prof.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+DEVI int q_swz(int k) { return ((k & 3) | ((k >> 1) & 4)) << 1; }
+
+// MFMA operand (16 x-values x 32 k) out of a k-major half-tile image: lane l gets, for
+// x = x0 + (l & 15), the 8 k-values krow0 .. krow0+7 (krow0 = 32 ks + 8 (l >> 4))
+DEVI bf16x8 q_frag(const char* img, int krow0, int x0, int lane) {
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int c = (x0 >> 3) + (p >> 1);
+    const int r0 = krow0 + q, r1 = krow0 + 4 + q;
+    const int o0 = r0 * 256 + ((c ^ q_swz(r0)) << 4) + ((p & 1) << 3);
+    const int o1 = r1 * 256 + ((c ^ q_swz(r1)) << 4) + ((p & 1) << 3);
+    typedef __attribute__((address_space(3))) s16x4* lp_t;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(img + o0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(img + o1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// grid.x = ntiles * splits; split s of tile t covers K-tiles [nkt*s/splits, nkt*(s+1)/splits)
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
+    const bf16_t* __restrict__ At, long long ldat, const bf16_t* __restrict__ Bt, long long ldbt,
+    float* __restrict__ C, long long ldc, float* __restrict__ slabs, int M, int N, int K,
+    int tiles_n, int ntiles, int splits, float alpha, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = bid / ntiles, tile = bid % ntiles;
+    const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * P_BN;
+    const int nkt = K / P_BK;
+    const int kt0 = (int)((long long)nkt * split / splits);
+    const int kt1 = (int)((long long)nkt * (split + 1) / splits);
+    const int total_kt = kt1 - kt0;
+
+    // ---- LDS-DMA stream: this lane's source element offsets (without the k-row term of the
+    // K-tile, which advances the wave-uniform base): piece i covers k-rows 4 (2 wave + i) .. +3
+    unsigned v0_0, v0_1, v1_0, v1_1, v2_0, v2_1, v3_0, v3_1;
+    {
+        const int mch = (M >> 3) - 1, nch = (N >> 3) - 1;  // last valid 16-B chunk of a row
+        auto offs = [&](int i, int h, bool is_a) -> unsigned {
+            const int kr = (wave * 2 + i) * 4 + (lane >> 4);  // k-row inside the K-tile
+            const int c = (lane & 15) ^ q_swz(kr);            // logical chunk kept at position l&15
+            if (is_a) {
+                int ch = ((m0 + (c >> 3) * 128 + h * 64) >> 3) + (c & 7);
+                ch = ch < mch ? ch : mch;
+                return (unsigned)(((long long)kr * ldat + ch * 8) * 2);
+            }
+            int ch = ((n0 + (c >> 2) * 64 + h * 32) >> 3) + (c & 3);
+            ch = ch < nch ? ch : nch;
+            return (unsigned)(((long long)kr * ldbt + ch * 8) * 2);
+        };
+        v0_0 = offs(0, 0, false); v0_1 = offs(1, 0, false);  // B_h0
+        v1_0 = offs(0, 0, true);  v1_1 = offs(1, 0, true);   // A_h0
+        v2_0 = offs(0, 1, false); v2_1 = offs(1, 1, false);  // B_h1
+        v3_0 = offs(0, 1, true);  v3_1 = offs(1, 1, true);   // A_h1
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + wave * 2048);
+    int s_kt = 0;  // stream cursor (K-tile relative to kt0)
+    auto issue = [&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        if (s_kt < total_kt) {
+            const unsigned dst = lds0 + (s_kt & 1) * P_BUF + J * P_HALF;
+            const size_t krow = (size_t)(kt0 + s_kt) * P_BK;
+            const bf16_t* base = (J & 1) ? At + krow * ldat : Bt + krow * ldbt;
+            const unsigned va = J == 0 ? v0_0 : J == 1 ? v1_0 : J == 2 ? v2_0 : v3_0;
+            const unsigned vb = J == 0 ? v0_1 : J == 1 ? v1_1 : J == 2 ? v2_1 : v3_1;
+            p_glds2(base, va, vb, dst, dst + 1024);
+        }
+        if (J == 3) ++s_kt;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    const int kl = 8 * (lane >> 4);
+    auto ldA = [&](int buf, int h, int mi, int ks) -> bf16x8 {
+        return q_frag(smem + buf * P_BUF + (h ? 3 : 1) * P_HALF, ks * 32 + kl, wr * 64 + mi * 16, lane);
+    };
+    auto ldB = [&](int buf, int h, int ni, int ks) -> bf16x8 {
+        return q_frag(smem + buf * P_BUF + (h ? 2 : 0) * P_HALF, ks * 32 + kl, wc * 32 + ni * 16, lane);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    bf16x8 a[4][2], b0[2][2], b1[2][2];
+
+    auto mma = [&](auto QMc, auto QNc, bf16x8 (&bb)[2][2]) {
+        constexpr int QM = decltype(QMc)::value, QN = decltype(QNc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[QM * 4 + mi][QN * 2 + ni] =
+                        P_MFMA(bb[ni][ks], a[mi][ks], acc[QM * 4 + mi][QN * 2 + ni]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (total_kt > 0) {
+        issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
+        issue(I0{}); issue(I1{}); issue(I2{});
+        if (total_kt >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+
+        for (int T = 0; T < total_kt; ++T) {
+            const int cb = T & 1;
+            // ---------------- P0
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = ldB(cb, 0, ni, ks);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 0, mi, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(I3{});
+            asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // the 8 B_h0 reads are retired
+            __builtin_amdgcn_s_barrier();
+            mma(I0{}, I0{}, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- P1
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = ldB(cb, 1, ni, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(I0{});
+            __builtin_amdgcn_s_barrier();
+            mma(I0{}, I1{}, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- P2
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 1, mi, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(I1{});
+            __builtin_amdgcn_s_barrier();
+            mma(I1{}, I1{}, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- P3
+            issue(I2{});
+            if (T + 2 < total_kt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mma(I1{}, I0{}, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: slab (splits > 1) or C
+    const f32x4 zero4[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
+    float* out = (splits == 1) ? C : slabs + (size_t)split * M * N;
+    const long long ldo = (splits == 1) ? ldc : N;
+    const float al = (splits == 1) ? alpha : 1.f;
+    const bool accu = (splits == 1) && accumulate;
+    if (m0 + P_BM <= M && n0 + P_BN <= N)
+        p_store_f32<true, false>(acc, stg, al, zero4, nullptr, 0, accu, out, ldo, m0 + wr * 128,
+                                 n0 + wc * 64, M, N, lane);
+    else
+        p_store_f32<false, false>(acc, stg, al, zero4, nullptr, 0, accu, out, ldo, m0 + wr * 128,
+                                  n0 + wc * 64, M, N, lane);
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+static int tn256_mode() {  // SSL4GIE_TN256: "0" never, "1" whenever possible, unset = heuristic
+    static int v = -2;
+    if (v == -2) {
+        const char* s = getenv("SSL4GIE_TN256");
+        v = !s ? -1 : (s[0] == '0' ? 0 : 1);
+    }
+    return v;
+}
+
+bool ssl4gie_internal_tn256_ok(const ssl4gie_gemm_desc* d) {
+    const int mode = tn256_mode();
+    if (mode == 0) return false;
+    if (d->K % P_BK != 0 || d->K < P_BK) return false;
+    if ((long long)d->K * d->sAk * 2 >= (1LL << 32) || (long long)d->K * d->sBk * 2 >= (1LL << 32))
+        return false;  // 32-bit per-lane byte offsets are relative to a per-K-tile base: generous
+    if (mode == 1) return true;
+    return d->K >= 16 * P_BK && (long long)d->M * d->N >= 128 * 128 * 4;
+}
+
+int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d) {
+    const int tiles = ((d->M + P_BM - 1) / P_BM) * ((d->N + P_BN - 1) / P_BN);
+    const int nkt = d->K / P_BK;
+    int s = (256 + tiles / 2) / tiles;  // one workgroup per CU
+    if (s > nkt / 8) s = nkt / 8;       // at least 8 K-tiles per split
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, void* workspace, hipStream_t st) {
+    const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + P_BN - 1) / P_BN;
+    const int splits = ssl4gie_internal_tn256_splits(d);
+    auto kfn = gemm_bf16_tn256_kernel;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    P_LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid(tm * tn * splits), block(512);
+    hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAk,
+                       (const bf16_t*)d->B, d->sBk, (float*)d->C, d->ldc, (float*)workspace, d->M,
+                       d->N, d->K, tn, tm * tn, splits, d->alpha, d->accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}

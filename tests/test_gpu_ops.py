@@ -161,7 +161,9 @@ def test_gemm_bf16_nt_epilogues(M, N, K):
 
 # ------------------------------------------------------------------ bf16 TN GEMM (weight grads)
 TN_SHAPES = [(128, 128, 64), (768, 768, 400), (2304, 768, 1576), (512, 2048, 1000), (768, 768, 100),
-             (136, 264, 12800), (8, 768, 70)]
+             (136, 264, 12800), (8, 768, 70),
+             # 256x256 ping-pong TN kernel (K % 64 == 0, K >= 1024): split-K, ragged M / N tiles
+             (2304, 768, 1600), (520, 264, 2048), (512, 2048, 4096), (768, 768, 12800)]
 
 
 @pytest.mark.parametrize("No,Ki,T", TN_SHAPES)
