@@ -34,9 +34,10 @@ template <int HD> DEVI int img_off(int row, int chunk) {
 
 // stage a [n, HD] bf16 slice (row stride rs elements) into an image of npad rows (zero padded)
 template <int HD>
-DEVI void stage_rows(char* img, const bf16_t* src, long long rs, int n, int npad, int tid) {
+DEVI void stage_rows(char* img, const bf16_t* src, long long rs, int n, int npad, int tid,
+                     int nth = 256) {
     constexpr int CPR = HD / 8;
-    for (int idx = tid; idx < npad * CPR; idx += 256) {
+    for (int idx = tid; idx < npad * CPR; idx += nth) {
         const int row = idx / CPR, c = idx % CPR;
         u32x4 v = {0, 0, 0, 0};
         if (row < n) v = *(const u32x4*)(src + (size_t)row * rs + c * 8);
@@ -91,22 +92,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kimg = smem;
     char* Vimg = smem + NPAD * RB;
+    char* Qimg = smem + 2 * NPAD * RB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // consecutive (b, h) ids share an XCD: with hd = 32 two neighbouring heads share every 128-B
+    // line of the packed qkv rows, so the second one hits in that XCD's L2
+    const int bh = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bh / H, h = bh % H;
     const int D = H * HD;
     const long long rs = 3LL * D;
     const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
     stage_rows<HD>(Kimg, qb + D, rs, N, NPAD, tid);
     stage_rows<HD>(Vimg, qb + 2 * D, rs, N, NPAD, tid);
-    __syncthreads();
+    stage_rows<HD>(Qimg, qb, rs, N, NPAD, tid);  // every operand is LDS-fed: no global-load latency
+    __syncthreads();                              // inside the per-tile dependency chains
     const float c = scale * 1.44269504088896340736f;
     const int nqt = (N + 15) >> 4;
     for (int qt = wave; qt < nqt; qt += 4) {
         const int q = qt * 16 + (lane & 15);
-        const int qrow = q < N ? q : N - 1;
         bf16x8 qf[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(qb, rs, qrow, ks, lane);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag<HD>(Qimg, qt * 16, ks, lane);
         f32x4 s[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -156,19 +161,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
 }
 
 // ------------------------------------------------------------------ backward
+// LDS holds all four operand images of the head for the whole kernel — K, V, Q, dO — plus the
+// saved log-sum-exp and delta_q = sum_d dO[q,d] O[q,d] (computed while dO is staged): after the
+// prologue no wave ever waits on a global load inside its per-tile dependency chain (at 2 waves
+// per SIMD an exposed ~2 us HBM round trip per query tile used to dominate this kernel).
+#define ATTN_BWD_WAVES 8  // 512 threads share one set of images: 2 workgroups = 16 waves per CU
 template <int HD, int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(
+__global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
     int N, int H, float scale) {
-    constexpr int NPAD = NKT * 16, RB = HD * 2, KS = HD / 32, DT = HD / 16;
+    constexpr int NPAD = NKT * 16, RB = HD * 2, KS = HD / 32, DT = HD / 16, CPR = HD / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* img0 = smem;
-    char* img1 = smem + NPAD * RB;
-    float* lse_s = (float*)(smem + 2 * NPAD * RB);
+    char* Kimg = smem;
+    char* Vimg = smem + NPAD * RB;
+    char* Qimg = smem + 2 * NPAD * RB;
+    char* Oimg = smem + 3 * NPAD * RB;  // dO
+    float* lse_s = (float*)(smem + 4 * NPAD * RB);
     float* del_s = lse_s + NPAD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // consecutive (b, h) ids share an XCD: with hd = 32 two neighbouring heads share every 128-B
+    // line of the packed qkv rows, so the second one hits in that XCD's L2
+    const int bh = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bh / H, h = bh % H;
     const int D = H * HD;
     const long long rs = 3LL * D;
     const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
@@ -179,59 +194,70 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(
     const float LOG2E = 1.44269504088896340736f;
     const float c = scale * LOG2E;
 
-    // ---------------- phase A: dQ (waves own query tiles); LDS = K, V
-    stage_rows<HD>(img0, qb + D, rs, N, NPAD, tid);
-    stage_rows<HD>(img1, qb + 2 * D, rs, N, NPAD, tid);
-    for (int i = tid; i < NPAD; i += 256) {
-        lse_s[i] = i < N ? lrow[i] : 0.f;
-        del_s[i] = 0.f;
+    constexpr int NTH = 64 * ATTN_BWD_WAVES;
+    // ---------------- prologue: stage K, V, Q, dO; delta and lse rows
+    stage_rows<HD>(Kimg, qb + D, rs, N, NPAD, tid, NTH);
+    stage_rows<HD>(Vimg, qb + 2 * D, rs, N, NPAD, tid, NTH);
+    stage_rows<HD>(Qimg, qb, rs, N, NPAD, tid, NTH);
+    for (int idx = tid; idx < NPAD * CPR; idx += NTH) {  // wave-uniform trip count (NPAD*CPR % 64 == 0)
+        const int row = idx / CPR, ch = idx % CPR;
+        u32x4 v = {0, 0, 0, 0};
+        float dot = 0.f;
+        if (row < N) {
+            v = *(const u32x4*)(dob + (size_t)row * D + ch * 8);
+            const u32x4 o = *(const u32x4*)(ob + (size_t)row * D + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dot += __uint_as_float(v[j] << 16) * __uint_as_float(o[j] << 16);
+                dot += __uint_as_float(v[j] & 0xffff0000u) * __uint_as_float(o[j] & 0xffff0000u);
+            }
+        }
+        *(u32x4*)(Oimg + img_off<HD>(row, ch)) = v;
+#pragma unroll
+        for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);  // the row's CPR lanes
+        if (ch == 0) del_s[row] = dot;
     }
+    for (int i = tid; i < NPAD; i += NTH) lse_s[i] = i < N ? lrow[i] * LOG2E : 0.f;
     __syncthreads();
     const int nqt = (N + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+
+    // ---------------- phase A: dQ (waves own query tiles)
+    for (int qt = wave; qt < nqt; qt += ATTN_BWD_WAVES) {
         const int q = qt * 16 + (lane & 15);
-        const int qrow = q < N ? q : N - 1;
         bf16x8 qf[KS], dof[KS];
-        float dl = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = row_frag_global(qb, rs, qrow, ks, lane);
-            dof[ks] = row_frag_global(dob, D, qrow, ks, lane);
-            const bf16x8 of = row_frag_global(ob, D, qrow, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
+            qf[ks] = row_frag<HD>(Qimg, qt * 16, ks, lane);
+            dof[ks] = row_frag<HD>(Oimg, qt * 16, ks, lane);
         }
-        dl = group_sum(dl);  // delta_q = sum_d dO[q,d] O[q,d]
-        if (g == 0 && q < N) del_s[q] = dl;
-        const float l2 = lse_s[qrow] * LOG2E;
-        f32x4 s[NKT], dp[NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            s[kt] = f32x4{0, 0, 0, 0};
-            dp[kt] = f32x4{0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s[kt] = MFMA16(row_frag<HD>(img0, kt * 16, ks, lane), qf[ks], s[kt]);
-                dp[kt] = MFMA16(row_frag<HD>(img1, kt * 16, ks, lane), dof[ks], dp[kt]);
-            }
-        }
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = (kt * 16 + 4 * g + r < N)
-                                    ? __builtin_amdgcn_exp2f(s[kt][r] * c - l2) : 0.f;
-                s[kt][r] = p * (dp[kt][r] - dl);  // dS^T
-            }
+        const float dl = del_s[q];
+        const float l2 = lse_s[q];
+        // dS^T needs only the saved row statistics, so key tiles are consumed pair by pair
         f32x4 dq[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
-#pragma unroll
+#pragma unroll 1
         for (int kp = 0; kp < NKT / 2; ++kp) {
-            const bf16x8 dsf = pack8(s[2 * kp], s[2 * kp + 1]);
+            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = MFMA16(row_frag<HD>(Kimg, kp * 32, ks, lane), qf[ks], s0);
+                s1 = MFMA16(row_frag<HD>(Kimg, kp * 32 + 16, ks, lane), qf[ks], s1);
+                p0 = MFMA16(row_frag<HD>(Vimg, kp * 32, ks, lane), dof[ks], p0);
+                p1 = MFMA16(row_frag<HD>(Vimg, kp * 32 + 16, ks, lane), dof[ks], p1);
+            }
+            const int ka = kp * 32 + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pa = (ka + r < N) ? __builtin_amdgcn_exp2f(s0[r] * c - l2) : 0.f;
+                const float pb = (ka + 16 + r < N) ? __builtin_amdgcn_exp2f(s1[r] * c - l2) : 0.f;
+                s0[r] = pa * (p0[r] - dl);  // dS^T
+                s1[r] = pb * (p1[r] - dl);
+            }
+            const bf16x8 dsf = pack8(s0, s1);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                dq[dt] = MFMA16(tr_frag<HD>(img0, kp * 32, dt * 16, lane), dsf, dq[dt]);
+                dq[dt] = MFMA16(tr_frag<HD>(Kimg, kp * 32, dt * 16, lane), dsf, dq[dt]);
         }
         if (q < N) {
             bf16_t* r = dqb + (size_t)q * rs + 4 * g;
@@ -239,20 +265,15 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(
             for (int dt = 0; dt < DT; ++dt) st4(r + dt * 16, dq[dt] * scale);
         }
     }
-    __syncthreads();
 
-    // ---------------- phase B: dK, dV (waves own key tiles); LDS = Q, dO
-    stage_rows<HD>(img0, qb, rs, N, NPAD, tid);
-    stage_rows<HD>(img1, dob, D, N, NPAD, tid);
-    __syncthreads();
-    for (int kt = wave; kt < nqt; kt += 4) {
+    // ---------------- phase B: dK, dV (waves own key tiles); same LDS images, no restaging
+    for (int kt = wave; kt < nqt; kt += ATTN_BWD_WAVES) {
         const int key = kt * 16 + (lane & 15);
-        const int krow = key < N ? key : N - 1;
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = row_frag_global(qb + D, rs, krow, ks, lane);
-            vf[ks] = row_frag_global(qb + 2 * D, rs, krow, ks, lane);
+            kf[ks] = row_frag<HD>(Kimg, kt * 16, ks, lane);
+            vf[ks] = row_frag<HD>(Vimg, kt * 16, ks, lane);
         }
         f32x4 dk[DT], dv[DT];
 #pragma unroll
@@ -260,15 +281,15 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(
             dk[dt] = f32x4{0, 0, 0, 0};
             dv[dt] = f32x4{0, 0, 0, 0};
         }
-#pragma unroll 2
+#pragma unroll 1
         for (int qp = 0; qp < NKT / 2; ++qp) {
             f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s0 = MFMA16(row_frag<HD>(img0, qp * 32, ks, lane), kf[ks], s0);
-                s1 = MFMA16(row_frag<HD>(img0, qp * 32 + 16, ks, lane), kf[ks], s1);
-                p0 = MFMA16(row_frag<HD>(img1, qp * 32, ks, lane), vf[ks], p0);
-                p1 = MFMA16(row_frag<HD>(img1, qp * 32 + 16, ks, lane), vf[ks], p1);
+                s0 = MFMA16(row_frag<HD>(Qimg, qp * 32, ks, lane), kf[ks], s0);
+                s1 = MFMA16(row_frag<HD>(Qimg, qp * 32 + 16, ks, lane), kf[ks], s1);
+                p0 = MFMA16(row_frag<HD>(Oimg, qp * 32, ks, lane), vf[ks], p0);
+                p1 = MFMA16(row_frag<HD>(Oimg, qp * 32 + 16, ks, lane), vf[ks], p1);
             }
             // lane holds S[q = qp*32 (+16) + 4g + r][key]; p0/p1 hold dP
             const int qa = qp * 32 + 4 * g;
@@ -277,16 +298,16 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(
             f32x4 pa, pb, dsa, dsb;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pa[r] = (qa + r < N) ? __builtin_amdgcn_exp2f(s0[r] * c - la[r] * LOG2E) : 0.f;
-                pb[r] = (qa + 16 + r < N) ? __builtin_amdgcn_exp2f(s1[r] * c - lb[r] * LOG2E) : 0.f;
+                pa[r] = (qa + r < N) ? __builtin_amdgcn_exp2f(s0[r] * c - la[r]) : 0.f;
+                pb[r] = (qa + 16 + r < N) ? __builtin_amdgcn_exp2f(s1[r] * c - lb[r]) : 0.f;
                 dsa[r] = pa[r] * (p0[r] - da[r]);
                 dsb[r] = pb[r] * (p1[r] - db[r]);
             }
             const bf16x8 pf = pack8(pa, pb), dsf = pack8(dsa, dsb);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                dv[dt] = MFMA16(tr_frag<HD>(img1, qp * 32, dt * 16, lane), pf, dv[dt]);
-                dk[dt] = MFMA16(tr_frag<HD>(img0, qp * 32, dt * 16, lane), dsf, dk[dt]);
+                dv[dt] = MFMA16(tr_frag<HD>(Oimg, qp * 32, dt * 16, lane), pf, dv[dt]);
+                dk[dt] = MFMA16(tr_frag<HD>(Qimg, qp * 32, dt * 16, lane), dsf, dk[dt]);
             }
         }
         if (key < N) {
@@ -367,7 +388,7 @@ extern "C" size_t ssl4gie_attn_workspace_bytes(int dtype, int B, int N, int H, i
 template <int HD, int NKT>
 static int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale,
                       hipStream_t st) {
-    const size_t lds = (size_t)2 * NKT * 16 * HD * 2;
+    const size_t lds = (size_t)3 * NKT * 16 * HD * 2;
     auto k = attn_fwd_bf16_kernel<HD, NKT>;
     if (lds > 65536)
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -380,13 +401,13 @@ static int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int 
 template <int HD, int NKT>
 static int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                       void* dqkv, int B, int N, int H, float scale, hipStream_t st) {
-    const size_t lds = (size_t)2 * NKT * 16 * HD * 2 + 2 * NKT * 16 * sizeof(float);
+    const size_t lds = (size_t)4 * NKT * 16 * HD * 2 + 2 * NKT * 16 * sizeof(float);
     auto k = attn_bwd_bf16_kernel<HD, NKT>;
     if (lds > 65536)
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * HD, st);
-    hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
+    hipLaunchKernelGGL(k, dim3(B * H), dim3(64 * ATTN_BWD_WAVES), lds, st, (const bf16_t*)qkv,
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
     LAUNCH_CHECK();
     return 0;
 }
