@@ -81,6 +81,11 @@ typedef struct ssl4gie_gemm_desc {
     const void* aux; /* [M, N] row stride ldc, dtype_c */
     void* out2;      /* [M, N] row stride ldc, dtype_c */
     int accumulate;  /* C += (EPI_NONE only) */
+    /* optional [M] fp32: colsum_a[m] (+)= sum_k A(m,k) with the same `accumulate` flag (alpha not
+     * applied).  The bias gradient of nn.Linear riding on its weight-gradient product
+     * dW = dY^T X (A = dY^T): fused into the 256x256 TN kernel (one extra MFMA against a ones
+     * fragment per A fragment), a separate column-sum pass on the other paths.  Needs sAm == 1. */
+    float* colsum_a;
 } ssl4gie_gemm_desc;
 size_t ssl4gie_gemm_workspace_bytes(const ssl4gie_gemm_desc* d);
 int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t workspace_bytes,

@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
         ("C", vp), ("ldc", i64), ("sCb1", i64), ("sCb2", i64),
         ("dtype_ab", i32), ("dtype_c", i32), ("alpha", f32), ("epilogue", i32),
         ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("out2", vp),
-        ("accumulate", i32),
+        ("accumulate", i32), ("colsum_a", vp),
     ]
 
 

@@ -8,8 +8,8 @@
 // Forward (7 launches):  LN1 -> QKV GEMM(+bias) -> fused attention -> proj GEMM(+bias+residual)
 //                        -> LN2 -> fc1 GEMM(+bias, GELU; saves u and gelu(u)) -> fc2 GEMM(+bias+res).
 // Backward: data-gradient GEMMs are NT products against pre-transposed weight copies (GELU' fused
-// in the fc2 one), weight-gradient GEMMs are split-K TN products over the token axis, bias
-// gradients are two-stage column sums, and both LayerNorm backward kernels add the residual
+// in the fc2 one), weight-gradient GEMMs are split-K TN products over the token axis with the
+// bias gradients (column sums of dY) fused in, and both LayerNorm backward kernels add the residual
 // gradient and emit the operand-type copy the next GEMM consumes.
 #include "common.h"
 #include "ssl4gie_hip.h"
@@ -67,7 +67,7 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t esize(int dt) { return dt == SSL4GIE_BF16 ? 2 : 4; }
 
 struct BwdLayout {
-    size_t du, dh, dxmid, dxmid_lp, dattn, dqkv, ln_ws, col_ws, gemm_ws, attn_ws, total;
+    size_t du, dh, dxmid, dxmid_lp, dattn, dqkv, ln_ws, gemm_ws, attn_ws, total;
     size_t gemm_ws_bytes;
 };
 
@@ -79,12 +79,14 @@ ssl4gie_gemm_desc lin_desc(int M, int N, int K, int dt) {
     return d;
 }
 // dW[N_out, K_in] = dY[T, N_out]^T X[T, K_in]
+// (db[N_out] = column sums of dY rides on the same product: ssl4gie_gemm_desc.colsum_a)
 ssl4gie_gemm_desc wgrad_desc(int n_out, int k_in, int T, const void* dY, const void* X, float* dW,
-                             int dt, int accumulate) {
+                             float* db, int dt, int accumulate) {
     ssl4gie_gemm_desc d = lin_desc(n_out, k_in, T, dt);
     d.A = dY; d.sAm = 1; d.sAk = n_out;
     d.B = X; d.sBk = k_in; d.sBn = 1;
     d.C = dW; d.ldc = k_in; d.dtype_c = SSL4GIE_F32; d.accumulate = accumulate;
+    d.colsum_a = db;
     return d;
 }
 
@@ -99,13 +101,12 @@ BwdLayout bwd_layout(const ssl4gie_block_dims* d) {
     L.dattn = o; o += align_up(T * D * es);
     L.dqkv = o; o += align_up(T * 3 * D * es);
     L.ln_ws = o; o += align_up(ssl4gie_layernorm_bwd_workspace_bytes((int)T, (int)D));
-    L.col_ws = o; o += align_up(ssl4gie_colsum_workspace_bytes((int)T, (int)(3 * D > F ? 3 * D : F)));
     size_t g = 0;
     const int dims[4][2] = {{(int)(3 * D), (int)D}, {(int)D, (int)D}, {(int)F, (int)D}, {(int)D, (int)F}};
     for (int i = 0; i < 4; ++i) {
         // pointers only matter for alignment checks: use 16-B aligned dummies
         ssl4gie_gemm_desc w = wgrad_desc(dims[i][0], dims[i][1], (int)T, (const void*)256,
-                                         (const void*)256, (float*)256, d->dtype, 0);
+                                         (const void*)256, (float*)256, (float*)256, d->dtype, 0);
         const size_t b = ssl4gie_gemm_workspace_bytes(&w);
         if (b > g) g = b;
     }
@@ -206,7 +207,6 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     void* dattn = ws + L.dattn;
     void* dqkv = ws + L.dqkv;
     float* ln_ws = (float*)(ws + L.ln_ws);
-    float* col_ws = (float*)(ws + L.col_ws);
     void* gws = ws + L.gemm_ws;
     const void* dy = (dt == SSL4GIE_F32) ? (const void*)dx_out : dx_out_lp;
     ssl4gie_gemm_desc e, wg;
@@ -215,16 +215,14 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     memset(&e, 0, sizeof(e));
     e.C = du; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_DGELU; e.aux = a->u;
     RC(linear_bwd_data(dy, w->wfc2, w->wfc2_t, T, D, F, dt, e, stream));
-    wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, dt, accumulate);
+    wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, g->bfc2, dt, accumulate);
     RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
-    RC(ssl4gie_colsum(dy, dt, g->bfc2, accumulate, col_ws, T, D, D, stream));
     // ---- fc1
     memset(&e, 0, sizeof(e));
     e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(du, w->wfc1, w->wfc1_t, T, F, D, dt, e, stream));
-    wg = wgrad_desc(F, D, T, du, a->h2, g->wfc1, dt, accumulate);
+    wg = wgrad_desc(F, D, T, du, a->h2, g->wfc1, g->bfc1, dt, accumulate);
     RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
-    RC(ssl4gie_colsum(du, dt, g->bfc1, accumulate, col_ws, T, F, F, stream));
     // ---- LN2 (adds the residual gradient dx_out)
     RC(ssl4gie_layernorm_bwd(dh, dt, a->xmid, w->ln2_g, a->mean2, a->rstd2, dx_out, dxmid,
                              dt == SSL4GIE_F32 ? nullptr : dxmid_lp, dt, g->ln2_g, g->ln2_b,
@@ -233,9 +231,8 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     memset(&e, 0, sizeof(e));
     e.C = dattn; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(dxmid_lp, w->wproj, w->wproj_t, T, D, D, dt, e, stream));
-    wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, dt, accumulate);
+    wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
     RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
-    RC(ssl4gie_colsum(dxmid_lp, dt, g->bproj, accumulate, col_ws, T, D, D, stream));
     // ---- attention
     RC(ssl4gie_attn_bwd(a->qkv, a->attn, dattn, a->lse, dqkv, dt, d->B, d->N, d->H, D / d->H,
                         ws + L.attn_ws, stream));
@@ -243,9 +240,8 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     memset(&e, 0, sizeof(e));
     e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(dqkv, w->wqkv, w->wqkv_t, T, 3 * D, D, dt, e, stream));
-    wg = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, dt, accumulate);
+    wg = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
     RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
-    RC(ssl4gie_colsum(dqkv, dt, g->bqkv, accumulate, col_ws, T, 3 * D, 3 * D, stream));
     // ---- LN1 (adds the residual gradient dxmid)
     RC(ssl4gie_layernorm_bwd(dh, dt, x_in, w->ln1_g, a->mean1, a->rstd1, dxmid, dx_in,
                              dt == SSL4GIE_F32 ? nullptr : dx_in_lp, dt, g->ln1_g, g->ln1_b,

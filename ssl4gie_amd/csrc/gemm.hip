@@ -849,10 +849,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(
     epi_wave_tile<float, SSL4GIE_EPI_NONE>(es, out, ldo, m0 + wm, n0 + wn, M, N, acc, lane);
 }
 
-// C[m, n] (+)= alpha * sum_s slabs[s][m][n]   (N % 4 == 0)
+// C[m, n] (+)= alpha * sum_s slabs[s][m][n]   (N % 4 == 0); the blocks past the C range reduce the
+// column-sum partials cs_part[s][m] into cs_out[m] (bias gradient of the fused TN kernel)
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C,
                                    long long ldc, int M, int N, int splits, float alpha,
-                                   int accumulate) {
+                                   int accumulate, const float* __restrict__ cs_part,
+                                   float* __restrict__ cs_out, unsigned c_blocks) {
+    if (blockIdx.x >= c_blocks) {
+        const int m = (blockIdx.x - c_blocks) * blockDim.x + threadIdx.x;
+        if (m < M) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += cs_part[(size_t)k * M + m];
+            cs_out[m] = accumulate ? cs_out[m] + s : s;
+        }
+        return;
+    }
     const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total4 = (size_t)M * N / 4;
     if (i4 >= total4) return;
@@ -906,12 +917,31 @@ static int tn_splits(const ssl4gie_gemm_desc* d) {
     return s;
 }
 
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+// workspace layout of the TN paths: [slabs (splits > 1)] [column-sum scratch (colsum_a)]
+struct TnPlan {
+    bool big;
+    int splits;
+    size_t slab_bytes, cs_off, cs_bytes, total;
+};
+static TnPlan tn_plan(const ssl4gie_gemm_desc* d) {
+    TnPlan p;
+    p.big = ssl4gie_internal_tn256_ok(d);
+    p.splits = p.big ? ssl4gie_internal_tn256_splits(d) : tn_splits(d);
+    p.slab_bytes = p.splits > 1 ? (size_t)p.splits * d->M * d->N * sizeof(float) : 0;
+    p.cs_off = al256(p.slab_bytes);
+    p.cs_bytes = 0;
+    if (d->colsum_a)
+        p.cs_bytes = p.big ? (p.splits > 1 ? (size_t)p.splits * d->M * sizeof(float) : 0)
+                           : ssl4gie_colsum_workspace_bytes(d->K, d->M);
+    p.total = p.cs_bytes ? p.cs_off + p.cs_bytes : p.slab_bytes;
+    return p;
+}
+
 extern "C" size_t ssl4gie_gemm_workspace_bytes(const ssl4gie_gemm_desc* d) {
     if (!d) return 0;
-    if (d->dtype_ab == SSL4GIE_BF16 && !nt_ok(d) && tn_ok(d)) {
-        const int s = ssl4gie_internal_tn256_ok(d) ? ssl4gie_internal_tn256_splits(d) : tn_splits(d);
-        return s > 1 ? (size_t)s * d->M * d->N * sizeof(float) : 0;
-    }
+    if (d->dtype_ab == SSL4GIE_BF16 && !nt_ok(d) && tn_ok(d)) return tn_plan(d).total;
+    if (d->colsum_a) return ssl4gie_colsum_workspace_bytes(d->K, d->M);
     return 0;
 }
 
@@ -928,6 +958,7 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     REQUIRE(d->epilogue != SSL4GIE_EPI_DGELU || d->aux);
     REQUIRE(d->batch1 * d->batch2 == 1 || d->epilogue == SSL4GIE_EPI_NONE);
     REQUIRE(!d->accumulate || d->epilogue == SSL4GIE_EPI_NONE);
+    REQUIRE(!d->colsum_a || (d->sAm == 1 && d->batch1 * d->batch2 == 1 && d->sAk >= d->M));
     if (d->M == 0 || d->N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate};
@@ -974,31 +1005,38 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     }
     if (tn_ok(d)) {
         const int tm = (d->M + BT_M - 1) / BT_M, tn = (d->N + BT_N - 1) / BT_N;
-        const bool big = ssl4gie_internal_tn256_ok(d);
-        const int splits = big ? ssl4gie_internal_tn256_splits(d) : tn_splits(d);
-        if (splits > 1)
-            REQUIRE(workspace && workspace_bytes >= (size_t)splits * d->M * d->N * sizeof(float));
+        const TnPlan p = tn_plan(d);
+        const int splits = p.splits;
+        REQUIRE(p.total == 0 || (workspace && workspace_bytes >= p.total));
+        float* slabs = (float*)workspace;
+        float* cs_ws = p.cs_bytes ? (float*)((char*)workspace + p.cs_off) : nullptr;
         {
             ProfScope prof(PROF_GEMM_TN, 2.0 * d->M * d->N * d->K, st);
-            if (big) {
-                const int rc = ssl4gie_internal_tn256_launch(d, workspace, st);
+            if (p.big) {
+                const int rc = ssl4gie_internal_tn256_launch(d, slabs, cs_ws, st);
                 if (rc) return rc;
             } else {
                 dim3 grid(tm * tn * splits), block(256);
                 hipLaunchKernelGGL(gemm_bf16_tn_kernel, grid, block, BT_LDS_BYTES, st,
                                    (const bf16_t*)d->A, d->sAk, (const bf16_t*)d->B, d->sBk,
-                                   (float*)d->C, d->ldc, (float*)workspace, d->M, d->N, d->K, tn,
-                                   tm * tn, splits, e);
+                                   (float*)d->C, d->ldc, slabs, d->M, d->N, d->K, tn, tm * tn,
+                                   splits, e);
                 LAUNCH_CHECK();
             }
         }
+        const bool fused_cs = p.big && d->colsum_a;
         if (splits > 1) {
             const size_t total4 = (size_t)d->M * d->N / 4;
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)),
-                               dim3(256), 0, st, (const float*)workspace, (float*)d->C, d->ldc,
-                               d->M, d->N, splits, d->alpha, d->accumulate);
+            const unsigned c_blocks = (unsigned)((total4 + 255) / 256);
+            const unsigned b_blocks = fused_cs ? (unsigned)((d->M + 255) / 256) : 0;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(c_blocks + b_blocks), dim3(256), 0, st,
+                               (const float*)slabs, (float*)d->C, d->ldc, d->M, d->N, splits,
+                               d->alpha, d->accumulate, (const float*)cs_ws, d->colsum_a, c_blocks);
             LAUNCH_CHECK();
         }
+        if (d->colsum_a && !fused_cs)
+            return ssl4gie_colsum(d->A, d->dtype_ab, d->colsum_a, d->accumulate, cs_ws, d->K, d->M,
+                                  d->sAk, stream);
         return 0;
     }
     // generic
@@ -1021,5 +1059,10 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     else
         hipLaunchKernelGGL((gemm_generic_kernel<float, bf16_t>), grid, block, 0, st, g);
     LAUNCH_CHECK();
+    if (d->colsum_a) {
+        REQUIRE(workspace && workspace_bytes >= ssl4gie_colsum_workspace_bytes(d->K, d->M));
+        return ssl4gie_colsum(d->A, d->dtype_ab, d->colsum_a, d->accumulate, (float*)workspace,
+                              d->K, d->M, d->sAk, stream);
+    }
     return 0;
 }

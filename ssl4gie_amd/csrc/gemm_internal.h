@@ -23,4 +23,6 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st);
 // 256x256x64 ping-pong TN kernel (gemm_tn256.hip): weight-gradient product with split-K slabs.
 bool ssl4gie_internal_tn256_ok(const ssl4gie_gemm_desc* d);
 int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d);
-int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, void* workspace, hipStream_t st);
+// `slabs` (splits > 1) and `colsum_part` ([splits][M], splits > 1 and d->colsum_a) are workspace
+int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, float* slabs, float* colsum_part,
+                                  hipStream_t st);

@@ -39,11 +39,16 @@ DEVI bf16x8 q_frag(const char* img, int krow0, int x0, int lane) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// grid.x = ntiles * splits; split s of tile t covers K-tiles [nkt*s/splits, nkt*(s+1)/splits)
+// grid.x = ntiles * splits; split s of tile t covers K-tiles [nkt*s/splits, nkt*(s+1)/splits).
+// COLSUM: the workgroups of the first tile column (n0 == 0) also produce colsum[m] = sum_k At[k][m]
+// (the bias gradient): wave (wr, wc) multiplies its wc-th A fragment of each quadrant against a
+// ones fragment — 2 extra MFMAs in P0 and in P2 — and writes 2 x 16 sums.
+template <bool COLSUM>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     const bf16_t* __restrict__ At, long long ldat, const bf16_t* __restrict__ Bt, long long ldbt,
     float* __restrict__ C, long long ldc, float* __restrict__ slabs, int M, int N, int K,
-    int tiles_n, int ntiles, int splits, float alpha, int accumulate) {
+    int tiles_n, int ntiles, int splits, float alpha, int accumulate, float* __restrict__ colsum,
+    float* __restrict__ colsum_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -111,10 +116,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     bf16x8 a[4][2], b0[2][2], b1[2][2];
+    f32x4 accb[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    const bool do_cs = COLSUM && (n0 == 0);
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
     auto mma = [&](auto QMc, auto QNc, bf16x8 (&bb)[2][2]) {
         constexpr int QM = decltype(QMc)::value, QN = decltype(QNc)::value;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (COLSUM && QM == QN) {  // P0 and P2: the phases that have just loaded `a`
+            if (do_cs) {
+                auto cs = [&](bf16x8 (&af)[2]) {
+                    accb[QM] = P_MFMA(ones, af[0], accb[QM]);
+                    accb[QM] = P_MFMA(ones, af[1], accb[QM]);
+                };
+                if (wc == 0) cs(a[0]);
+                else if (wc == 1) cs(a[1]);
+                else if (wc == 2) cs(a[2]);
+                else cs(a[3]);
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -187,6 +209,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
         if (wr == 0) __builtin_amdgcn_s_barrier();
     }
 
+    // ---- column sums: D[n][m] is the same for every n, so lanes 0..15 hold m = l, register 0
+    if constexpr (COLSUM) {
+        if (do_cs && lane < 16) {
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm) {
+                const int m = m0 + wr * 128 + qm * 64 + wc * 16 + lane;
+                if (m < M) {
+                    if (splits == 1) colsum[m] = accumulate ? colsum[m] + accb[qm][0] : accb[qm][0];
+                    else colsum_part[(size_t)split * M + m] = accb[qm][0];
+                }
+            }
+        }
+    }
     // ---- epilogue: slab (splits > 1) or C
     const f32x4 zero4[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
     char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
@@ -234,20 +269,28 @@ int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d) {
     return s;
 }
 
-int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, void* workspace, hipStream_t st) {
+int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, float* slabs, float* colsum_part,
+                                  hipStream_t st) {
     const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + P_BN - 1) / P_BN;
     const int splits = ssl4gie_internal_tn256_splits(d);
-    auto kfn = gemm_bf16_tn256_kernel;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    P_LDS_BYTES));
-        attr_set = true;
-    }
     dim3 grid(tm * tn * splits), block(512);
-    hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAk,
-                       (const bf16_t*)d->B, d->sBk, (float*)d->C, d->ldc, (float*)workspace, d->M,
-                       d->N, d->K, tn, tm * tn, splits, d->alpha, d->accumulate);
+#define Q_LAUNCH(CS_)                                                                              \
+    do {                                                                                           \
+        auto kfn = gemm_bf16_tn256_kernel<CS_>;                                                    \
+        static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
+        if (!attr_set) {                                                                           \
+            HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES)); \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAk,         \
+                           (const bf16_t*)d->B, d->sBk, (float*)d->C, d->ldc, slabs, d->M, d->N,   \
+                           d->K, tn, tm * tn, splits, d->alpha, d->accumulate, d->colsum_a,        \
+                           colsum_part);                                                           \
+    } while (0)
+    if (d->colsum_a) Q_LAUNCH(true);
+    else Q_LAUNCH(false);
+#undef Q_LAUNCH
     LAUNCH_CHECK();
     return 0;
 }

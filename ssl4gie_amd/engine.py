@@ -354,8 +354,8 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_bwd_data(dy2, ctx.wlp, ctx.wt).view(ctx.shp)
         if tw is not None:
-            ops.linear_bwd_weight(dy2, x2, out=tw, accumulate=acc)
-        if tb is not None:
+            ops.linear_bwd_weight(dy2, x2, out=tw, accumulate=acc, bias_out=tb)
+        elif tb is not None:
             ops.colsum(dy2, out=tb, accumulate=acc)
         return dx, rets[0], rets[1], None, None, None, None
 
@@ -386,8 +386,8 @@ class PatchEmbedFn(torch.autograd.Function):
         (tw, tb, tc), acc, rets = ctx.sink.plan([weight, bias, cls])
         dy = ops.tokens_assemble_bwd(dx.contiguous(), ctx.dtype, dcls_out=tc, accumulate=acc)
         if tw is not None:
-            ops.linear_bwd_weight(dy, cols, out=tw, accumulate=acc)
-        if tb is not None:
+            ops.linear_bwd_weight(dy, cols, out=tw, accumulate=acc, bias_out=tb)
+        elif tb is not None:
             ops.colsum(dy, out=tb, accumulate=acc)
         return (None, rets[0], rets[1], rets[2]) + (None,) * 7
 

@@ -176,9 +176,10 @@ def linear_bwd_data(dy2d, w, w_t=None, out_dtype=None, dgelu_aux=None):
     return dx
 
 
-def linear_bwd_weight(dy2d, x2d, out=None, accumulate=False):
-    """dW[n_out, k_in] = dy[T, n_out]^T @ x[T, k_in]  (fp32 output)."""
-    _dev(dy2d, x2d, out)
+def linear_bwd_weight(dy2d, x2d, out=None, accumulate=False, bias_out=None):
+    """dW[n_out, k_in] = dy[T, n_out]^T @ x[T, k_in]  (fp32 output); with `bias_out` [n_out] the
+    bias gradient (column sums of dy) is produced by the same call."""
+    _dev(dy2d, x2d, out, bias_out)
     T, n_out = dy2d.shape
     T2, k_in = x2d.shape
     assert T == T2 and dy2d.dtype == x2d.dtype
@@ -190,6 +191,9 @@ def linear_bwd_weight(dy2d, x2d, out=None, accumulate=False):
     d.B, d.sBk, d.sBn = ptr(x2d), k_in, 1
     d.C, d.ldc = ptr(out), k_in
     d.accumulate = int(accumulate)
+    if bias_out is not None:
+        assert bias_out.dtype == torch.float32 and bias_out.numel() == n_out
+        d.colsum_a = ptr(bias_out)
     gemm_raw(d, x2d.device)
     return out
 

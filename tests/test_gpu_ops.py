@@ -176,6 +176,13 @@ def test_gemm_bf16_tn_exact_integers(No, Ki, T):
     assert torch.equal(dw.cpu().double(), ref), f"max diff {(dw.cpu().double() - ref).abs().max()}"
     dw2 = ops.linear_bwd_weight(dy.to(DEV).to(BF), x.to(DEV).to(BF), out=dw.clone(), accumulate=True)
     assert torch.equal(dw2.cpu().double(), 2 * ref)
+    # bias gradient (column sums of dy) riding on the same product, overwrite and accumulate
+    db = torch.full((No,), 7.0, device=DEV)
+    dw3 = ops.linear_bwd_weight(dy.to(DEV).to(BF), x.to(DEV).to(BF), bias_out=db)
+    assert torch.equal(dw3.cpu().double(), ref)
+    assert torch.equal(db.cpu().double(), dy.double().sum(0))
+    ops.linear_bwd_weight(dy.to(DEV).to(BF), x.to(DEV).to(BF), out=dw3, accumulate=True, bias_out=db)
+    assert torch.equal(db.cpu().double(), 2 * dy.double().sum(0))
 
 
 def test_gemm_f32_weight_grad_generic():
