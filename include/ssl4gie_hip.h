@@ -60,7 +60,11 @@ enum {
     SSL4GIE_EPI_BIAS = 1,          /* C = acc + bias[n]                   */
     SSL4GIE_EPI_BIAS_GELU = 2,     /* C = u = acc + bias[n]; out2 = gelu(u) (exact erf) */
     SSL4GIE_EPI_BIAS_RESIDUAL = 3, /* C = acc + bias[n] + residual[m,n] (fp32 residual) */
-    SSL4GIE_EPI_DGELU = 4          /* C = acc * gelu'(aux[m,n])           */
+    SSL4GIE_EPI_DGELU = 4,         /* C = acc * gelu'(aux[m,n])           */
+    /* the pair the block executor uses: the forward stores gelu'(u) instead of u, so that the
+     * backward epilogue is one multiply (no transcendental work on the data-gradient GEMM) */
+    SSL4GIE_EPI_BIAS_GELU_GRAD = 5, /* u = acc + bias[n]; C = gelu'(u); out2 = gelu(u) */
+    SSL4GIE_EPI_MUL_AUX = 6         /* C = acc * aux[m,n]                  */
 };
 typedef struct ssl4gie_gemm_desc {
     int M, N, K;
@@ -178,7 +182,7 @@ typedef struct ssl4gie_block_act { /* per-block saved activations; T = tokens = 
     float* lse;                           /* [B, H, N]             */
     float* xmid;                          /* [T, D]  fp32          */
     void* h2;                             /* [T, D]  norm2 out     */
-    void* u;                              /* [T, F]  fc1 pre-act   */
+    void* u;                              /* [T, F]  gelu'(fc1 pre-activation) */
     void* g;                              /* [T, F]  gelu(u)       */
 } ssl4gie_block_act;
 typedef struct ssl4gie_block_dims {

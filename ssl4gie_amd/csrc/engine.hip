@@ -6,9 +6,9 @@
 // looped at models_mae.py:166-167,186-187 / Models/models.py:451-454.
 //
 // Forward (7 launches):  LN1 -> QKV GEMM(+bias) -> fused attention -> proj GEMM(+bias+residual)
-//                        -> LN2 -> fc1 GEMM(+bias, GELU; saves u and gelu(u)) -> fc2 GEMM(+bias+res).
-// Backward: data-gradient GEMMs are NT products against pre-transposed weight copies (GELU' fused
-// in the fc2 one), weight-gradient GEMMs are split-K TN products over the token axis with the
+//                        -> LN2 -> fc1 GEMM(+bias; saves gelu'(u) and gelu(u)) -> fc2 GEMM(+bias+res).
+// Backward: data-gradient GEMMs are NT products against pre-transposed weight copies (the saved GELU'
+// multiplied in by the fc2 one), weight-gradient GEMMs are split-K TN products over the token axis with the
 // bias gradients (column sums of dY) fused in, and both LayerNorm backward kernels add the residual
 // gradient and emit the operand-type copy the next GEMM consumes.
 #include "common.h"
@@ -180,7 +180,7 @@ extern "C" int ssl4gie_block_fwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     RC(ssl4gie_layernorm_fwd(a->xmid, w->ln2_g, w->ln2_b, a->h2, dt, a->mean2, a->rstd2, T, D,
                              d->eps, stream));
     memset(&e, 0, sizeof(e));
-    e.C = a->u; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_BIAS_GELU; e.bias = w->bfc1;
+    e.C = a->u; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_BIAS_GELU_GRAD; e.bias = w->bfc1;
     e.out2 = a->g;
     RC(linear_fwd(a->h2, w->wfc1, T, F, D, dt, e, stream));
     memset(&e, 0, sizeof(e));
@@ -213,7 +213,7 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
 
     // ---- fc2
     memset(&e, 0, sizeof(e));
-    e.C = du; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_DGELU; e.aux = a->u;
+    e.C = du; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_MUL_AUX; e.aux = a->u;
     RC(linear_bwd_data(dy, w->wfc2, w->wfc2_t, T, D, F, dt, e, stream));
     wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, g->bfc2, dt, accumulate);
     RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));

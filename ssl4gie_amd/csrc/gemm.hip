@@ -64,6 +64,21 @@ DEVI void epi_store4(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m,
                 for (int j = 0; j < 4; ++j) v[j] *= FAST ? dgelu_fast(u[j]) : dgelu_f(u[j]);
                 break;
             }
+            case SSL4GIE_EPI_BIAS_GELU_GRAD: {
+                if (e.bias) v += ld4(e.bias + n);
+                f32x4 g, d;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    g[j] = FAST ? gelu_fast(v[j]) : gelu_f(v[j]);
+                    d[j] = FAST ? dgelu_fast(v[j]) : dgelu_f(v[j]);
+                }
+                st4(C + off, d);
+                st4((TC*)e.out2 + off, g);
+                return;
+            }
+            case SSL4GIE_EPI_MUL_AUX:
+                v *= ld4((const TC*)e.aux + off);
+                break;
             default:
                 if (e.accumulate) v += ld4(C + off);
                 break;
@@ -88,6 +103,14 @@ DEVI void epi_store4(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m,
                     break;
                 case SSL4GIE_EPI_DGELU:
                     v *= dgelu_f(Elem<TC>::ld((const TC*)e.aux + off + j));
+                    break;
+                case SSL4GIE_EPI_BIAS_GELU_GRAD:
+                    if (e.bias) v += e.bias[n + j];
+                    Elem<TC>::st(C + off + j, dgelu_f(v));
+                    Elem<TC>::st((TC*)e.out2 + off + j, gelu_f(v));
+                    continue;
+                case SSL4GIE_EPI_MUL_AUX:
+                    v *= Elem<TC>::ld((const TC*)e.aux + off + j);
                     break;
                 default:
                     if (e.accumulate) v += Elem<TC>::ld(C + off + j);
@@ -122,6 +145,21 @@ DEVI void epi_vec(const EpiArgs& e, TC* __restrict__ C, long long ldc, int m, in
         const f32x4 u = ld4((const TC*)e.aux + off);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= dgelu_fast(u[j]);
+    } else if (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
+        if (e.bias) v += ld4(e.bias + n);
+        f32x4 g, d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float cdf, xpdf;
+            gelu_parts_fast(v[j], cdf, xpdf);
+            g[j] = v[j] * cdf;
+            d[j] = cdf + xpdf;
+        }
+        st4(C + off, d);
+        st4((TC*)e.out2 + off, g);
+        return;
+    } else if (MODE == SSL4GIE_EPI_MUL_AUX) {
+        v *= ld4((const TC*)e.aux + off);
     } else {
         if (e.accumulate) v += ld4(C + off);
     }
@@ -146,6 +184,8 @@ DEVI void epi_wave_tile_dispatch(const EpiArgs& e, TC* __restrict__ C, long long
         case SSL4GIE_EPI_BIAS_GELU: epi_wave_tile<TC, SSL4GIE_EPI_BIAS_GELU>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
         case SSL4GIE_EPI_BIAS_RESIDUAL: epi_wave_tile<TC, SSL4GIE_EPI_BIAS_RESIDUAL>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
         case SSL4GIE_EPI_DGELU: epi_wave_tile<TC, SSL4GIE_EPI_DGELU>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
+        case SSL4GIE_EPI_BIAS_GELU_GRAD: epi_wave_tile<TC, SSL4GIE_EPI_BIAS_GELU_GRAD>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
+        case SSL4GIE_EPI_MUL_AUX: epi_wave_tile<TC, SSL4GIE_EPI_MUL_AUX>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
         default: epi_wave_tile<TC, SSL4GIE_EPI_NONE>(e, C, ldc, m_base, n_base, M, N, acc, lane); break;
     }
 }
@@ -282,7 +322,7 @@ DEVI int nt_swz(int r) { return (r >> 1) & 7; }
 // that has just been consumed (exactly 32 KiB) and written out as whole 256-byte rows, 16 B/lane.
 // LDS image: row r at r*256, 16-B chunk c stored at position c ^ (r & 15)  (ds_write_b64 2-way,
 // ds_read_b128 conflict-free).
-template <bool GELU>
+template <int XF>  // 0 as is, 1 gelu, 2 gelu'
 DEVI void tile_lds_write(char* buf, int row_base, int col_base, const f32x4 (&v)[4][4], int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -292,15 +332,15 @@ DEVI void tile_lds_write(char* buf, int row_base, int col_base, const f32x4 (&v)
             const int col = col_base + 16 * j + 4 * (lane >> 4);
             const int c = col >> 3;
             f32x4 x = v[i][j];
-            if (GELU) {
+            if (XF != 0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = gelu_fast(x[q]);
+                for (int q = 0; q < 4; ++q) x[q] = XF == 1 ? gelu_fast(x[q]) : dgelu_fast(x[q]);
             }
             u32x2 pk;
             pk[0] = pack_bf2(x[0], x[1]);
             pk[1] = pack_bf2(x[2], x[3]);
             *(u32x2*)(buf + row * 256 + ((c ^ (row & 15)) << 4) + ((col & 4) << 1)) = pk;
-            if (GELU) __builtin_amdgcn_sched_barrier(0);
+            if (XF != 0) __builtin_amdgcn_sched_barrier(0);
         }
 }
 DEVI void tile_lds_store(const char* buf, bf16_t* __restrict__ C, long long ldc, int m0, int n0, int M,
@@ -316,16 +356,16 @@ DEVI void tile_lds_store(const char* buf, bf16_t* __restrict__ C, long long ldc,
 // whole-tile epilogue (all 4 waves; contains workgroup barriers -> call uniformly)
 // stage the (already transformed) 128x128 tile and store whole rows; `gelu2` adds the second,
 // GELU-activated output.  Contains workgroup barriers -> call uniformly.
-template <bool GELU2>
+template <bool GELU2, int XF1 = 0>  // XF1: transform of the first output (2 = gelu' for GELU_GRAD)
 DEVI void tile_out_lds(char* buf, bf16_t* __restrict__ C, bf16_t* __restrict__ C2, long long ldc, int m0,
                        int n0, int wm, int wn, int M, int N, f32x4 (&acc)[4][4], int wave, int lane) {
     __builtin_amdgcn_s_barrier();  // every wave has finished reading this K-tile buffer
-    tile_lds_write<false>(buf, wm, wn, acc, lane);
+    tile_lds_write<XF1>(buf, wm, wn, acc, lane);
     __syncthreads();
     tile_lds_store(buf, C, ldc, m0, n0, M, N, wave, lane);
     if (GELU2) {
         __syncthreads();
-        tile_lds_write<true>(buf, wm, wn, acc, lane);
+        tile_lds_write<1>(buf, wm, wn, acc, lane);
         __syncthreads();
         tile_lds_store(buf, C2, ldc, m0, n0, M, N, wave, lane);
     }
@@ -408,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
     };
 
     constexpr bool PRE_RES = false;  // measured: prefetching the fp32 residual tile does not pay
-    constexpr bool PRE_AUX = (MODE == SSL4GIE_EPI_DGELU) && (sizeof(TC) == 2);
+    constexpr bool PRE_AUX = (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX) && (sizeof(TC) == 2);
     f32x4 pre_res[PRE_RES ? 4 : 1][4];
     u32x2 pre_aux[PRE_AUX ? 4 : 1][4];
     (void)pre_res; (void)pre_aux;
@@ -460,23 +500,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
                         const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
                         acc[i][j] *= e.alpha;
                         if constexpr (MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
-                                      MODE == SSL4GIE_EPI_BIAS_RESIDUAL) {
+                                      MODE == SSL4GIE_EPI_BIAS_RESIDUAL ||
+                                      MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
                             if (e.bias && n < N) acc[i][j] += ld4(e.bias + n);
                         }
                         if constexpr (PRE_RES) acc[i][j] += pre_res[i][j];
                         if constexpr (PRE_AUX) {
                             const u32x2 r = pre_aux[i][j];
-                            acc[i][j][0] *= dgelu_fast(__uint_as_float(r[0] << 16));
-                            acc[i][j][1] *= dgelu_fast(__uint_as_float(r[0] & 0xffff0000u));
-                            acc[i][j][2] *= dgelu_fast(__uint_as_float(r[1] << 16));
-                            acc[i][j][3] *= dgelu_fast(__uint_as_float(r[1] & 0xffff0000u));
+                            f32x4 u = {__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u),
+                                       __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+                            if constexpr (MODE == SSL4GIE_EPI_DGELU) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) u[q] = dgelu_fast(u[q]);
+                            }
+                            acc[i][j] *= u;
                         }
                     }
                 if constexpr (sizeof(TC) == 2 && MODE != SSL4GIE_EPI_BIAS_RESIDUAL) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    tile_out_lds<MODE == SSL4GIE_EPI_BIAS_GELU>(smem + cur * BT_STAGE_BYTES, (bf16_t*)C,
-                                                                (bf16_t*)e.out2, ldc, m0, n0, wm, wn, M,
-                                                                N, acc, wave, lane);
+                    tile_out_lds<MODE == SSL4GIE_EPI_BIAS_GELU || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD,
+                                 MODE == SSL4GIE_EPI_BIAS_GELU_GRAD ? 2 : 0>(
+                        smem + cur * BT_STAGE_BYTES, (bf16_t*)C, (bf16_t*)e.out2, ldc, m0, n0, wm, wn, M,
+                        N, acc, wave, lane);
                 } else if constexpr (MODE == SSL4GIE_EPI_BIAS_RESIDUAL) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -493,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
                     EpiArgs e2 = e;  // alpha / bias already applied above
                     e2.alpha = 1.f;
                     e2.bias = nullptr;
+                    // fp32 outputs: bias already added; DGELU / MUL_AUX re-read aux in the tile epilogue
                     constexpr int REST = (MODE == SSL4GIE_EPI_BIAS) ? SSL4GIE_EPI_NONE : MODE;
                     epi_wave_tile<TC, REST>(e2, C, ldc, m0 + wm, n0 + wn, M, N, acc, lane);
                 }
@@ -504,221 +550,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             cur ^= 1;
-        }
-    }
-}
-
-// ---- NT, deep pipeline ---------------------------------------------------------------------
-// The 2-stage kernel above keeps only one 32-KiB K-tile in flight per workgroup, and measured
-// K-iterations are bound by the L2/MALL round trip (Little's law: 64 KiB per CU in flight / ~2.5 us
-// = 26 GB/s per CU), not by MFMA issue.  This variant trades K-tile depth for pipeline depth:
-// BK = 32 (16-KiB stages), a ring of 4 stages with THREE in flight behind counted `s_waitcnt
-// vmcnt(N)` (LDS-DMA issued from inline asm so hipcc's conservative vmcnt(0) never drains the
-// ring), one raw s_barrier per K-step, and a dedicated 16-KiB epilogue staging area.  80 KiB of LDS
-// per workgroup -> still 2 workgroups per CU (all 160 KiB used).  Persistent over tiles: the ring
-// keeps streaming across tile boundaries.
-//
-// vmcnt bookkeeping (per wave): 4 LDS-DMA per stage.  Before consuming stage `it` the wave allows
-// 4*min(2, stages issued after it) younger LDS-DMA to remain outstanding, plus the E epilogue
-// stores that were queued behind them during the 3 iterations that follow a tile's epilogue
-// (CDNA4 counts loads, stores and LDS-DMA in one in-order queue).
-#define N3_BK 32
-#define N3_STAGES 4
-#define N3_STAGE_BYTES 16384
-#define N3_LDS_BYTES (N3_STAGES * N3_STAGE_BYTES + 16384)
-DEVI int n3_swz(int r) { return (r >> 1) & 2; }  // 64-B rows: chunk ^= 2*bit2(row); conflict-free b128
-
-template <int N> DEVI void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt immediate");
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-}
-DEVI void n3_wait(int ahead, int extra) {  // ahead in 0..2 stages, extra in {0, 8, 16} stores
-    switch (ahead * 3 + (extra >> 3)) {
-        case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<8>(); break;
-        case 2: wait_vmcnt<16>(); break;
-        case 3: wait_vmcnt<4>(); break;
-        case 4: wait_vmcnt<12>(); break;
-        case 5: wait_vmcnt<20>(); break;
-        case 6: wait_vmcnt<8>(); break;
-        case 7: wait_vmcnt<16>(); break;
-        default: wait_vmcnt<24>(); break;
-    }
-}
-// half-tile (64 rows x 128 cols bf16 = 16 KiB) images for the coalesced output stores
-DEVI void half_lds_write(char* buf, int row_in_half0, int col_base, const f32x4 (&v)[4][4], int lane,
-                         bool gelu) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = row_in_half0 + 16 * i + (lane & 15);
-            const int col = col_base + 16 * j + 4 * (lane >> 4);
-            const int c = col >> 3;
-            f32x4 x = v[i][j];
-            if (gelu) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = gelu_fast(x[q]);
-            }
-            u32x2 pk;
-            pk[0] = pack_bf2(x[0], x[1]);
-            pk[1] = pack_bf2(x[2], x[3]);
-            *(u32x2*)(buf + row * 256 + ((c ^ (row & 15)) << 4) + ((col & 4) << 1)) = pk;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-}
-DEVI void tile_store_2half(const char* h0, const char* h1, bf16_t* __restrict__ C, long long ldc, int m0,
-                           int n0, int M, int N, int wave, int lane) {
-#pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
-        const int row = wave * 32 + it * 4 + (lane >> 4), c = lane & 15;
-        const char* src = (row < 64 ? h0 : h1) + (row & 63) * 256 + ((c ^ (row & 15)) << 4);
-        const u32x4 v = *(const u32x4*)src;
-        const int gm = m0 + row, gn = n0 + c * 8;
-        if (gm < M && gn < N) __builtin_nontemporal_store(v, (u32x4*)(C + (size_t)gm * ldc + gn));
-    }
-}
-
-template <typename TC, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt3_kernel(
-    const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
-    TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool LDS_EPI = (sizeof(TC) == 2) && (MODE != SSL4GIE_EPI_BIAS_RESIDUAL);
-    constexpr int ESTORES = LDS_EPI ? (MODE == SSL4GIE_EPI_BIAS_GELU ? 16 : 8) : 0;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int G = gridDim.x;
-    const int pos = xcd_remap(blockIdx.x, G);
-    const int my_tiles = (ntiles - pos + G - 1) / G;
-    const int nk = K / N3_BK;
-    const int total = my_tiles * nk;
-    char* epi_buf = smem + N3_STAGES * N3_STAGE_BYTES;
-
-    // this lane's source rows/chunks for the 2 A and 2 B pieces (16 rows each) its wave stages
-    const bf16_t* asrc[2];
-    const bf16_t* bsrc[2];
-    auto point_at = [&](int ti) {
-        const int tile = pos + ti * G;
-        const int sm0 = (tile / tiles_n) * BT_M, sn0 = (tile % tiles_n) * BT_N;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = (wave * 2 + i) * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ n3_swz(r);
-            int ga = sm0 + r; ga = ga < M ? ga : M - 1;
-            int gb = sn0 + r; gb = gb < N ? gb : N - 1;
-            asrc[i] = A + (size_t)ga * lda + c * 8;
-            bsrc[i] = B + (size_t)gb * ldb + c * 8;
-        }
-    };
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 2048);
-    int st_ti = 0, st_kt = 0;  // next (tile, k-step) to stage
-    auto stage_next = [&](int buf) {
-        const unsigned base = lds0 + buf * N3_STAGE_BYTES;
-        const size_t ko = (size_t)st_kt * N3_BK;
-        glds16_asm(asrc[0] + ko, base);
-        glds16_asm(asrc[1] + ko, base + 1024);
-        glds16_asm(bsrc[0] + ko, base + 8192);
-        glds16_asm(bsrc[1] + ko, base + 8192 + 1024);
-        if (++st_kt == nk) {
-            st_kt = 0;
-            if (++st_ti < my_tiles) point_at(st_ti);
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    int a_off[4], b_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ra = wm + i * 16 + (lane & 15), rb = wn + i * 16 + (lane & 15);
-        a_off[i] = ra * 64 + (((lane >> 4) ^ n3_swz(ra)) << 4);
-        b_off[i] = 8192 + rb * 64 + (((lane >> 4) ^ n3_swz(rb)) << 4);
-    }
-
-    point_at(0);
-    int issued = 0;
-    for (; issued < N3_STAGES - 1 && issued < total; ++issued) stage_next(issued);
-
-    int since_epi = 1 << 20;  // iterations since the last epilogue (stores queued behind DMA)
-    int kt = 0, ti = 0;
-    for (int it = 0; it < total; ++it) {
-        const int ahead = issued - it - 1;  // stages issued after stage `it` (0..2)
-        n3_wait(ahead, since_epi < N3_STAGES - 1 ? ESTORES : 0);
-        __builtin_amdgcn_s_barrier();
-        if (issued < total) { stage_next(issued % N3_STAGES); ++issued; }
-        ++since_epi;
-        {
-            const char* base = smem + (it % N3_STAGES) * N3_STAGE_BYTES;
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *(const bf16x8*)(base + a_off[i]);
-                bfr[i] = *(const bf16x8*)(base + b_off[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        if (++kt == nk) {
-            kt = 0;
-            const int tile = pos + ti * G;
-            ++ti;
-            const int m0 = (tile / tiles_n) * BT_M, n0 = (tile % tiles_n) * BT_N;
-            if constexpr (LDS_EPI) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[i][j] *= e.alpha;
-                        const int n = n0 + wn + j * 16 + 4 * (lane >> 4);
-                        if (MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU) {
-                            if (e.bias && n < N) acc[i][j] += ld4(e.bias + n);
-                        } else if (MODE == SSL4GIE_EPI_DGELU) {
-                            const int m = m0 + wm + i * 16 + (lane & 15);
-                            if (m < M && n < N) {
-                                const f32x4 u = ld4((const bf16_t*)e.aux + (size_t)m * ldc + n);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) acc[i][j][q] *= dgelu_fast(u[q]);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // rows 0-63 -> dedicated area, rows 64-127 -> the stage buffer just consumed
-                char* h0 = epi_buf;
-                char* h1 = smem + (it % N3_STAGES) * N3_STAGE_BYTES;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();  // all waves are done reading this stage
-                half_lds_write(wm ? h1 : h0, 0, wn, acc, lane, false);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                tile_store_2half(h0, h1, (bf16_t*)C, ldc, m0, n0, M, N, wave, lane);
-                if (MODE == SSL4GIE_EPI_BIAS_GELU) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    half_lds_write(wm ? h1 : h0, 0, wn, acc, lane, true);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    tile_store_2half(h0, h1, (bf16_t*)e.out2, ldc, m0, n0, M, N, wave, lane);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // the store allowance is exact only if no store instruction was skipped (full tile)
-                since_epi = (m0 + BT_M <= M && n0 + BT_N <= N) ? 0 : (1 << 20);
-            } else {
-                epi_wave_tile<TC, MODE>(e, C, ldc, m0 + wm, n0 + wn, M, N, acc, lane);
-                since_epi = 1 << 20;  // compiler-visible loads/stores: keep the conservative count
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
         }
     }
 }
@@ -880,13 +711,6 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
 // =====================================================================================
 // dispatch
 // =====================================================================================
-// kernel selection knob for A/B measurements (tools/gemm_bench.py): SSL4GIE_NT_DEEP=1 selects the
-// 4-stage BK=32 ring, default is the 2-stage BK=64 kernel (faster on every shape measured).
-static bool nt_use_deep() {
-    static int v = -1;
-    if (v < 0) { const char* s = getenv("SSL4GIE_NT_DEEP"); v = (s && s[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
 static bool is16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static bool nt_ok(const ssl4gie_gemm_desc* d) {
@@ -951,11 +775,11 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     REQUIRE(d->batch1 >= 1 && d->batch2 >= 1);
     REQUIRE(d->dtype_ab == SSL4GIE_F32 || d->dtype_ab == SSL4GIE_BF16);
     REQUIRE(d->dtype_c == SSL4GIE_F32 || d->dtype_c == SSL4GIE_BF16);
-    REQUIRE(d->epilogue >= SSL4GIE_EPI_NONE && d->epilogue <= SSL4GIE_EPI_DGELU);
+    REQUIRE(d->epilogue >= SSL4GIE_EPI_NONE && d->epilogue <= SSL4GIE_EPI_MUL_AUX);
     REQUIRE(d->epilogue != SSL4GIE_EPI_BIAS || d->bias);
-    REQUIRE(d->epilogue != SSL4GIE_EPI_BIAS_GELU || d->out2);
+    REQUIRE((d->epilogue != SSL4GIE_EPI_BIAS_GELU && d->epilogue != SSL4GIE_EPI_BIAS_GELU_GRAD) || d->out2);
     REQUIRE(d->epilogue != SSL4GIE_EPI_BIAS_RESIDUAL || d->residual);
-    REQUIRE(d->epilogue != SSL4GIE_EPI_DGELU || d->aux);
+    REQUIRE((d->epilogue != SSL4GIE_EPI_DGELU && d->epilogue != SSL4GIE_EPI_MUL_AUX) || d->aux);
     REQUIRE(d->batch1 * d->batch2 == 1 || d->epilogue == SSL4GIE_EPI_NONE);
     REQUIRE(!d->accumulate || d->epilogue == SSL4GIE_EPI_NONE);
     REQUIRE(!d->colsum_a || (d->sAm == 1 && d->batch1 * d->batch2 == 1 && d->sAk >= d->M));
@@ -969,32 +793,18 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
         const int ntiles = tm * tn;
         dim3 grid(ntiles < NT_MAX_WGS ? ntiles : NT_MAX_WGS), block(256);
         ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
-#define NT_LAUNCH(TC_, MODE_)                                                                      \
-    do {                                                                                           \
-        if (nt_use_deep()) {                                                                       \
-            auto kfn = gemm_bf16_nt3_kernel<TC_, MODE_>;                                           \
-            static bool attr_set = false; /* idempotent; a benign race only repeats the call */    \
-            if (!attr_set) {                                                                       \
-                HIP_RET(hipFuncSetAttribute((const void*)kfn,                                      \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                            N3_LDS_BYTES));                                        \
-                attr_set = true;                                                                   \
-            }                                                                                      \
-            hipLaunchKernelGGL(kfn, grid, block, N3_LDS_BYTES, st, (const bf16_t*)d->A, d->sAm,    \
-                               (const bf16_t*)d->B, d->sBn, (TC_*)d->C, d->ldc, d->M, d->N, d->K,  \
-                               tn, ntiles, e);                                                     \
-        } else {                                                                                   \
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<TC_, MODE_>), grid, block, BT_LDS_BYTES, st,   \
-                               (const bf16_t*)d->A, d->sAm, (const bf16_t*)d->B, d->sBn,           \
-                               (TC_*)d->C, d->ldc, d->M, d->N, d->K, tn, ntiles, e);               \
-        }                                                                                          \
-    } while (0)
+#define NT_LAUNCH(TC_, MODE_)                                                                  \
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<TC_, MODE_>), grid, block, BT_LDS_BYTES, st,       \
+                       (const bf16_t*)d->A, d->sAm, (const bf16_t*)d->B, d->sBn, (TC_*)d->C,   \
+                       d->ldc, d->M, d->N, d->K, tn, ntiles, e)
 #define NT_MODES(TC_)                                                                    \
     switch (d->epilogue) {                                                               \
         case SSL4GIE_EPI_BIAS: NT_LAUNCH(TC_, SSL4GIE_EPI_BIAS); break;                  \
         case SSL4GIE_EPI_BIAS_GELU: NT_LAUNCH(TC_, SSL4GIE_EPI_BIAS_GELU); break;        \
         case SSL4GIE_EPI_BIAS_RESIDUAL: NT_LAUNCH(TC_, SSL4GIE_EPI_BIAS_RESIDUAL); break; \
         case SSL4GIE_EPI_DGELU: NT_LAUNCH(TC_, SSL4GIE_EPI_DGELU); break;                \
+        case SSL4GIE_EPI_BIAS_GELU_GRAD: NT_LAUNCH(TC_, SSL4GIE_EPI_BIAS_GELU_GRAD); break; \
+        case SSL4GIE_EPI_MUL_AUX: NT_LAUNCH(TC_, SSL4GIE_EPI_MUL_AUX); break;            \
         default: NT_LAUNCH(TC_, SSL4GIE_EPI_NONE); break;                                \
     }
         if (d->dtype_c == SSL4GIE_BF16) { NT_MODES(bf16_t) } else { NT_MODES(float) }

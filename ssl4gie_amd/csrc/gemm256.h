@@ -53,6 +53,23 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
                       int lane) {
     const int r16 = lane & 15, g4 = lane >> 4;
     const int R0 = lane >> 4, Cc = lane & 15;
+    const int gn = cbase + 4 * Cc;
+    // the residual rows are fetched PF blocks ahead (a ring of PF x 4 row segments in the registers
+    // that held the operand fragments): one exposed HBM round trip per tile instead of one per block
+    constexpr int PF = 3;
+    f32x4 rs[PF][4];
+    auto fetch = [&](int mt, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gm = rbase + 16 * mt + R0 + 4 * q;
+            dst[q] = (FULL || (gm < M && gn < N)) ? ld4(residual + (size_t)gm * ldr + gn)
+                                                  : f32x4{0, 0, 0, 0};
+        }
+    };
+    if constexpr (RESID) {
+#pragma unroll
+        for (int mt = 0; mt < PF; ++mt) fetch(mt, rs[mt]);
+    }
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
 #pragma unroll
@@ -65,13 +82,66 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
         for (int q = 0; q < 4; ++q) {
             const int R = R0 + 4 * q;
             f32x4 w = *(const f32x4*)(stg + R * 256 + ((Cc ^ R) << 4));
-            const int gm = rbase + 16 * mt + R, gn = cbase + 4 * Cc;
+            const int gm = rbase + 16 * mt + R;
+            if constexpr (RESID) w += rs[mt % PF][q];
             if (FULL || (gm < M && gn < N)) {
                 float* c = C + (size_t)gm * ldc + gn;
-                if constexpr (RESID) w += ld4(residual + (size_t)gm * ldr + gn);
                 if (accumulate) w += ld4(c);
                 st4(c, w);
             }
         }
+        if constexpr (RESID) {
+            if (mt + PF < 8) fetch(mt + PF, rs[mt % PF]);
+        }
+    }
+}
+
+// bf16 outputs multiplied by a bf16 auxiliary tile (the saved GELU derivative): same transposition,
+// fp32 through the staging area, the aux rows requested 6 row blocks ahead (48 VGPRs, the registers of the
+// dead operand fragments) in the coalesced row layout.
+// AUXF: 1 multiply by aux, 2 multiply by gelu'(aux).
+template <bool FULL, int AUXF>
+DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
+                           const bf16_t* __restrict__ aux, bf16_t* __restrict__ C,
+                           const long long ldc, int rbase, int cbase, int M, int N, int lane) {
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int R0 = lane >> 4, Cc = lane & 15;
+    const int gn = cbase + 4 * Cc;
+    constexpr int PF = AUXF == 2 ? 4 : 6;  // ring of 6 of the 8 row blocks: 48 VGPRs
+    u32x2 ax[PF][4];
+    auto fetch = [&](int mt, u32x2 (&dst)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gm = rbase + 16 * mt + R0 + 4 * q;
+            dst[q] = (FULL || (gm < M && gn < N)) ? *(const u32x2*)(aux + (size_t)gm * ldc + gn)
+                                                  : u32x2{0, 0};
+        }
+    };
+#pragma unroll
+    for (int mt = 0; mt < PF; ++mt) fetch(mt, ax[mt]);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 v = acc[mt][nt] * alpha;
+            const int c = nt * 4 + g4;
+            *(f32x4*)(stg + r16 * 256 + ((c ^ r16) << 4)) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = R0 + 4 * q;
+            f32x4 w = *(const f32x4*)(stg + R * 256 + ((Cc ^ R) << 4));
+            const int gm = rbase + 16 * mt + R;
+            const u32x2 r = ax[mt % PF][q];
+            f32x4 u = {__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u),
+                       __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+            if constexpr (AUXF == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = dgelu_fast(u[j]);
+            }
+            w *= u;
+            if (FULL || (gm < M && gn < N)) st4(C + (size_t)gm * ldc + gn, w);
+        }
+        if (mt + PF < 8) fetch(mt + PF, ax[mt % PF]);
     }
 }

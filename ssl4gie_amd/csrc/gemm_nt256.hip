@@ -60,54 +60,63 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
         const int n = cbase + 16 * nt + 4 * g4;
         bias4[nt] = f32x4{0, 0, 0, 0};
         if constexpr (MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
-                      MODE == SSL4GIE_EPI_BIAS_RESIDUAL) {
+                      MODE == SSL4GIE_EPI_BIAS_RESIDUAL || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
             if (bias && (FULL || n < N)) bias4[nt] = ld4(bias + n);
         }
     }
-    if constexpr (sizeof(TC) == 2) {
+    if constexpr (sizeof(TC) == 2 && (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX)) {
+        p_store_bf16_aux<FULL, MODE == SSL4GIE_EPI_DGELU ? 2 : 1>(acc, stg, alpha, aux, (bf16_t*)C,
+                                                                  ldc, rbase, cbase, M, N, lane);
+    } else if constexpr (sizeof(TC) == 2) {
         // bf16: stage 16 rows x 64 columns (2 KiB), chunk c of row r at position c ^ (r & 7)
         const int R0 = lane >> 3, Cc = lane & 7;
+        // stage one 16 x 64 bf16 block at byte offset `base` of the wave's staging area
+        auto put = [&](int base, int nt, const f32x4& x) {
+            u32x2 pk;
+            pk[0] = pack_bf2(x[0], x[1]);
+            pk[1] = pack_bf2(x[2], x[3]);
+            const int c = nt * 2 + (g4 >> 1);
+            *(u32x2*)(stg + base + r16 * 128 + ((c ^ (r16 & 7)) << 4) + ((g4 & 1) << 3)) = pk;
+        };
+        auto flush = [&](int base, bf16_t* __restrict__ dst, int mt) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int R = R0 + 8 * hh;
+                const u32x4 w = *(const u32x4*)(stg + base + R * 128 + ((Cc ^ (R & 7)) << 4));
+                const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
+                if (FULL || (gm < M && gn < N)) *(u32x4*)(dst + (size_t)gm * ldc + gn) = w;
+            }
+        };
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
-            const int grow = rbase + 16 * mt + r16;
-            f32x4 v[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                v[nt] = acc[mt][nt] * alpha + bias4[nt];
-                if constexpr (MODE == SSL4GIE_EPI_DGELU) {
-                    const int n = cbase + 16 * nt + 4 * g4;
-                    if (FULL || (grow < M && n < N)) {
-                        const f32x4 u = ld4(aux + (size_t)grow * ldc + n);
+                const f32x4 v = acc[mt][nt] * alpha + bias4[nt];
+                if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
+                    // gelu(u) and gelu'(u) share exp(-u^2/2) and the erf polynomial
+                    f32x4 g, d;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[nt][q] *= dgelu_fast(u[q]);
+                    for (int q = 0; q < 4; ++q) {
+                        float cdf, xpdf;
+                        gelu_parts_fast(v[q], cdf, xpdf);
+                        g[q] = v[q] * cdf;
+                        d[q] = cdf + xpdf;
                     }
+                    put(0, nt, d);
+                    put(2048, nt, g);
+                } else if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU) {
+                    f32x4 g;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = gelu_fast(v[q]);
+                    put(0, nt, v);
+                    put(2048, nt, g);
+                } else {
+                    put(0, nt, v);
                 }
             }
-            auto emit = [&](bf16_t* __restrict__ dst, auto gelu_c) {
-                constexpr bool GELU = decltype(gelu_c)::value;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    f32x4 x = v[nt];
-                    if constexpr (GELU) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) x[q] = gelu_fast(x[q]);
-                    }
-                    u32x2 pk;
-                    pk[0] = pack_bf2(x[0], x[1]);
-                    pk[1] = pack_bf2(x[2], x[3]);
-                    const int c = nt * 2 + (g4 >> 1);
-                    *(u32x2*)(stg + r16 * 128 + ((c ^ (r16 & 7)) << 4) + ((g4 & 1) << 3)) = pk;
-                }
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int R = R0 + 8 * hh;
-                    const u32x4 w = *(const u32x4*)(stg + R * 128 + ((Cc ^ (R & 7)) << 4));
-                    const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
-                    if (FULL || (gm < M && gn < N)) *(u32x4*)(dst + (size_t)gm * ldc + gn) = w;
-                }
-            };
-            emit((bf16_t*)C, std::false_type{});
-            if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU) emit(out2, std::true_type{});
+            flush(0, (bf16_t*)C, mt);
+            if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD || MODE == SSL4GIE_EPI_BIAS_GELU)
+                flush(2048, out2, mt);
         }
     } else {
         p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL>(
@@ -119,7 +128,8 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
 template <typename TC, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
-    TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e) {
+    TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e,
+    int dbg_skip_epilogue /* ablation knob: 1 = no epilogue (timing only, wrong output) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -295,7 +305,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * P_BN;
             if (wr == 0) __builtin_amdgcn_s_barrier();
             char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
-            if (m0 + P_BM <= M && n0 + P_BN <= N)
+            if (dbg_skip_epilogue) {
+                asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[7][3][3]));
+            } else if (m0 + P_BM <= M && n0 + P_BN <= N)
                 p_epilogue<TC, MODE, true>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                            e_out2, e_accumulate, C, ldc, m0 + wr * 128,
                                            n0 + wc * 64, M, N, lane);
@@ -338,7 +350,9 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
     if (d->dtype_c == SSL4GIE_BF16) {
         if (ep == SSL4GIE_EPI_BIAS_RESIDUAL || d->accumulate) return false;
     } else {
-        if (ep == SSL4GIE_EPI_BIAS_GELU || ep == SSL4GIE_EPI_DGELU) return false;
+        if (ep == SSL4GIE_EPI_BIAS_GELU || ep == SSL4GIE_EPI_DGELU ||
+            ep == SSL4GIE_EPI_BIAS_GELU_GRAD || ep == SSL4GIE_EPI_MUL_AUX)
+            return false;
     }
     if (mode == 1) return true;
     // heuristic: enough 256x256 tiles to fill most of the chip
@@ -351,6 +365,8 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     const int ntiles = tm * tn;
     dim3 grid(ntiles < 256 ? ntiles : 256), block(512);
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate};
+    static int skip_epi = -1;  // SSL4GIE_NT256_NOEPI=1: ablation (K-loop only; outputs are garbage)
+    if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] == '1') ? 1 : 0; }
     ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
 #define P_LAUNCH(TC_, MODE_)                                                                       \
     do {                                                                                           \
@@ -363,13 +379,15 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         }                                                                                          \
         hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAm,         \
                            (const bf16_t*)d->B, d->sBn, (TC_*)d->C, d->ldc, d->M, d->N, d->K, tn,  \
-                           ntiles, e);                                                             \
+                           ntiles, e, skip_epi);                                                    \
     } while (0)
     if (d->dtype_c == SSL4GIE_BF16) {
         switch (d->epilogue) {
             case SSL4GIE_EPI_BIAS: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS); break;
             case SSL4GIE_EPI_BIAS_GELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU); break;
             case SSL4GIE_EPI_DGELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_DGELU); break;
+            case SSL4GIE_EPI_BIAS_GELU_GRAD: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU_GRAD); break;
+            case SSL4GIE_EPI_MUL_AUX: P_LAUNCH(bf16_t, SSL4GIE_EPI_MUL_AUX); break;
             case SSL4GIE_EPI_NONE: P_LAUNCH(bf16_t, SSL4GIE_EPI_NONE); break;
             default: return ARG_ERR;
         }

@@ -145,16 +145,17 @@ def linear_fwd(x2d, w, bias=None, out_dtype=None, epilogue=None, residual=None):
         _f32(residual)
         assert residual.shape == (T, n_out)
         d.residual, d.ldr = ptr(residual), n_out
-    if epilogue == _lib.EPI_BIAS_GELU:
-        out2 = torch.empty_like(y)
+    if epilogue in (_lib.EPI_BIAS_GELU, _lib.EPI_BIAS_GELU_GRAD):
+        out2 = torch.empty_like(y)  # (u, gelu(u)) resp. (gelu'(u), gelu(u))
         d.out2 = ptr(out2)
     gemm_raw(d, x2d.device)
     return (y, out2) if out2 is not None else y
 
 
-def linear_bwd_data(dy2d, w, w_t=None, out_dtype=None, dgelu_aux=None):
-    """dx[T, k_in] = dy[T, n_out] @ w[n_out, k_in]; uses w_t[k_in, n_out] (NT fast path) if given."""
-    _dev(dy2d, w, w_t, dgelu_aux)
+def linear_bwd_data(dy2d, w, w_t=None, out_dtype=None, dgelu_aux=None, mul_aux=None):
+    """dx[T, k_in] = dy[T, n_out] @ w[n_out, k_in]; uses w_t[k_in, n_out] (NT fast path) if given.
+    `dgelu_aux` = u: dx *= gelu'(u);  `mul_aux` = m: dx *= m (m = gelu'(u) saved by the forward)."""
+    _dev(dy2d, w, w_t, dgelu_aux, mul_aux)
     T, n_out = dy2d.shape
     k_in = w.shape[1]
     assert w.shape[0] == n_out
@@ -172,6 +173,9 @@ def linear_bwd_data(dy2d, w, w_t=None, out_dtype=None, dgelu_aux=None):
     if dgelu_aux is not None:
         assert dgelu_aux.shape == dx.shape and dgelu_aux.dtype == out_dtype
         d.epilogue, d.aux = _lib.EPI_DGELU, ptr(dgelu_aux)
+    if mul_aux is not None:
+        assert dgelu_aux is None and mul_aux.shape == dx.shape and mul_aux.dtype == out_dtype
+        d.epilogue, d.aux = _lib.EPI_MUL_AUX, ptr(mul_aux)
     gemm_raw(d, dy2d.device)
     return dx
 

@@ -154,6 +154,14 @@ def test_gemm_bf16_nt_epilogues(M, N, K):
     F.gelu(t).backward(dy.double() @ w.double())
     dx = ops.linear_bwd_data(dy.to(DEV), wd, wt.to(DEV), dgelu_aux=aux.to(DEV))
     assert rel_err(dx.float(), t.grad) < 1e-2
+    # the executor's pair: forward saves gelu'(u) next to gelu(u), backward multiplies by it
+    d1, g1 = ops.linear_fwd(xd, wd, bd, out_dtype=BF, epilogue=_lib.EPI_BIAS_GELU_GRAD)
+    tt = acc.clone().requires_grad_(True)
+    F.gelu(tt).sum().backward()
+    assert rel_err(g1.float(), F.gelu(acc)) < 8e-3
+    assert rel_err(d1.float(), tt.grad) < 8e-3
+    dxm = ops.linear_bwd_data(dy.to(DEV), wd, wt.to(DEV), mul_aux=aux.to(DEV))
+    assert rel_err(dxm.float(), (dy.double() @ w.double()) * aux.double()) < 1e-2
     dx2 = ops.linear_bwd_data(dy.to(DEV), wd, None)  # generic NN fallback agrees with NT fast path
     dx3 = ops.linear_bwd_data(dy.to(DEV), wd, wt.to(DEV))
     assert rel_err(dx2.float(), dx3.float()) < 8e-3

@@ -48,7 +48,7 @@ for name, T, n, k, ep in NT:
     if ep == "bias": fn = lambda: ops.linear_fwd(x, w, b)
     elif ep == "biasf32": fn = lambda: ops.linear_fwd(x, w, b, out_dtype=torch.float32)
     elif ep == "res": fn = lambda: ops.linear_fwd(x, w, b, out_dtype=torch.float32, epilogue=_lib.EPI_BIAS_RESIDUAL, residual=res)
-    elif ep == "gelu": fn = lambda: ops.linear_fwd(x, w, b, epilogue=_lib.EPI_BIAS_GELU)
+    elif ep == "gelu": fn = lambda: ops.linear_fwd(x, w, b, epilogue=_lib.EPI_BIAS_GELU_GRAD)
     elif ep == "dgelu": fn = lambda: ops.linear_bwd_data(x, w.t().contiguous(), w, dgelu_aux=aux) if False else ops.linear_fwd(x, w, None)
     else: fn = lambda: ops.linear_fwd(x, w, None)
     if ep == "dgelu":
@@ -57,7 +57,7 @@ for name, T, n, k, ep in NT:
         d.A, d.sAm, d.sAk = x.data_ptr(), k, 1
         d.B, d.sBk, d.sBn = w.data_ptr(), 1, k
         d.C, d.ldc = y.data_ptr(), n
-        d.epilogue, d.aux = _lib.EPI_DGELU, aux.data_ptr()
+        d.epilogue, d.aux = _lib.EPI_MUL_AUX, aux.data_ptr()
         fn = lambda: ops.gemm_raw(d, dev)
     ms = timeit(fn)
     fl = 2.0 * T * n * k
