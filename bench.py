@@ -137,7 +137,7 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     # ---- roofline pass (instrumented; outside the timed region)
     L = _lib.load()
@@ -159,9 +159,19 @@ def main():
                for i, k in enumerate(kinds) if nl[i]}
         dom = max(range(5), key=lambda i: ms[i])
         ach = fl[dom] / max(ms[dom], 1e-9) / 1e9
+        # HBM bytes per launch of that kernel kind from the committed rocprofv3 --pmc passes
+        # (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE); null if no PMC file travels along
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch"].get(kinds[dom])
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": round(ach, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": None, "avg_launch_us": per[kinds[dom]]["avg_launch_us"],
+                "traffic": traffic, "traffic_unit": "HBM bytes/launch (profiles/pmc_traffic.json)",
+                "flops_per_launch": round(fl[dom] / max(nl[dom], 1)),
+                "avg_launch_us": per[kinds[dom]]["avg_launch_us"],
                 "launches_per_step": per[kinds[dom]]["launches_per_step"], "kernels": per}
     if world > 1:
         dist.barrier()
