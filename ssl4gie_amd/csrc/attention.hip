@@ -84,7 +84,7 @@ DEVI float group_sum(float v) {
 
 // ------------------------------------------------------------------ forward
 template <int HD, int NKT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                             bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int N, int H,
                                                             float scale) {
@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (kt * 16 + 4 * g + r >= N) s[kt][r] = -INFINITY;
+                if (kt * 16 + 16 > N) {  // wave-uniform: only the last tile(s) hold padded keys
+                    if (kt * 16 + 4 * g + r >= N) s[kt][r] = -INFINITY;
+                }
                 mx = fmaxf(mx, s[kt][r]);
             }
         mx = group_max(mx);
@@ -247,10 +249,15 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
                 p1 = MFMA16(row_frag<HD>(Vimg, kp * 32 + 16, ks, lane), dof[ks], p1);
             }
             const int ka = kp * 32 + 4 * g;
+            const bool tail = kp * 32 + 32 > N;  // wave-uniform: padded keys only in the last pair
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pa = (ka + r < N) ? __builtin_amdgcn_exp2f(s0[r] * c - l2) : 0.f;
-                const float pb = (ka + 16 + r < N) ? __builtin_amdgcn_exp2f(s1[r] * c - l2) : 0.f;
+                float pa = __builtin_amdgcn_exp2f(s0[r] * c - l2);
+                float pb = __builtin_amdgcn_exp2f(s1[r] * c - l2);
+                if (tail) {
+                    pa = (ka + r < N) ? pa : 0.f;
+                    pb = (ka + 16 + r < N) ? pb : 0.f;
+                }
                 s0[r] = pa * (p0[r] - dl);  // dS^T
                 s1[r] = pb * (p1[r] - dl);
             }
@@ -296,10 +303,15 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
             const f32x4 la = *(const f32x4*)(lse_s + qa), lb = *(const f32x4*)(lse_s + qa + 16);
             const f32x4 da = *(const f32x4*)(del_s + qa), db = *(const f32x4*)(del_s + qa + 16);
             f32x4 pa, pb, dsa, dsb;
+            const bool tail = qp * 32 + 32 > N;  // wave-uniform: padded queries only in the last pair
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pa[r] = (qa + r < N) ? __builtin_amdgcn_exp2f(s0[r] * c - la[r]) : 0.f;
-                pb[r] = (qa + 16 + r < N) ? __builtin_amdgcn_exp2f(s1[r] * c - lb[r]) : 0.f;
+                pa[r] = __builtin_amdgcn_exp2f(s0[r] * c - la[r]);
+                pb[r] = __builtin_amdgcn_exp2f(s1[r] * c - lb[r]);
+                if (tail) {
+                    pa[r] = (qa + r < N) ? pa[r] : 0.f;
+                    pb[r] = (qa + 16 + r < N) ? pb[r] : 0.f;
+                }
                 dsa[r] = pa[r] * (p0[r] - da[r]);
                 dsb[r] = pb[r] * (p1[r] - db[r]);
             }
