@@ -203,6 +203,49 @@ int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* 
                       float* dx_in, void* dx_in_lp, int accumulate, void* workspace,
                       void* stream);
 
+/* ---------------------------------------------------------------- DPT decoder glue (channels-last)
+ * Replaces the torch ops around the convolutions of Models/DPT_decoder.py (depth variant): the
+ * maps are [B, H, W, C] in the operand type (`dtype`), C % 8 == 0 (bf16) / % 4 == 0 (fp32).  With
+ * this layout Conv2d(k=1) and ConvTranspose2d(k=s) are token-major ssl4gie_gemm calls and
+ * Conv2d(k=3, pad=1) is ssl4gie_gemm over the patch matrix below.
+ *
+ * im2col3x3: cols[(b,oy,ox), (dy*3+dx)*C + c] = act(x[b, oy*s+dy-1, ox*s+dx-1, c]) (0 outside),
+ *   act = ReLU if `relu` (ResidualConvUnit_custom.forward :225-229 activates the conv INPUT);
+ *   row stride ld >= 9C, columns [9C, ld) zero-filled; s in {1, 2} (act_postprocess42.1 :397-403).
+ * col2im3x3: gather-form transpose (data gradient of the strided conv). */
+int ssl4gie_im2col3x3(const void* x, void* cols, int dtype, int B, int H, int W, int C, int stride,
+                      int relu, long long ld, void* stream);
+int ssl4gie_col2im3x3(const void* dcols, void* dx, int dtype, int B, int H, int W, int C,
+                      int stride, long long ld, void* stream);
+/* F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) (:293-295, Interpolate :69-104)
+ * x [B,H,W,C] -> y [B,2H,2W,C]; backward in gather form (no atomics) */
+int ssl4gie_bilinear2x_fwd(const void* x, void* y, int dtype, int B, int H, int W, int C,
+                           void* stream);
+int ssl4gie_bilinear2x_bwd(const void* dy, void* dx, int dtype, int B, int H, int W, int C,
+                           void* stream);
+/* ConvTranspose2d(k = s) (:345-354, :371-380) = GEMM + scatter: g [B*H*W, k*k*C] with columns
+ * ordered (i, j, c) -> y[b, k*y+i, k*x+j, c] = g + bias[c]; unshuffle is its inverse (gradient) */
+int ssl4gie_pixel_shuffle(const void* g, const float* bias, void* y, int dtype, int B, int H, int W,
+                          int k, int C, void* stream);
+int ssl4gie_pixel_unshuffle(const void* dy, void* dg, int dtype, int B, int H, int W, int k, int C,
+                            void* stream);
+/* Slice(1) + Transpose + Unflatten (:5-11, :449-459): fp32 tap z [B, 1+L, D] -> x [B*L, D] in
+ * `dtype` (cls row dropped); gradient: dz[:,0] = 0, dz[:,1:] = dx */
+int ssl4gie_tokens_to_map(const float* z, void* x, int dtype, int B, int L, int D, void* stream);
+int ssl4gie_map_to_tokens(const void* dx, float* dz, int dtype, int B, int L, int D, void* stream);
+/* op 0: out = a + b (skip_add :233, :290);  op 1: out = (a > 0 ? b : 0) + (c ? c : 0): gradient
+ * through the ReLU that precedes a conv (a = the activation's input) plus the skip gradient */
+int ssl4gie_eltwise(int op, const void* a, const void* b, const void* c, void* out, int dtype,
+                    long long n, void* stream);
+/* depth head tail ReLU -> Conv2d(32, 1, 1) -> Sigmoid (:479-481): y[m] = sigmoid(sum_c relu(x[m,c])
+ * w[c] + bias[0]), y fp32 [M]; backward gives dx and dw [C], db [1] (two-stage reduction) */
+int ssl4gie_depth_head_fwd(const void* x, const float* w, const float* bias, float* y, int dtype,
+                           long long M, int C, void* stream);
+size_t ssl4gie_depth_head_bwd_workspace_bytes(long long M, int C);
+int ssl4gie_depth_head_bwd(const void* x, const float* w, const float* y, const float* dy, void* dx,
+                           float* dw, float* db, int accumulate, float* workspace, int dtype,
+                           long long M, int C, void* stream);
+
 /* ---------------------------------------------------------------- launch profiler (bench.py)
  * HIP events on the launch stream around every launch of the heavy kernels, used for the
  * `roofline` object of the bench line.  Process-global, not thread-safe, off by default.

@@ -13,9 +13,9 @@ lin_head.*`; ViT_from_MAE keeps `decoder_pos_embed`, reference :395-399).  The u
 (patch-embed GEMM, cls/pos assembly, 12 blocks with taps after blocks 2/5/8/11, final LayerNorm,
 linear head) runs on libssl4gie_hip.so.
 
-Scope of this round: `dense=None, det=False` is complete; with `dense`
-set, `forward_features` returns the four tap tensors (the DPT_decoder head is the next §8 row) and
-`det=True` (windowed attention + ViTDet FPN, §8f rank 1) raises NotImplementedError.
+Scope of this round: `dense=None` and `dense="depth"` (DPT decoder on the
+four tap tensors, `Models/DPT_decoder.py`) are complete; `dense="seg"` and `det=True` (windowed
+attention + ViTDet FPN, §8f) raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn
 
 from ..engine import EngineModule, PatchEmbedFn
+from .DPT_decoder import DPT_decoder
 from .mae.util.pos_embed import get_2d_sincos_pos_embed
 from .vit_layers import Block, PatchEmbed
 
@@ -52,16 +53,14 @@ class _ViTBackbone(EngineModule):
         if det:
             raise NotImplementedError("det=True (WindowedAttention + ViTDet_FPN, reference "
                                       "models.py:155-259) is a later §8(f) row of this build")
-        if dense:
-            raise NotImplementedError("dense heads (DPT_decoder, reference DPT_decoder.py:315) are "
-                                      "the next §8 row of this build; use forward_features for "
-                                      "the four tap tensors")
         self.head_flag = head
         if head:
             self.lin_head = nn.Linear(self.embed_dim, num_classes)
         self.frozen = frozen
         self.dense = dense
         self.det = det
+        if dense:  # reference models.py:301,408,521
+            self.decoder = self.adopt(DPT_decoder(num_classes=num_classes, dense=dense))
         self.out_token = out_token
 
     def _trunk(self, imgs, dense):
@@ -95,6 +94,8 @@ class _ViTBackbone(EngineModule):
                 x = self.forward_features(imgs)
         else:
             x = self.forward_features(imgs)
+        if self.dense:  # reference models.py:346-347, 464-465, 566-567
+            return self.decoder(x)
         return self._readout(x)
 
 

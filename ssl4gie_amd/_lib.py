@@ -78,6 +78,18 @@ PROTOTYPES = {
     "ssl4gie_decoder_assemble_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ssl4gie_decoder_assemble_bwd": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "ssl4gie_mae_loss": (i32, [vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_im2col3x3": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, vp]),
+    "ssl4gie_col2im3x3": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i64, vp]),
+    "ssl4gie_bilinear2x_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_bilinear2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_pixel_shuffle": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_pixel_unshuffle": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_tokens_to_map": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_map_to_tokens": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_eltwise": (i32, [i32, vp, vp, vp, vp, i32, i64, vp]),
+    "ssl4gie_depth_head_fwd": (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
+    "ssl4gie_depth_head_bwd_workspace_bytes": (sz, [i64, i32]),
+    "ssl4gie_depth_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_prof_begin": (i32, [i32]),
     "ssl4gie_prof_collect": (i32, [vp, vp, vp]),
     "ssl4gie_prof_end": (i32, []),

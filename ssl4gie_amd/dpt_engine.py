@@ -1,0 +1,215 @@
+"""Autograd nodes of the DPT dense decoder on the HIP engine.
+
+Maps are channels-last ([B, H, W, C], the token-major layout of the ViT carried to the upsampled
+resolutions) in the engine's operand type.  Every convolution is a GEMM of libssl4gie_hip.so:
+  * Conv2d(k=1)            -> engine.LinearFn on [B*H*W, Cin]
+  * ConvTranspose2d(k = s) -> GEMM against W[(i, j, co), ci] + pixel-shuffle scatter
+  * Conv2d(k=3, pad=1)     -> GEMM over the (dy, dx, ci) patch matrix (ssl4gie_im2col3x3); the data
+                              gradient is the same product against the flipped kernel (stride 1)
+                              or the patch-matrix transpose (stride 2); the weight gradient is the
+                              split-K TN product dY^T cols with the bias gradient fused in.
+The patch matrix is recomputed in backward instead of being kept (it is 9x the activation).
+Weight re-layouts (a few MB, once per optimizer step) and the scatter of dW back into the
+parameter's [Cout, Cin, 3, 3] layout are host-side tensor plumbing; all activation-sized work is
+HIP.  Reference: Models/DPT_decoder.py (lines cited per node).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .engine import GradSink, LPCache
+
+
+def _derived(lp: LPCache, p: torch.Tensor, tag: str, dtype, fn):
+    """operand-type tensor derived from parameter `p` by `fn`, cached until p changes"""
+    key = (id(p), tag)
+    ver = (p._version, p.data_ptr(), dtype)
+    ent = lp._c.get(key)
+    if ent is None or ent[0] != ver:
+        with torch.no_grad():
+            t = fn(p.detach())
+            if t.dtype != dtype:
+                t = ops.cast(t.contiguous(), dtype)
+            else:
+                t = t.contiguous()
+        ent = (ver, t)
+        lp._c[key] = ent
+    return ent[1]
+
+
+def _pad_cols(m: torch.Tensor, ld: int) -> torch.Tensor:
+    if m.shape[1] == ld:
+        return m
+    out = m.new_zeros(m.shape[0], ld)
+    out[:, :m.shape[1]] = m
+    return out
+
+
+def _write_grad(target: torch.Tensor, value: torch.Tensor, accumulate: bool):
+    if accumulate:
+        target.add_(value)
+    else:
+        target.copy_(value)
+
+
+class TokensToMapFn(torch.autograd.Function):
+    """Slice(1) -> Transpose -> Unflatten (DPT_decoder.py:5-11, :328-332, :449-459): fp32 tap
+    [B, 1+L, D] -> [B*L, D] operand rows (= the [B, 14, 14, D] map)."""
+
+    @staticmethod
+    def forward(ctx, z, dtype):
+        ctx.shape = z.shape
+        return ops.tokens_to_map(z.contiguous(), dtype)
+
+    @staticmethod
+    def backward(ctx, dx):
+        B, L1, D = ctx.shape
+        return ops.map_to_tokens(dx.contiguous(), B, L1 - 1, D), None
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """y = conv3x3(act(x)) + bias, pad 1, stride 1 or 2; act = ReLU if relu_in
+    (layer*_rn :412-447, ResidualConvUnit_custom :212-233, output_conv.0/.2 :469-478,
+    act_postprocess42.1 :397-403)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, relu_in, sink: GradSink, lp: LPCache):
+        B, H, W, Cin = x.shape
+        Cout = weight.shape[0]
+        dt = x.dtype
+        ld = ops.k_pad(9 * Cin, dt)
+        w2 = _derived(lp, weight, f"c3:{ld}", dt,
+                      lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), ld))
+        cols = ops.im2col3x3(x, stride, relu_in, ld)
+        y = ops.linear_fwd(cols, w2, bias.detach() if bias is not None else None, out_dtype=dt)
+        Ho, Wo = ops.conv_out_hw(H, W, stride)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.cfg = (stride, relu_in, sink, lp, ld)
+        return y.view(B, Ho, Wo, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        stride, relu_in, sink, lp, ld = ctx.cfg
+        B, H, W, Cin = x.shape
+        Cout = weight.shape[0]
+        dt = x.dtype
+        dy = dy.contiguous()
+        dy2 = dy.view(-1, Cout)
+        (tw, tb), acc, rets = sink.plan([weight, bias])
+        if tw is not None:
+            cols = ops.im2col3x3(x, stride, relu_in, ld)  # recomputed, not kept
+            fuse_b = tb is not None and not acc  # the bias gradient rides on the same product
+            dw2 = ops.linear_bwd_weight(dy2, cols, bias_out=tb if fuse_b else None)
+            if tb is not None and not fuse_b:
+                ops.colsum(dy2, out=tb, accumulate=True)
+            del cols
+            _write_grad(tw, dw2[:, :9 * Cin].view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), acc)
+        elif tb is not None:
+            ops.colsum(dy2, out=tb, accumulate=acc)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                ld2 = ops.k_pad(9 * Cout, dt)
+                wd = _derived(lp, weight, f"c3d:{ld2}", dt,
+                              lambda w: _pad_cols(w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout), ld2))
+                dcols = ops.im2col3x3(dy, 1, False, ld2)
+                dxr = ops.linear_fwd(dcols, wd, None, out_dtype=dt).view(B, H, W, Cin)
+            else:
+                w2 = _derived(lp, weight, f"c3:{ld}", dt,
+                              lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), ld))
+                w2t = _derived(lp, weight, f"c3t:{ld}", dt,
+                               lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), ld).t())
+                dcols = ops.linear_bwd_data(dy2, w2, w2t)  # [M_out, ld]
+                dxr = ops.col2im3x3(dcols, B, H, W, Cin, stride)
+            dx = ops.relu_bwd(x, dxr) if relu_in else dxr
+        return dx, rets[0], rets[1], None, None, None, None
+
+
+class ConvTransposeFn(torch.autograd.Function):
+    """ConvTranspose2d(kernel = stride = k) on a [B*H*W, Cin] map (act_postprocess12.1 :345-354,
+    act_postprocess22.1 :371-380): GEMM against W2[(i, j, co), ci] = weight[ci, co, i, j], then a
+    pixel-shuffle scatter that also adds the bias."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias, B, H, W, sink: GradSink, lp: LPCache):
+        Cin, Cout, k, _ = weight.shape
+        dt = x2.dtype
+        w2 = _derived(lp, weight, "ct", dt, lambda w: w.permute(2, 3, 1, 0).reshape(k * k * Cout, Cin))
+        g = ops.linear_fwd(x2, w2, None, out_dtype=dt)
+        y = ops.pixel_shuffle(g, bias.detach(), B, H, W, k, Cout)
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.cfg = (B, H, W, sink, lp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        B, H, W, sink, lp = ctx.cfg
+        Cin, Cout, k, _ = weight.shape
+        dt = x2.dtype
+        dy = dy.contiguous()
+        dg = ops.pixel_unshuffle(dy, k)  # [B*H*W, k*k*Cout]
+        (tw, tb), acc, rets = sink.plan([weight, bias])
+        if tw is not None:
+            dw2 = ops.linear_bwd_weight(dg, x2)  # [k*k*Cout, Cin]
+            _write_grad(tw, dw2.view(k, k, Cout, Cin).permute(3, 2, 0, 1), acc)
+        if tb is not None:
+            ops.colsum(dy.view(-1, Cout), out=tb, accumulate=acc)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w2 = _derived(lp, weight, "ct", dt, lambda w: w.permute(2, 3, 1, 0).reshape(k * k * Cout, Cin))
+            w2t = _derived(lp, weight, "ct_t", dt,
+                           lambda w: w.permute(2, 3, 1, 0).reshape(k * k * Cout, Cin).t())
+            dx = ops.linear_bwd_data(dg, w2, w2t)
+        return dx, rets[0], rets[1], None, None, None, None, None
+
+
+class Upsample2xFn(torch.autograd.Function):
+    """bilinear x2, align_corners=True (FeatureFusionBlock_custom.forward :293-295; Interpolate)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.bilinear2x_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.bilinear2x_bwd(dy.contiguous())
+
+
+class AddFn(torch.autograd.Function):
+    """skip_add.add (:233, :290): FloatFunctional in float mode is a plain add."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.eltwise_add(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class DepthHeadFn(torch.autograd.Function):
+    """ReLU -> Conv2d(32, 1, 1) -> Sigmoid (output_conv.3-.5, :479-481) -> fp32 [B, 1, H, W]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sink: GradSink):
+        B, H, W, C = x.shape
+        x2 = x.contiguous().view(-1, C)
+        w = weight.detach().reshape(-1).contiguous()
+        y = ops.depth_head_fwd(x2, w, bias.detach())
+        ctx.save_for_backward(x2, weight, bias, y)
+        ctx.cfg = (B, H, W, sink)
+        return y.view(B, 1, H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias, y = ctx.saved_tensors
+        B, H, W, sink = ctx.cfg
+        (tw, tb), acc, rets = sink.plan([weight, bias])
+        dw = tw.view(-1) if tw is not None else torch.empty(weight.numel(), device=x2.device)
+        db = tb if tb is not None else torch.empty(1, device=x2.device)
+        dx = ops.depth_head_bwd(x2, weight.detach().reshape(-1).contiguous(), y,
+                                dy.contiguous().view(-1).float(), dw, db, acc)
+        return dx.view(B, H, W, -1), rets[0], rets[1], None

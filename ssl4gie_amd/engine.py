@@ -448,6 +448,13 @@ class EngineModule(nn.Module):
         self._lp = LPCache()
         self._sink = None
         self._grad_hook = None  # set by parallel.DataParallel
+        object.__setattr__(self, "_root", None)  # owning EngineModule when nested (not a child link)
+
+    def adopt(self, child: "EngineModule"):
+        """A nested EngineModule (e.g. the DPT decoder inside ViT_from_MAE) shares the parent's
+        arena, operand cache and precision: parameters live in ONE arena per model."""
+        object.__setattr__(child, "_root", self)
+        return child
 
     def set_precision(self, name_or_dtype):
         if isinstance(name_or_dtype, str):
@@ -459,9 +466,13 @@ class EngineModule(nn.Module):
 
     @property
     def dtype_(self):
+        if self._root is not None:
+            return self._root.dtype_
         return self.engine_dtype or default_dtype()
 
     def arena(self) -> ParamArena:
+        if self._root is not None:
+            return self._root.arena()
         ps = list(self.parameters())
         a = self._arena
         if a is None or len(a.params) != len(ps) or any(x is not y for x, y in zip(a.params, ps)) \
@@ -486,9 +497,15 @@ class EngineModule(nn.Module):
         self.arena()
 
     def sink(self) -> GradSink:
+        if self._root is not None:
+            return self._root.sink()
         if self._arena is None:
             self.arena()
         return self._sink
+
+    @property
+    def lp_cache(self) -> LPCache:
+        return self._root.lp_cache if self._root is not None else self._lp
 
     # helpers used by the model mirrors -----------------------------------------------------
     def _ln(self, x, norm: nn.LayerNorm, out_dtype=None):

@@ -1,0 +1,78 @@
+"""Loss functions of the finetune heads, kept host-side on PyTorch-ROCm as BASELINE.json's
+north_star prescribes ("Host code stays Python on PyTorch-ROCm for the DataLoader, optimizer step
+and loss reductions").  Same call signature and numerics as the reference's
+`Depth_estimation/Metrics/losses.py` (scale-and-shift-invariant depth loss, :120-146): per-image
+closed-form 2x2 least squares for (scale, shift) on the valid pixels (:5-25), masked MSE / (2M)
+(:51-57) and alpha x a 4-scale masked gradient L1 (:60-77, :104-117), batch-based reduction
+(:28-38).  Written without the reference's data-dependent `nonzero()` indexing, so a step has no
+device -> host synchronisation; results are identical (images with a singular system get
+scale = shift = 0, an empty mask contributes 0).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+
+def compute_scale_and_shift(prediction, target, mask):
+    mask = mask.to(prediction.dtype)
+    a_00 = torch.sum(mask * prediction * prediction, (1, 2))
+    a_01 = torch.sum(mask * prediction, (1, 2))
+    a_11 = torch.sum(mask, (1, 2))
+    b_0 = torch.sum(mask * prediction * target, (1, 2))
+    b_1 = torch.sum(mask * target, (1, 2))
+    det = a_00 * a_11 - a_01 * a_01
+    ok = det != 0
+    safe = torch.where(ok, det, torch.ones_like(det))
+    x_0 = torch.where(ok, (a_11 * b_0 - a_01 * b_1) / safe, torch.zeros_like(det))
+    x_1 = torch.where(ok, (-a_01 * b_0 + a_00 * b_1) / safe, torch.zeros_like(det))
+    return x_0, x_1
+
+
+def _batch_based(image_loss, M):
+    divisor = torch.sum(M)
+    total = torch.sum(image_loss)
+    return torch.where(divisor == 0, torch.zeros_like(total), total / torch.clamp(divisor, min=1e-30))
+
+
+def mse_loss(prediction, target, mask):
+    mask = mask.to(prediction.dtype)
+    M = torch.sum(mask, (1, 2))
+    res = prediction - target
+    return _batch_based(torch.sum(mask * res * res, (1, 2)), 2 * M)
+
+
+def gradient_loss(prediction, target, mask):
+    mask = mask.to(prediction.dtype)
+    M = torch.sum(mask, (1, 2))
+    diff = mask * (prediction - target)
+    grad_x = torch.abs(diff[:, :, 1:] - diff[:, :, :-1]) * (mask[:, :, 1:] * mask[:, :, :-1])
+    grad_y = torch.abs(diff[:, 1:, :] - diff[:, :-1, :]) * (mask[:, 1:, :] * mask[:, :-1, :])
+    return _batch_based(torch.sum(grad_x, (1, 2)) + torch.sum(grad_y, (1, 2)), M)
+
+
+class ScaleAndShiftInvariantLoss(nn.Module):
+    def __init__(self, alpha=0.5, scales=4, reduction="batch-based"):
+        super().__init__()
+        if reduction != "batch-based":
+            raise NotImplementedError("the reference trains with the batch-based reduction only")
+        self.alpha = alpha
+        self.scales = scales
+        self.prediction_ssi = None
+
+    def forward(self, prediction, target):
+        prediction = prediction.squeeze(1).float()
+        target = target.squeeze(1).float()
+        mask = target > 0
+        scale, shift = compute_scale_and_shift(prediction, target, mask)
+        ssi = scale.view(-1, 1, 1) * prediction + shift.view(-1, 1, 1)
+        self.prediction_ssi = ssi
+        total = mse_loss(ssi, target, mask)
+        if self.alpha > 0:
+            reg = 0
+            for s in range(self.scales):
+                step = 2 ** s
+                reg = reg + gradient_loss(ssi[:, ::step, ::step], target[:, ::step, ::step],
+                                          mask[:, ::step, ::step])
+            total = total + self.alpha * reg
+        return total

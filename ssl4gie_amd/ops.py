@@ -393,3 +393,132 @@ def mae_loss_bwd(pred, img, mask, p, norm_pix, gpp, gscale_host=1.0):
                                             ptr(gpp), float(gscale_host), int(norm_pix), has_cls,
                                             B, Cc, H, W, p, stream()), "mae_loss(bwd)")
     return dpred
+
+
+# ------------------------------------------------------------------ DPT decoder glue (channels-last)
+def _nhwc(x):
+    _dev(x)
+    assert x.dim() == 4, "expected [B, H, W, C]"
+    return x.shape
+
+
+def conv_out_hw(H, W, stride):
+    return (H - 1) // stride + 1, (W - 1) // stride + 1
+
+
+def k_pad(k, dtype):
+    """row stride of a patch matrix: the bf16 MFMA GEMM wants whole 64-deep K-tiles"""
+    return (k + 63) // 64 * 64 if dtype == torch.bfloat16 else k
+
+
+def im2col3x3(x, stride=1, relu=False, ld=None):
+    B, H, W, C = _nhwc(x)
+    Ho, Wo = conv_out_hw(H, W, stride)
+    ld = ld or k_pad(9 * C, x.dtype)
+    cols = torch.empty(B * Ho * Wo, ld, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().ssl4gie_im2col3x3(ptr(x), ptr(cols), code(x.dtype), B, H, W, C, stride,
+                                             int(relu), ld, stream()), "im2col3x3")
+    return cols
+
+
+def col2im3x3(dcols, B, H, W, C, stride):
+    _dev(dcols)
+    dx = torch.empty(B, H, W, C, dtype=dcols.dtype, device=dcols.device)
+    _lib.check(_lib.load().ssl4gie_col2im3x3(ptr(dcols), ptr(dx), code(dcols.dtype), B, H, W, C,
+                                             stride, dcols.shape[1], stream()), "col2im3x3")
+    return dx
+
+
+def bilinear2x_fwd(x):
+    B, H, W, C = _nhwc(x)
+    y = torch.empty(B, 2 * H, 2 * W, C, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().ssl4gie_bilinear2x_fwd(ptr(x), ptr(y), code(x.dtype), B, H, W, C,
+                                                  stream()), "bilinear2x_fwd")
+    return y
+
+
+def bilinear2x_bwd(dy):
+    B, Ho, Wo, C = _nhwc(dy)
+    dx = torch.empty(B, Ho // 2, Wo // 2, C, dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().ssl4gie_bilinear2x_bwd(ptr(dy), ptr(dx), code(dy.dtype), B, Ho // 2,
+                                                  Wo // 2, C, stream()), "bilinear2x_bwd")
+    return dx
+
+
+def pixel_shuffle(g, bias, B, H, W, k, C):
+    _dev(g, bias)
+    assert g.shape == (B * H * W, k * k * C)
+    y = torch.empty(B, k * H, k * W, C, dtype=g.dtype, device=g.device)
+    _lib.check(_lib.load().ssl4gie_pixel_shuffle(ptr(g), ptr(bias), ptr(y), code(g.dtype), B, H, W,
+                                                 k, C, stream()), "pixel_shuffle")
+    return y
+
+
+def pixel_unshuffle(dy, k):
+    B, Ho, Wo, C = _nhwc(dy)
+    H, W = Ho // k, Wo // k
+    dg = torch.empty(B * H * W, k * k * C, dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().ssl4gie_pixel_unshuffle(ptr(dy), ptr(dg), code(dy.dtype), B, H, W, k, C,
+                                                   stream()), "pixel_unshuffle")
+    return dg
+
+
+def tokens_to_map(z, dtype):
+    _dev(z)
+    _f32(z)
+    B, L1, D = z.shape
+    x = torch.empty(B * (L1 - 1), D, dtype=dtype, device=z.device)
+    _lib.check(_lib.load().ssl4gie_tokens_to_map(ptr(z), ptr(x), code(dtype), B, L1 - 1, D, stream()),
+               "tokens_to_map")
+    return x
+
+
+def map_to_tokens(dx, B, L, D):
+    _dev(dx)
+    dz = torch.empty(B, L + 1, D, dtype=torch.float32, device=dx.device)
+    _lib.check(_lib.load().ssl4gie_map_to_tokens(ptr(dx), ptr(dz), code(dx.dtype), B, L, D, stream()),
+               "map_to_tokens")
+    return dz
+
+
+def eltwise_add(a, b):
+    _dev(a, b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().ssl4gie_eltwise(0, ptr(a), ptr(b), None, ptr(out), code(a.dtype), a.numel(),
+                                           stream()), "eltwise add")
+    return out
+
+
+def relu_bwd(x, g, skip=None):
+    """(x > 0 ? g : 0) + skip"""
+    _dev(x, g, skip)
+    assert x.shape == g.shape and x.dtype == g.dtype
+    out = torch.empty_like(g)
+    _lib.check(_lib.load().ssl4gie_eltwise(1, ptr(x), ptr(g), ptr(skip), ptr(out), code(g.dtype),
+                                           g.numel(), stream()), "relu_bwd")
+    return out
+
+
+def depth_head_fwd(x2d, w, bias):
+    _dev(x2d, w, bias)
+    _f32(w, bias)
+    M, C = x2d.shape
+    y = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    _lib.check(_lib.load().ssl4gie_depth_head_fwd(ptr(x2d), ptr(w), ptr(bias), ptr(y), code(x2d.dtype),
+                                                  M, C, stream()), "depth_head_fwd")
+    return y
+
+
+def depth_head_bwd(x2d, w, y, dy, dw, db, accumulate):
+    _dev(x2d, w, y, dy, dw, db)
+    _f32(w, y, dy, dw, db)
+    M, C = x2d.shape
+    L = _lib.load()
+    ws = torch.empty(L.ssl4gie_depth_head_bwd_workspace_bytes(M, C), dtype=torch.uint8,
+                     device=x2d.device)
+    dx = torch.empty_like(x2d)
+    _lib.check(L.ssl4gie_depth_head_bwd(ptr(x2d), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dw), ptr(db),
+                                        int(accumulate), ptr(ws), code(x2d.dtype), M, C, stream()),
+               "depth_head_bwd")
+    return dx

@@ -18,6 +18,8 @@ Fixtures written:
   g5_curve_tiny.npz   100-step AdamW loss curve, tiny config (B=8)
   g5_curve_vitb.npz   100-step AdamW loss curve, ViT-B (B=8)  [slow; --skip-curve]
   g_lr_sched.npz      per-iteration warm-up+cosine LR (mae/util/lr_sched.py:9-21)
+  g6_dpt_depth.npz    reference DPT_decoder("depth") fwd + SSI loss + grads on seeded taps, B=2
+  g7_ssi_loss.npz     reference ScaleAndShiftInvariantLoss(alpha=0.1) value + gradient
 """
 from __future__ import annotations
 
@@ -230,6 +232,79 @@ def g_lr_sched():
     print("lr_sched ok")
 
 
+def _load_by_path(name, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def dpt_inputs(seed, b=2):
+    g = torch.Generator("cpu").manual_seed(seed)
+    acts = [torch.randn(b, 197, 768, generator=g) for _ in range(4)]
+    target = torch.rand(b, 1, 224, 224, generator=g)
+    target = torch.where(torch.rand(b, 1, 224, 224, generator=g) < 0.1, torch.zeros(()), target)
+    return acts, target
+
+
+def g6_dpt():
+    """the reference's DPT_decoder (pure torch, imported as is) + its SSI loss, fwd and bwd"""
+    from oracle import dpt_ref
+    ref_dpt = _load_by_path("ref_dpt", os.path.join(REF, "Models", "DPT_decoder.py"))
+    ref_loss = _load_by_path("ref_losses", os.path.join(REF, "Depth_estimation", "Metrics", "losses.py"))
+    sd = dpt_ref.dpt_state_dict(seed=3)
+    m = ref_dpt.DPT_decoder(num_classes=1, dense="depth")
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dpt_ref.dpt_param_shapes()
+    m.load_state_dict(sd, strict=True)
+    acts, target = dpt_inputs(11)
+    acts = [a.requires_grad_(True) for a in acts]
+    skips = m.forward_skip([a for a in acts])
+    out = m(acts)
+    loss = ref_loss.ScaleAndShiftInvariantLoss(alpha=0.1)(out, target)
+    loss.backward()
+    # the oracle must agree with the reference before anything is written
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    acts_o = [a.detach().clone().requires_grad_(True) for a in acts]
+    out_o, mid = dpt_ref.dpt_forward(sdo, acts_o, return_all=True)
+    loss_o = dpt_ref.ssi_loss(out_o, target, alpha=0.1)
+    loss_o.backward()
+    np.testing.assert_allclose(out_o.detach().numpy(), out.detach().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(loss_o), float(loss), rtol=1e-5)
+    np.testing.assert_allclose(mid["layer_4"].detach().numpy(), skips[3].detach().numpy(), rtol=1e-4, atol=1e-5)
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    missing = sorted(k for k, p in m.named_parameters() if p.grad is None)
+    out_d = {"out": out.detach().numpy(), "loss": np.array(float(loss)),
+             "layer_4": skips[3].detach().numpy(), "layer_1_slice": skips[0].detach().numpy()[:, :8, :8, :8],
+             "no_grad_params": np.array(missing), "seed_weights": np.array(3), "seed_inputs": np.array(11),
+             "grad_names": np.array(sorted(grads)),
+             "grad_norms": np.array([float(grads[k].norm()) for k in sorted(grads)], dtype=np.float64)}
+    for k, g in grads.items():
+        if g.numel() <= 4096:
+            out_d[f"grad/{k}"] = g.numpy()
+        else:
+            out_d[f"gslice/{k}"] = g.reshape(g.shape[0], -1)[:8, :64].numpy()
+    for i, a in enumerate(acts):
+        out_d[f"act_grad_norm/{i}"] = np.array(float(a.grad.norm()))
+        out_d[f"act_grad_slice/{i}"] = a.grad[:, :4, :64].numpy()
+    np.savez_compressed(os.path.join(HERE, "g6_dpt_depth.npz"), **out_d)
+    print(f"g6 dpt: loss={float(loss):.6f} out mean={float(out.mean()):.4f}; params without grad: {missing}")
+
+
+def g7_ssi():
+    ref_loss = _load_by_path("ref_losses", os.path.join(REF, "Depth_estimation", "Metrics", "losses.py"))
+    g = torch.Generator("cpu").manual_seed(5)
+    pred = torch.rand(3, 1, 64, 64, generator=g).requires_grad_(True)
+    target = torch.rand(3, 1, 64, 64, generator=g)
+    target = torch.where(torch.rand(3, 1, 64, 64, generator=g) < 0.2, torch.zeros(()), target)
+    target[2] = 0  # an image without valid pixels (empty mask, singular system)
+    loss = ref_loss.ScaleAndShiftInvariantLoss(alpha=0.1)(pred, target)
+    loss.backward()
+    np.savez_compressed(os.path.join(HERE, "g7_ssi_loss.npz"), pred=pred.detach().numpy(),
+                        target=target.numpy(), loss=np.array(float(loss)), grad=pred.grad.numpy())
+    print(f"g7 ssi: loss={float(loss):.6f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-curve", action="store_true")
@@ -241,7 +316,7 @@ def main():
     jobs = {
         "g1": lambda: g1_masking(ref_mae), "g2": lambda: g2_patchify(ref_mae), "g3": g3_sincos,
         "g5tiny": lambda: g5_tiny(ref_mae), "g5vitb": lambda: g5_vitb(ref_mae),
-        "lr": g_lr_sched,
+        "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi,
         "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
             **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
             "g5_curve_tiny.npz"),
