@@ -79,6 +79,72 @@ def cpu_baseline(steps=8, warmup=2, b=8):
                       f"CPU oracle (oracle/mae_ref.py), {warmup} warm-up steps"}
 
 
+def bench_depth(a):
+    """configs[3]: ViT_from_MAE(dense="depth") + SSI loss + AdamW(1e-4) (train_depth.py:22-78,230,280)
+    on synthetic img [B,3,224,224] N(0,1) and depth targets U(0,1) with 10 % zeros."""
+    import torch.distributed as dist
+    from ssl4gie_amd import _lib, parallel
+    from ssl4gie_amd.Models import models
+    from ssl4gie_amd.losses import ScaleAndShiftInvariantLoss
+    _lib.load()
+    rank, local, world = parallel.init_from_env()
+    assert world == a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = a.batch if a.batch != 256 else 128
+    torch.manual_seed(0)
+    model = models.ViT_from_MAE(None, False, 1, False, "depth", False, None, 768, 12, 12, "cls")
+    model.to(dev).set_precision(a.precision)
+    ddp = parallel.DataParallel(model) if world > 1 else None
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
+    loss_fn = ScaleAndShiftInvariantLoss(alpha=0.1)
+    g = torch.Generator("cpu").manual_seed(rank)
+    imgs = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    tgt = torch.rand(B, 1, 224, 224, generator=g)
+    tgt = torch.where(torch.rand(B, 1, 224, 224, generator=g) < 0.1, torch.zeros(()), tgt).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn((ddp or model)(imgs), tgt)
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        ips = B * world * a.steps / dt
+        print(json.dumps({
+            "metric": "images/sec (fwd+bwd+AdamW) ViT-B + DPT depth finetune 224x224 (BASELINE.json configs[3])",
+            "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "ViT_from_MAE(dense='depth') + DPT_decoder + SSI loss(alpha=0.1) + "
+                                   "AdamW(1e-4), synthetic img + depth resident in HBM",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "model_mfma_frac": round(ips / world * 214.86 / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(float(loss.detach()), 5)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,7 +154,12 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--workload", default="mae", choices=["mae", "depth"],
+                    help="mae = BASELINE.json configs[1] (the headline metric); depth = configs[3] "
+                         "(ViT-B + DPT depth finetune step, bs 128/GPU) as an extra measurement")
     a = ap.parse_args()
+    if a.workload == "depth":
+        return bench_depth(a)
 
     import torch.distributed as dist
     from ssl4gie_amd import _lib, parallel
