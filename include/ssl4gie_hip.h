@@ -246,6 +246,42 @@ int ssl4gie_depth_head_bwd(const void* x, const float* w, const float* y, const 
                            float* dw, float* db, int accumulate, float* workspace, int dtype,
                            long long M, int C, void* stream);
 
+/* ---------------------------------------------------------------- ResNet50 glue (channels-last)
+ * Replaces the torch ops around the convolutions of torchvision ResNet(Bottleneck,[3,4,6,3]) as the
+ * reference builds it (Models/models.py:63-152; MoCo: Models/moco_v3/main_moco.py:185-187).  1x1
+ * convolutions are token-major ssl4gie_gemm calls, 3x3 ones go through ssl4gie_im2col3x3.
+ * stem_im2col7x7: fp32 NCHW image -> conv1 (7x7, s2, p3) patch matrix [B*Ho*Wo, ld], K = 147
+ *   ordered (dy, dx, c), columns [147, ld) zero.
+ * subsample2: rows of a stride-2 1x1 convolution (downsample.0); backward = 1 scatters zeros. */
+int ssl4gie_stem_im2col7x7(const float* img, void* cols, int dtype, int B, int H, int W,
+                           long long ld, void* stream);
+int ssl4gie_subsample2(const void* x, void* y, int dtype, int B, int H, int W, int C, int backward,
+                       void* stream);
+/* BatchNorm2d / BatchNorm1d in training mode over the rows of x [rows, C] (C % 8 == 0): batch
+ * statistics in fp32 (biased variance for the normalisation, unbiased for running_var, momentum as
+ * nn.BatchNorm: running = (1-m) running + m batch), y = act(xhat gamma + beta (+ res)) with
+ * act = ReLU if `relu`; gamma / beta / res / running_* may be NULL.  mean / rstd [C] are outputs
+ * kept for backward (with training == 0 they are INPUTS: the caller's running statistics, no
+ * reduction runs).  Backward: g = relu ? (y > 0 ? dy : 0) : dy; dgamma = sum g xhat, dbeta = sum g,
+ * dx = gamma rstd (g - mean(g) - xhat mean(g xhat)); dres (optional) = g. */
+size_t ssl4gie_bn_workspace_bytes(long long rows, int C);
+int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y,
+                   float* mean, float* rstd, float* running_mean, float* running_var,
+                   float momentum, float eps, int relu, int training, float* workspace, int dtype,
+                   long long rows, int C, void* stream);
+int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, const float* gamma,
+                   const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
+                   float* dbeta, int accumulate, int relu, float* workspace, int dtype,
+                   long long rows, int C, void* stream);
+/* MaxPool2d(3, stride 2, pad 1) with the argmax window position saved (first maximum in row-major
+ * scan order); backward in gather form.  Global average pool -> fp32 [B, C] and its gradient. */
+int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* arg, int dtype, int B, int H,
+                             int W, int C, void* stream);
+int ssl4gie_maxpool3x3s2_bwd(const void* dy, const unsigned char* arg, void* dx, int dtype, int B,
+                             int H, int W, int C, void* stream);
+int ssl4gie_avgpool_fwd(const void* x, float* y, int dtype, int B, int HW, int C, void* stream);
+int ssl4gie_avgpool_bwd(const float* dy, void* dx, int dtype, int B, int HW, int C, void* stream);
+
 /* ---------------------------------------------------------------- launch profiler (bench.py)
  * HIP events on the launch stream around every launch of the heavy kernels, used for the
  * `roofline` object of the bench line.  Process-global, not thread-safe, off by default.

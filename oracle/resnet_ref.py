@@ -1,0 +1,47 @@
+"""CPU oracle: functional fp32 restatement of torchvision 0.10 ResNet50 (Bottleneck v1.5) in
+training mode.  TEST INFRASTRUCTURE.
+
+torchvision is pinned by the reference (`requirements.txt:10`; call sites `Models/models.py:3,63-75`,
+`Models/moco_v3/main_moco.py:30,185-187`) but is neither under /root/reference nor installed in this
+image, and the reference holds no tests or fixtures for this path: **parity unpinned** — the
+restatement follows torchvision's published `resnet.py` (conv1 7x7/2 -> bn1 -> relu -> maxpool 3x3/2
+-> layer1..4 of Bottleneck{conv1 1x1, bn1, relu, conv2 3x3 (stride), bn2, relu, conv3 1x1, bn3,
+(+ downsample = conv1x1(stride) + bn), relu} -> avgpool) on a state_dict with torchvision's key
+names, and is anchored only by torch op semantics (F.conv2d / F.batch_norm / F.max_pool2d).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
+
+
+def _bn(sd, p, x, eps=1e-5):
+    return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, eps)
+
+
+def bottleneck(sd, p, x, stride, has_down):
+    out = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
+    out = F.relu(_bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], stride=stride, padding=1)))
+    out = _bn(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]))
+    idn = x
+    if has_down:
+        idn = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride))
+    return F.relu(out + idn)
+
+
+def resnet50_features(sd, imgs):
+    x = F.conv2d(imgs, sd["conv1.weight"], stride=2, padding=3)
+    x = F.relu(_bn(sd, "bn1", x))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, (planes, blocks, stride) in enumerate(LAYERS, start=1):
+        for j in range(blocks):
+            x = bottleneck(sd, f"layer{li}.{j}", x, stride if j == 0 else 1, j == 0)
+    return x
+
+
+def resnet50_pooled(sd, imgs):
+    return resnet50_features(sd, imgs).mean((2, 3))

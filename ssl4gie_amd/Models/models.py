@@ -25,8 +25,9 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from ..engine import EngineModule, PatchEmbedFn
+from ..engine import EngineModule, LinearFn, PatchEmbedFn
 from .DPT_decoder import DPT_decoder
+from .resnet import ResNet50
 from .mae.util.pos_embed import get_2d_sincos_pos_embed
 from .vit_layers import Block, PatchEmbed
 
@@ -200,3 +201,41 @@ def moco_sincos_pos_embed(embed_dim, grid_size, temperature=10000.):
     oh = gh.flatten()[:, None] * omega[None]
     emb = torch.cat([ow.sin(), ow.cos(), oh.sin(), oh.cos()], dim=1)[None]
     return torch.cat([torch.zeros(1, 1, embed_dim), emb], dim=1)
+
+
+class ResNet_from_Any(ResNet50):
+    """Reference `Models/models.py:63-152`: torchvision ResNet50 with `fc = Identity` (no `fc.*` keys:
+    the reference assigns Identity before its strict load, :77-80), optional linear head.  The dense
+    decoder of the ResNet path (`ResNet_Dec_Level`, :16-60, :88-135) is a later SURVEY §8(f) row."""
+
+    def __init__(self, weight_path, head, num_classes, frozen, dense, ImageNet_weights=False):
+        super().__init__()
+        if ImageNet_weights:
+            raise RuntimeError("ImageNet weights are downloaded by the reference (models.py:70-75); no "
+                               "network here — load a state_dict instead")
+        if dense:
+            raise NotImplementedError("the ResNet dense decoder (reference models.py:88-135) is a later "
+                                      "§8(f) row of this build")
+        self.fc = nn.Identity()
+        if weight_path is not None:
+            self.load_state_dict(torch.load(weight_path, map_location="cpu"))
+        self.head = head
+        if head:
+            self.lin_head = nn.Linear(2048, num_classes)
+        self.frozen = frozen
+        self.dense = dense
+
+    def forward_features(self, x):
+        return self.forward_maps(x)
+
+    def forward(self, imgs):
+        if self.frozen:
+            with torch.no_grad():
+                x = self.pooled(imgs)
+        else:
+            x = self.pooled(imgs)
+        if self.head:
+            x = LinearFn.apply(x.to(self.dtype_).contiguous(), self.lin_head.weight,
+                               self.lin_head.bias, self.dtype_, torch.float32, self.sink(),
+                               self.lp_cache)
+        return x

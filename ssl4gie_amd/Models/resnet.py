@@ -1,0 +1,112 @@
+"""ResNet50 trunk on the MI355X engine with torchvision's module tree / state_dict names
+(`conv1.weight, bn1.{weight,bias,running_mean,running_var,num_batches_tracked},
+layer{1-4}.{j}.{conv1,bn1,conv2,bn2,conv3,bn3}.*, layer{k}.0.downsample.{0,1}.*`).
+
+torchvision 0.10 is pinned by the reference (`requirements.txt:10`) but neither vendored nor
+installed, so this restates `ResNet(Bottleneck, [3, 4, 6, 3])` (v1.5: the stride sits on the 3x3
+convolution; kaiming-normal fan_out init; BN weight 1 / bias 0; `zero_init_residual` zeroes every
+bn3.weight — used by MoCo, Models/moco_v3/main_moco.py:186).  The nn.Conv2d / nn.BatchNorm2d
+children only hold parameters and buffers; the arithmetic runs on libssl4gie_hip.so
+(`ssl4gie_amd.resnet_engine`), channels-last.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ..dpt_engine import Conv3x3Fn
+from ..engine import EngineModule, LinearFn
+from ..resnet_engine import AvgPoolFn, BatchNormFn, MaxPoolFn, StemConvFn, Subsample2Fn
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet50(EngineModule):
+    """trunk only: `forward_features` -> channels-last layer4 map (or the 4 stage maps)"""
+
+    def __init__(self, zero_init_residual=False):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(64, 3)
+        self.layer2 = self._make_layer(128, 4, stride=2)
+        self.layer3 = self._make_layer(256, 6, stride=2)
+        self.layer4 = self._make_layer(512, 3, stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    # ------------------------------------------------------------------ engine forward
+    def _bn(self, x, bn, relu, res=None):
+        return BatchNormFn.apply(x, bn.weight, bn.bias, res, bn, relu, self.sink())
+
+    def _c1(self, x, conv):
+        if conv.stride[0] == 2:
+            x = Subsample2Fn.apply(x)
+        B, H, W, C = x.shape
+        y = LinearFn.apply(x.reshape(-1, C), conv.weight, None, self.dtype_, self.dtype_, self.sink(),
+                           self.lp_cache)
+        return y.view(B, H, W, -1)
+
+    def _block(self, x, blk: Bottleneck):
+        out = self._bn(self._c1(x, blk.conv1), blk.bn1, True)
+        out = Conv3x3Fn.apply(out, blk.conv2.weight, None, blk.conv2.stride[0], False, self.sink(),
+                              self.lp_cache)
+        out = self._bn(out, blk.bn2, True)
+        out = self._c1(out, blk.conv3)
+        identity = x
+        if blk.downsample is not None:
+            identity = self._bn(self._c1(x, blk.downsample[0]), blk.downsample[1], False)
+        return self._bn(out, blk.bn3, True, res=identity)  # relu(bn3(out) + identity)
+
+    def forward_maps(self, imgs, all_stages=False):
+        self._prepare()
+        x = StemConvFn.apply(imgs, self.conv1.weight, self.dtype_, self.sink(), self.lp_cache)
+        x = self._bn(x, self.bn1, True)
+        x = MaxPoolFn.apply(x)
+        maps = []
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                x = self._block(x, blk)
+            maps.append(x)
+        return maps if all_stages else x
+
+    def pooled(self, imgs):
+        """[B, 2048] fp32: avgpool + flatten of the layer4 map"""
+        return AvgPoolFn.apply(self.forward_maps(imgs))

@@ -90,6 +90,15 @@ PROTOTYPES = {
     "ssl4gie_depth_head_fwd": (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
     "ssl4gie_depth_head_bwd_workspace_bytes": (sz, [i64, i32]),
     "ssl4gie_depth_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
+    "ssl4gie_stem_im2col7x7": (i32, [vp, vp, i32, i32, i32, i32, i64, vp]),
+    "ssl4gie_subsample2": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_bn_workspace_bytes": (sz, [i64, i32]),
+    "ssl4gie_bn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, i64, i32, vp]),
+    "ssl4gie_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, i64, i32, vp]),
+    "ssl4gie_maxpool3x3s2_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_avgpool_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ssl4gie_prof_begin": (i32, [i32]),
     "ssl4gie_prof_collect": (i32, [vp, vp, vp]),
     "ssl4gie_prof_end": (i32, []),

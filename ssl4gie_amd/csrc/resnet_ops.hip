@@ -1,0 +1,471 @@
+// ResNet50 glue for gfx950: everything around the convolution GEMMs of
+// torchvision's ResNet(Bottleneck, [3, 4, 6, 3]) as the reference uses it (Models/models.py:63-152,
+// Models/moco_v3/main_moco.py:185-187).  Maps are channels-last [B, H, W, C] in the operand type, so
+// a 1x1 convolution is a token-major GEMM and BatchNorm2d statistics are column sums over M = B*H*W
+// rows.  All HBM-bound: 16-byte accesses, two-stage deterministic reductions (no atomics).
+//
+//   stem_im2col7x7   fp32 NCHW image -> patch matrix of conv1 (7x7, stride 2, pad 3), K = 147 (+pad)
+//   subsample2       rows of a stride-2 1x1 convolution (downsample.0) and its gradient
+//   bn_stats         per-channel sum / sum of squares partials  (+ finalize: mean, rstd)
+//   bn_apply         y = act((x - mean) rstd gamma + beta (+ residual))     act = ReLU | id
+//   bn_bwd_reduce    partials of sum(dy) and sum(dy * xhat) over the rows (dy already ReLU-masked)
+//   bn_bwd_apply     dx = gamma rstd (g - mean(g) - xhat mean(g xhat)); optional dres = g
+//   maxpool3x3s2     forward with argmax byte, backward in gather form
+//   avgpool          global average per image and its gradient
+#include "common.h"
+#include "ssl4gie_hip.h"
+#include "internal.h"
+
+namespace {
+template <typename T> struct V16;
+template <> struct V16<bf16_t> { static constexpr int N = 8; typedef u32x4 raw; };
+template <> struct V16<float> { static constexpr int N = 4; typedef f32x4 raw; };
+template <typename T> DEVI void un(const typename V16<T>::raw& r, float (&f)[V16<T>::N]);
+template <> DEVI void un<bf16_t>(const u32x4& r, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = __uint_as_float(r[j] << 16);
+        f[2 * j + 1] = __uint_as_float(r[j] & 0xffff0000u);
+    }
+}
+template <> DEVI void un<float>(const f32x4& r, float (&f)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = r[j];
+}
+template <typename T> DEVI typename V16<T>::raw pk(const float (&f)[V16<T>::N]);
+template <> DEVI u32x4 pk<bf16_t>(const float (&f)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = pack_bf2(f[2 * j], f[2 * j + 1]);
+    return r;
+}
+template <> DEVI f32x4 pk<float>(const float (&f)[4]) { return f32x4{f[0], f[1], f[2], f[3]}; }
+}  // namespace
+
+#define RN_GRID(total) dim3((unsigned)(((total) + 255) / 256)), dim3(256)
+#define RN_LAUNCH(dtype, KERNEL, total, ...)                                                       \
+    do {                                                                                           \
+        if ((dtype) == SSL4GIE_BF16) {                                                             \
+            typedef bf16_t T;                                                                      \
+            hipLaunchKernelGGL(KERNEL<T>, RN_GRID(total), 0, st, __VA_ARGS__);                     \
+        } else {                                                                                   \
+            typedef float T;                                                                       \
+            hipLaunchKernelGGL(KERNEL<T>, RN_GRID(total), 0, st, __VA_ARGS__);                     \
+        }                                                                                          \
+        LAUNCH_CHECK();                                                                            \
+    } while (0)
+
+// ------------------------------------------------------------------ stem patch matrix
+// cols[(b, oy, ox), (dy*7 + dx)*3 + c] = img[b, c, 2 oy + dy - 3, 2 ox + dx - 3]; [147, ld) zero
+template <typename T>
+__global__ void stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H,
+                                   int W, int Ho, int Wo, long long ld, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long m = idx / ld;
+    const int col = (int)(idx % ld);
+    float v = 0.f;
+    if (col < 147) {
+        const int tap = col / 3, c = col % 3, dy = tap / 7, dx = tap % 7;
+        const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((long long)Wo * Ho));
+        const int iy = 2 * oy + dy - 3, ix = 2 * ox + dx - 3;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((size_t)b * 3 + c) * H + iy) * W + ix];
+    }
+    Elem<T>::st(cols + idx, v);
+}
+
+// ------------------------------------------------------------------ stride-2 row subsampling
+template <typename T>
+__global__ void subsample2_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C,
+                                  int Ho, int Wo, long long total) {
+    constexpr int V = V16<T>::N;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cpr = C / V;
+    const long long p = idx / cpr;
+    const int c = (int)(idx % cpr) * V;
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
+    const long long b = p / ((long long)Wo * Ho);
+    *(typename V16<T>::raw*)(y + (size_t)p * C + c) =
+        *(const typename V16<T>::raw*)(x + ((b * H + 2 * oy) * W + 2 * ox) * C + c);
+}
+template <typename T>
+__global__ void subsample2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W,
+                                      int C, int Ho, int Wo, long long total) {
+    constexpr int V = V16<T>::N;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cpr = C / V;
+    const long long p = idx / cpr;
+    const int c = (int)(idx % cpr) * V;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const long long b = p / ((long long)W * H);
+    typename V16<T>::raw v = {};
+    if (!(x & 1) && !(y & 1))
+        v = *(const typename V16<T>::raw*)(dy + ((b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c);
+    *(typename V16<T>::raw*)(dx + (size_t)p * C + c) = v;
+}
+
+// ------------------------------------------------------------------ BatchNorm (training mode)
+// partial[blockIdx.y][0][c] = sum_r x[r, c], partial[..][1][c] = sum_r x^2 over this block's rows
+// (sums are taken about the pivot x[0, c] — written to `pivot` — so that E[d^2] - E[d]^2 does not
+// cancel catastrophically when |mean| >> std)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x,
+                                                       float* __restrict__ partial,
+                                                       float* __restrict__ pivot, long long rows,
+                                                       int C) {
+    __shared__ f32x4 red[3][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    if (c < C) {
+        const f32x4 piv = ld4(x + c);
+        if (blockIdx.y == 0 && wave == 0) st4(pivot + c, piv);
+        for (long long r = (long long)blockIdx.y * 4 + wave; r < rows; r += (long long)gridDim.y * 4) {
+            const f32x4 v = ld4(x + (size_t)r * C + c) - piv;
+            s += v;
+            q += v * v;
+        }
+    }
+    if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
+        float* p = partial + (size_t)blockIdx.y * 2 * C;
+        st4(p + c, s);
+        st4(p + C + c, q);
+    }
+}
+// sums [2][C] -> mean, rstd (biased variance, as F.batch_norm normalises with), and the running
+// statistics update of nn.BatchNorm2d (momentum, unbiased variance) when running_* are given
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ pivot,
+                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float count, float eps, float momentum, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float d = sums[c] / count;
+    float var = sums[C + c] / count - d * d;
+    var = var > 0.f ? var : 0.f;
+    const float m = pivot[c] + d;
+    mean[c] = m;
+    rstd[c] = rsqrtf(var + eps);
+    if (running_mean) {
+        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+// y = act(xhat gamma + beta (+ res))
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const T* __restrict__ res,
+                                T* __restrict__ y, int relu, int C, long long total) {
+    constexpr int V = V16<T>::N;
+    const long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    float f[V], r[V];
+    un<T>(*(const typename V16<T>::raw*)(x + idx), f);
+    if (res) un<T>(*(const typename V16<T>::raw*)(res + idx), r);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        float v = (f[j] - mean[c + j]) * rstd[c + j] * (gamma ? gamma[c + j] : 1.f) +
+                  (beta ? beta[c + j] : 0.f);
+        if (res) v += r[j];
+        f[j] = (relu && v < 0.f) ? 0.f : v;
+    }
+    *(typename V16<T>::raw*)(y + idx) = pk<T>(f);
+}
+// g = relu ? (y > 0 ? dy : 0) : dy;  partial[blk][0][c] = sum g, [1][c] = sum g * xhat; when the block
+// had a residual input its gradient is g itself (dres, optional)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dres,
+    float* __restrict__ partial, int relu, long long rows, int C) {
+    __shared__ f32x4 red[3][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    if (c < C) {
+        const f32x4 mu = ld4(mean + c), rs = ld4(rstd + c);
+        for (long long r = (long long)blockIdx.y * 4 + wave; r < rows; r += (long long)gridDim.y * 4) {
+            const size_t o = (size_t)r * C + c;
+            f32x4 g = ld4(dy + o);
+            if (relu) {
+                const f32x4 yy = ld4(y + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+            }
+            if (dres) st4(dres + o, g);
+            const f32x4 xh = (ld4(x + o) - mu) * rs;
+            s += g;
+            q += g * xh;
+        }
+    }
+    if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
+        float* p = partial + (size_t)blockIdx.y * 2 * C;
+        st4(p + c, s);
+        st4(p + C + c, q);
+    }
+}
+// dx = gamma rstd (g - sum_g / n - xhat sum_gx / n)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                    const T* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sums, T* __restrict__ dx, int relu,
+                                    float inv_n, int C, long long total) {
+    constexpr int V = V16<T>::N;
+    const long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    float g[V], xv[V], yy[V];
+    un<T>(*(const typename V16<T>::raw*)(dy + idx), g);
+    un<T>(*(const typename V16<T>::raw*)(x + idx), xv);
+    if (relu) un<T>(*(const typename V16<T>::raw*)(y + idx), yy);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const float gg = (relu && !(yy[j] > 0.f)) ? 0.f : g[j];
+        const float xh = (xv[j] - mean[c + j]) * rstd[c + j];
+        const float gm = gamma ? gamma[c + j] : 1.f;
+        g[j] = gm * rstd[c + j] * (gg - sums[c + j] * inv_n - xh * sums[C + c + j] * inv_n);
+    }
+    *(typename V16<T>::raw*)(dx + idx) = pk<T>(g);
+}
+
+// ------------------------------------------------------------------ MaxPool2d(3, 2, 1)
+// arg = window position (dy*3+dx) of the first maximum in row-major scan order (ATen's choice)
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                   unsigned char* __restrict__ arg, int H, int W, int C, int Ho,
+                                   int Wo, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long p = idx / C;
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
+    const long long b = p / ((long long)Wo * Ho);
+    float best = -INFINITY;
+    int bi = 0;
+    bool found = false;
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = 2 * oy + dy - 1;
+        if (iy < 0 || iy >= H) continue;
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = 2 * ox + dx - 1;
+            if (ix < 0 || ix >= W) continue;
+            const float v = Elem<T>::ld(x + ((b * H + iy) * W + ix) * C + c);
+            if (!found || v > best) {  // first maximum in scan order
+                best = v;
+                bi = dy * 3 + dx;
+                found = true;
+            }
+        }
+    }
+    Elem<T>::st(y + idx, best);
+    arg[idx] = (unsigned char)bi;
+}
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                   T* __restrict__ dx, int H, int W, int C, int Ho, int Wo,
+                                   long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long p = idx / C;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const long long b = p / ((long long)W * H);
+    float acc = 0.f;
+    for (int dy_ = 0; dy_ < 3; ++dy_) {
+        const int ny = y + 1 - dy_;
+        if (ny < 0 || (ny & 1)) continue;
+        const int oy = ny >> 1;
+        if (oy >= Ho) continue;
+        for (int dx_ = 0; dx_ < 3; ++dx_) {
+            const int nx = x + 1 - dx_;
+            if (nx < 0 || (nx & 1)) continue;
+            const int ox = nx >> 1;
+            if (ox >= Wo) continue;
+            const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * C + c;
+            if (arg[o] == dy_ * 3 + dx_) acc += Elem<T>::ld(dy + o);
+        }
+    }
+    Elem<T>::st(dx + idx, acc);
+}
+
+// ------------------------------------------------------------------ global average pool
+// y[b, c] = mean over the HW rows of image b (fp32 out); one block per (image, 256-channel strip)
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, int HW, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < HW; ++r) s += Elem<T>::ld(x + ((size_t)b * HW + r) * C + c);
+    y[(size_t)b * C + c] = s / (float)HW;
+}
+template <typename T>
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, T* __restrict__ dx, int HW, int C,
+                                   long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long b = idx / ((long long)HW * C);
+    Elem<T>::st(dx + idx, dy[b * C + c] / (float)HW);
+}
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+static bool rdt(int dt) { return dt == SSL4GIE_F32 || dt == SSL4GIE_BF16; }
+static int rvn(int dt) { return dt == SSL4GIE_BF16 ? 8 : 4; }
+static int bn_parts(long long rows) {
+    long long p = (rows + 255) / 256;
+    return (int)(p < 1 ? 1 : (p > 512 ? 512 : p));
+}
+
+extern "C" int ssl4gie_stem_im2col7x7(const float* img, void* cols, int dtype, int B, int H, int W,
+                                      long long ld, void* stream) {
+    REQUIRE(img && cols && rdt(dtype) && B > 0 && H > 0 && W > 0 && ld >= 147);
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)B * Ho * Wo * ld;
+    RN_LAUNCH(dtype, stem_im2col_kernel, total, img, (T*)cols, B, H, W, Ho, Wo, ld, total);
+    return 0;
+}
+extern "C" int ssl4gie_subsample2(const void* x, void* y, int dtype, int B, int H, int W, int C,
+                                  int backward, void* stream) {
+    REQUIRE(x && y && rdt(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && C % rvn(dtype) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (!backward) {
+        const long long total = (long long)B * Ho * Wo * (C / rvn(dtype));
+        RN_LAUNCH(dtype, subsample2_kernel, total, (const T*)x, (T*)y, H, W, C, Ho, Wo, total);
+    } else {  // x = dy [B, Ho, Wo, C], y = dx [B, H, W, C]
+        const long long total = (long long)B * H * W * (C / rvn(dtype));
+        RN_LAUNCH(dtype, subsample2_bwd_kernel, total, (const T*)x, (T*)y, H, W, C, Ho, Wo, total);
+    }
+    return 0;
+}
+extern "C" size_t ssl4gie_bn_workspace_bytes(long long rows, int C) {
+    return (((size_t)bn_parts(rows) + 1) * 2 + 1) * C * sizeof(float);
+}
+// forward: statistics over the rows of x [rows, C] (biased variance), optional running-stat update,
+// y = act(xhat gamma + beta (+ res)); mean / rstd [C] are kept for backward
+extern "C" int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* beta, const void* res,
+                              void* y, float* mean, float* rstd, float* running_mean,
+                              float* running_var, float momentum, float eps, int relu,
+                              int training, float* workspace, int dtype, long long rows, int C,
+                              void* stream) {
+    REQUIRE(x && y && mean && rstd && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
+    REQUIRE(!training || workspace);
+    hipStream_t st = (hipStream_t)stream;
+    if (!training) {  // evaluation: mean / rstd are INPUTS (running statistics prepared by the caller)
+        const long long total = rows * C;
+        RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, mean, rstd, gamma, beta,
+                  (const T*)res, (T*)y, relu, C, total);
+        return 0;
+    }
+    const int parts = bn_parts(rows);
+    dim3 grid((C + 255) / 256, parts), block(256);
+    float* sums = workspace + (size_t)parts * 2 * C;
+    float* pivot = sums + 2 * C;
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, workspace,
+                           pivot, rows, C);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, block, 0, st, (const float*)x, workspace,
+                           pivot, rows, C);
+    LAUNCH_CHECK();
+    int rc = ssl4gie_internal_reduce_partials(workspace, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, pivot, mean,
+                       rstd, running_mean, running_var, (float)rows, eps, momentum, C);
+    LAUNCH_CHECK();
+    const long long total = rows * C;
+    RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, mean, rstd, gamma, beta,
+              (const T*)res, (T*)y, relu, C, total);
+    return 0;
+}
+// backward: dgamma / dbeta (overwritten or accumulated), dx, and (optional) the residual gradient
+extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, const float* gamma,
+                              const float* mean, const float* rstd, void* dx, void* dres,
+                              float* dgamma, float* dbeta, int accumulate, int relu,
+                              float* workspace, int dtype, long long rows, int C, void* stream) {
+    REQUIRE(dy && x && mean && rstd && dx && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
+    REQUIRE(!relu || y);
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = bn_parts(rows);
+    dim3 grid((C + 255) / 256, parts), block(256);
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy,
+                           (const bf16_t*)y, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, workspace,
+                           relu, rows, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)dy,
+                           (const float*)y, (const float*)x, mean, rstd, (float*)dres, workspace, relu,
+                           rows, C);
+    LAUNCH_CHECK();
+    float* sums = workspace + (size_t)parts * 2 * C;
+    int rc = ssl4gie_internal_reduce_partials(workspace, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+    if (rc) return rc;
+    const long long total = rows * C;
+    RN_LAUNCH(dtype, bn_bwd_apply_kernel, total / rvn(dtype), (const T*)dy, (const T*)y, (const T*)x,
+              mean, rstd, gamma, sums, (T*)dx, relu, 1.0f / (float)rows, C, total);
+    // dbeta = sum g, dgamma = sum g xhat
+    if (dbeta) {
+        rc = ssl4gie_internal_reduce_partials(sums, dbeta, 1, C, (size_t)2 * C, accumulate, st);
+        if (rc) return rc;
+    }
+    if (dgamma) {
+        rc = ssl4gie_internal_reduce_partials(sums + C, dgamma, 1, C, (size_t)2 * C, accumulate, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+extern "C" int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* arg, int dtype, int B,
+                                        int H, int W, int C, void* stream) {
+    REQUIRE(x && y && arg && rdt(dtype) && B > 0 && H > 0 && W > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)B * Ho * Wo * C;
+    RN_LAUNCH(dtype, maxpool_fwd_kernel, total, (const T*)x, (T*)y, arg, H, W, C, Ho, Wo, total);
+    return 0;
+}
+extern "C" int ssl4gie_maxpool3x3s2_bwd(const void* dy, const unsigned char* arg, void* dx, int dtype,
+                                        int B, int H, int W, int C, void* stream) {
+    REQUIRE(dy && dx && arg && rdt(dtype) && B > 0 && H > 0 && W > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)B * H * W * C;
+    RN_LAUNCH(dtype, maxpool_bwd_kernel, total, (const T*)dy, arg, (T*)dx, H, W, C, Ho, Wo, total);
+    return 0;
+}
+extern "C" int ssl4gie_avgpool_fwd(const void* x, float* y, int dtype, int B, int HW, int C,
+                                   void* stream) {
+    REQUIRE(x && y && rdt(dtype) && B > 0 && HW > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((C + 255) / 256, B), block(256);
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, y, HW, C);
+    else
+        hipLaunchKernelGGL(avgpool_fwd_kernel<float>, grid, block, 0, st, (const float*)x, y, HW, C);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ssl4gie_avgpool_bwd(const float* dy, void* dx, int dtype, int B, int HW, int C,
+                                   void* stream) {
+    REQUIRE(dy && dx && rdt(dtype) && B > 0 && HW > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)B * HW * C;
+    RN_LAUNCH(dtype, avgpool_bwd_kernel, total, dy, (T*)dx, HW, C, total);
+    return 0;
+}

@@ -522,3 +522,102 @@ def depth_head_bwd(x2d, w, y, dy, dw, db, accumulate):
                                         int(accumulate), ptr(ws), code(x2d.dtype), M, C, stream()),
                "depth_head_bwd")
     return dx
+
+
+# ------------------------------------------------------------------ ResNet glue (channels-last)
+def stem_im2col7x7(imgs, dtype):
+    _dev(imgs)
+    _f32(imgs)
+    B, C, H, W = imgs.shape
+    assert C == 3
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    ld = k_pad(147, dtype)
+    cols = torch.empty(B * Ho * Wo, ld, dtype=dtype, device=imgs.device)
+    _lib.check(_lib.load().ssl4gie_stem_im2col7x7(ptr(imgs), ptr(cols), code(dtype), B, H, W, ld,
+                                                  stream()), "stem_im2col7x7")
+    return cols, Ho, Wo
+
+
+def subsample2(x):
+    B, H, W, C = _nhwc(x)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, C, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().ssl4gie_subsample2(ptr(x), ptr(y), code(x.dtype), B, H, W, C, 0, stream()),
+               "subsample2")
+    return y
+
+
+def subsample2_bwd(dy, H, W):
+    B, Ho, Wo, C = _nhwc(dy)
+    dx = torch.empty(B, H, W, C, dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().ssl4gie_subsample2(ptr(dy), ptr(dx), code(dy.dtype), B, H, W, C, 1, stream()),
+               "subsample2_bwd")
+    return dx
+
+
+def bn_fwd(x2d, gamma, beta, res, running_mean, running_var, momentum, eps, relu, training,
+           mean=None, rstd=None):
+    _dev(x2d, gamma, beta, res, running_mean, running_var, mean, rstd)
+    rows, C = x2d.shape
+    L = _lib.load()
+    y = torch.empty_like(x2d)
+    if training:
+        mean = torch.empty(C, dtype=torch.float32, device=x2d.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=x2d.device)
+        ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    else:
+        ws = None
+    _lib.check(L.ssl4gie_bn_fwd(ptr(x2d), ptr(gamma), ptr(beta), ptr(res), ptr(y), ptr(mean), ptr(rstd),
+                                ptr(running_mean), ptr(running_var), float(momentum), float(eps),
+                                int(relu), int(training), ptr(ws), code(x2d.dtype), rows, C, stream()),
+               "bn_fwd")
+    return y, mean, rstd
+
+
+def bn_bwd(dy2d, y2d, x2d, gamma, mean, rstd, relu, want_dres, dgamma, dbeta, accumulate):
+    _dev(dy2d, y2d, x2d, gamma, mean, rstd, dgamma, dbeta)
+    rows, C = x2d.shape
+    L = _lib.load()
+    dx = torch.empty_like(x2d)
+    dres = torch.empty_like(x2d) if want_dres else None
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_bwd(ptr(dy2d), ptr(y2d), ptr(x2d), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate), int(relu), ptr(ws),
+                                code(x2d.dtype), rows, C, stream()), "bn_bwd")
+    return dx, dres
+
+
+def maxpool3x3s2_fwd(x):
+    B, H, W, C = _nhwc(x)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, C, dtype=x.dtype, device=x.device)
+    arg = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().ssl4gie_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(arg), code(x.dtype), B, H, W, C,
+                                                    stream()), "maxpool_fwd")
+    return y, arg
+
+
+def maxpool3x3s2_bwd(dy, arg, H, W):
+    B, Ho, Wo, C = _nhwc(dy)
+    dx = torch.empty(B, H, W, C, dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().ssl4gie_maxpool3x3s2_bwd(ptr(dy), ptr(arg), ptr(dx), code(dy.dtype), B, H, W,
+                                                    C, stream()), "maxpool_bwd")
+    return dx
+
+
+def avgpool_fwd(x):
+    B, H, W, C = _nhwc(x)
+    y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ssl4gie_avgpool_fwd(ptr(x), ptr(y), code(x.dtype), B, H * W, C, stream()),
+               "avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, H, W, dtype):
+    _dev(dy)
+    _f32(dy)
+    B, C = dy.shape
+    dx = torch.empty(B, H, W, C, dtype=dtype, device=dy.device)
+    _lib.check(_lib.load().ssl4gie_avgpool_bwd(ptr(dy), ptr(dx), code(dtype), B, H * W, C, stream()),
+               "avgpool_bwd")
+    return dx

@@ -1,0 +1,128 @@
+"""Autograd nodes of the ResNet50 trunk on the HIP engine.
+
+Channels-last maps in the engine's operand type.  conv1 (7x7 s2) is a GEMM over the stem patch
+matrix, 1x1 convolutions are token-major GEMMs (engine.LinearFn, after a stride-2 row pick for the
+downsample branches), 3x3 convolutions reuse dpt_engine.Conv3x3Fn; BatchNorm2d runs in training
+mode with fp32 batch statistics and fuses ReLU and the bottleneck's residual add.
+Reference: torchvision 0.10 resnet.py (un-vendored) as instantiated at
+Models/models.py:63-75 and Models/moco_v3/main_moco.py:185-187.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .dpt_engine import _derived, _pad_cols, _write_grad
+from .engine import GradSink, LPCache
+
+
+class StemConvFn(torch.autograd.Function):
+    """conv1: Conv2d(3, 64, 7, stride 2, pad 3, bias=False) on the fp32 NCHW image."""
+
+    @staticmethod
+    def forward(ctx, imgs, weight, dtype, sink: GradSink, lp: LPCache):
+        imgs = imgs.contiguous().float()
+        B = imgs.shape[0]
+        cols, Ho, Wo = ops.stem_im2col7x7(imgs, dtype)
+        ld = cols.shape[1]
+        Cout = weight.shape[0]
+        w2 = _derived(lp, weight, f"stem:{ld}", dtype,
+                      lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 147), ld))
+        y = ops.linear_fwd(cols, w2, None, out_dtype=dtype)
+        ctx.save_for_backward(imgs, weight)
+        ctx.cfg = (dtype, sink)
+        return y.view(B, Ho, Wo, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        imgs, weight = ctx.saved_tensors
+        dtype, sink = ctx.cfg
+        Cout = weight.shape[0]
+        (tw,), acc, rets = sink.plan([weight])
+        if tw is not None:
+            cols, _, _ = ops.stem_im2col7x7(imgs, dtype)  # recomputed, not kept
+            dw2 = ops.linear_bwd_weight(dy.contiguous().view(-1, Cout), cols)
+            _write_grad(tw, dw2[:, :147].view(Cout, 7, 7, 3).permute(0, 3, 1, 2), acc)
+        return None, rets[0], None, None, None
+
+
+class Subsample2Fn(torch.autograd.Function):
+    """the pixel pick of a stride-2 1x1 convolution (Bottleneck.downsample[0])"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = x.shape[1:3]
+        return ops.subsample2(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.subsample2_bwd(dy.contiguous(), *ctx.hw)
+
+
+class BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm2d / BatchNorm1d over the rows of a [..., C] tensor, (+ residual) (+ ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, bn, relu, sink: GradSink):
+        shp = x.shape
+        C = shp[-1]
+        x2 = x.contiguous().view(-1, C)
+        r2 = res.contiguous().view(-1, C) if res is not None else None
+        training = bn.training or bn.running_mean is None
+        g = gamma.detach() if gamma is not None else None
+        b = beta.detach() if beta is not None else None
+        if training:
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            y, mean, rstd = ops.bn_fwd(x2, g, b, r2, bn.running_mean, bn.running_var, mom, bn.eps, relu,
+                                       True)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        else:
+            mean = bn.running_mean
+            rstd = torch.rsqrt(bn.running_var + bn.eps)  # [C] floats: host-side plumbing
+            y, _, _ = ops.bn_fwd(x2, g, b, r2, None, None, 0.0, bn.eps, relu, False, mean, rstd)
+        ctx.save_for_backward(x2, y if relu else None, gamma, beta, mean, rstd)
+        ctx.cfg = (shp, relu, res is not None, sink, training)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y, gamma, beta, mean, rstd = ctx.saved_tensors
+        shp, relu, has_res, sink, training = ctx.cfg
+        if not training:
+            raise NotImplementedError("backward through BatchNorm in eval mode (frozen statistics) is "
+                                      "not built: the reference freezes trunks under no_grad")
+        C = shp[-1]
+        (tg, tb), acc, rets = sink.plan([gamma, beta])
+        dx, dres = ops.bn_bwd(dy.contiguous().view(-1, C), y, x2,
+                              gamma.detach() if gamma is not None else None, mean, rstd, relu, has_res,
+                              tg, tb, acc)
+        return (dx.view(shp), rets[0], rets[1], dres.view(shp) if has_res else None, None, None, None)
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, arg = ops.maxpool3x3s2_fwd(x.contiguous())
+        ctx.save_for_backward(arg)
+        ctx.hw = x.shape[1:3]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        return ops.maxpool3x3s2_bwd(dy.contiguous(), arg, *ctx.hw)
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1) + flatten -> fp32 [B, C]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.cfg = (x.shape[1], x.shape[2], x.dtype)
+        return ops.avgpool_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        H, W, dt = ctx.cfg
+        return ops.avgpool_bwd(dy.contiguous().float(), H, W, dt)

@@ -32,7 +32,5 @@ def get_ImageNet_or_random_ViT(head, num_classes, frozen, dense, det, ImageNet_w
                                              12, 12, out_token, ImageNet_weights)
 
 
-def _resnet(*args, **kwargs):
-    raise NotImplementedError(
-        "ResNet_from_Any (reference Models/models.py:63-152; SURVEY §8 row a14) is not built yet: "
-        "this round covers the ViT-B / MAE path")
+def _resnet(weight_path, head, num_classes, frozen, dense, ImageNet_weights=False):
+    return models.ResNet_from_Any(weight_path, head, num_classes, frozen, dense, ImageNet_weights)

@@ -1,0 +1,185 @@
+"""GPU parity of the ResNet50 trunk: glue kernels against torch fp32 of the same
+op and the whole trunk (training-mode BatchNorm) against the CPU restatement.  torchvision is absent
+from the reference checkout and this image, so parity at that boundary is unpinned (oracle header)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F32, BF = torch.float32, torch.bfloat16
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ssl4gie_amd import _lib
+    _lib.load()
+
+
+def G(seed):
+    return torch.Generator("cpu").manual_seed(seed)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("relu,with_res", [(False, False), (True, False), (True, True)])
+def test_batchnorm_fwd_bwd_fp32(relu, with_res):
+    from ssl4gie_amd.engine import GradSink
+    from ssl4gie_amd.resnet_engine import BatchNormFn
+    C = 64
+    x = torch.randn(3, C, 9, 7, generator=G(1)) * 2 + 5  # |mean| >> std exercises the pivoted sums
+    res = torch.randn(3, C, 9, 7, generator=G(2)) if with_res else None
+    bn_ref = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.randn(C, generator=G(3)))
+        bn_ref.bias.copy_(torch.randn(C, generator=G(4)))
+    bn = torch.nn.BatchNorm2d(C)
+    bn.load_state_dict(bn_ref.state_dict())
+    bn.to(DEV)
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    yr = bn_ref(xr)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    dy = torch.randn(yr.shape, generator=G(5))
+    yr.backward(dy)
+    xd = nhwc(x).to(DEV).requires_grad_(True)
+    rd = nhwc(res).to(DEV).requires_grad_(True) if with_res else None
+    y = BatchNormFn.apply(xd, bn.weight, bn.bias, rd, bn, relu, GradSink(None))
+    y.backward(nhwc(dy).to(DEV))
+    assert rel_err(nchw(y.detach().cpu()), yr) < 1e-5
+    assert rel_err(nchw(xd.grad.cpu()), xr.grad) < 1e-4
+    assert rel_err(bn.weight.grad.cpu(), bn_ref.weight.grad) < 1e-4
+    assert rel_err(bn.bias.grad.cpu(), bn_ref.bias.grad) < 1e-4
+    if with_res:
+        assert rel_err(nchw(rd.grad.cpu()), rr.grad) < 1e-5
+    assert rel_err(bn.running_mean.cpu(), bn_ref.running_mean) < 1e-5
+    assert rel_err(bn.running_var.cpu(), bn_ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_maxpool_avgpool_subsample():
+    from ssl4gie_amd.resnet_engine import AvgPoolFn, MaxPoolFn, Subsample2Fn
+    x = torch.relu(torch.randn(2, 16, 12, 10, generator=G(6)))  # ReLU output: many tied zeros
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(yr.shape, generator=G(7))
+    yr.backward(dy)
+    xd = nhwc(x).to(DEV).requires_grad_(True)
+    y = MaxPoolFn.apply(xd)
+    y.backward(nhwc(dy).to(DEV))
+    assert torch.equal(nchw(y.detach().cpu()), yr.detach())
+    assert rel_err(nchw(xd.grad.cpu()), xr.grad) < 1e-6
+    xr.grad = None
+    pr = xr.mean((2, 3))
+    dp = torch.randn(pr.shape, generator=G(8))
+    pr.backward(dp)
+    xd2 = nhwc(x).to(DEV).requires_grad_(True)
+    p = AvgPoolFn.apply(xd2)
+    p.backward(dp.to(DEV))
+    assert rel_err(p.detach().cpu(), pr) < 1e-6
+    assert rel_err(nchw(xd2.grad.cpu()), xr.grad) < 1e-6
+    xd3 = nhwc(x).to(DEV).requires_grad_(True)
+    s = Subsample2Fn.apply(xd3)
+    assert torch.equal(nchw(s.detach().cpu()), x[:, :, ::2, ::2])
+    s.backward(torch.ones_like(s))
+    ref = torch.zeros_like(x)
+    ref[:, :, ::2, ::2] = 1
+    assert torch.equal(nchw(xd3.grad.cpu()), ref)
+
+
+def _resnet_pair(seed, zero_init=False):
+    from ssl4gie_amd.Models import models
+    torch.manual_seed(seed)
+    m = models.ResNet_from_Any(None, False, None, False, None)
+    if zero_init:
+        pass
+    # non-trivial affine parameters so that dgamma / dbeta paths are exercised
+    g = G(seed + 1)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.copy_(1 + 0.1 * torch.randn(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m, sd
+
+
+def test_resnet50_schema():
+    m, sd = _resnet_pair(0)
+    assert "fc.weight" not in sd and "conv1.weight" in sd
+    assert sd["layer1.0.downsample.0.weight"].shape == (256, 64, 1, 1)
+    assert sd["layer4.2.conv3.weight"].shape == (2048, 512, 1, 1)
+    assert sd["layer2.0.conv2.weight"].shape == (128, 128, 3, 3)
+    n_params = sum(p.numel() for p in m.parameters())
+    assert n_params == 23508032  # torchvision resnet50 without fc
+    assert sum(1 for k in sd if k.endswith("running_mean")) == 53
+
+
+def _l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def _oracle_run(sd, imgs, w, dt):
+    from oracle import resnet_ref
+    sdo = {k: (v.clone().to(dt).requires_grad_(True) if (v.is_floating_point() and "running" not in k)
+               else v.clone()) for k, v in sd.items()}
+    out = resnet_ref.resnet50_pooled(sdo, imgs.to(dt))
+    (out * w.to(dt)).sum().backward()
+    return out.detach(), {k: v.grad for k, v in sdo.items() if v.requires_grad and v.grad is not None}
+
+
+NAMES = ("layer4.2.bn3.bias", "layer4.2.conv3.weight", "layer4.0.conv1.weight", "layer3.0.conv2.weight",
+         "layer2.0.downsample.0.weight", "layer1.0.conv2.weight", "bn1.weight", "conv1.weight")
+
+
+def test_resnet50_trunk_fp32_as_accurate_as_torch_fp32():
+    """Random-init ResNet50 in training mode is ill-conditioned for a 1e-3 gradient check: a handful
+    of ReLU masks flip between any two fp32 evaluations and BatchNorm's batch statistics spread that
+    over every element (torch's own fp32 and fp64 CPU results differ by ~2 % in relative L2 on the
+    early-layer gradients).  So the engine's fp32 path is held to the bar torch fp32 itself meets:
+    its distance to the fp64 oracle may not exceed 2.5x torch-fp32's distance to the fp64 oracle;
+    the forward (no discontinuity amplification) is held to 1e-3."""
+    m, sd = _resnet_pair(1)
+    m.to(DEV).set_precision("fp32")
+    imgs = torch.randn(8, 3, 128, 128, generator=G(9))
+    w = torch.randn(2048, generator=G(10))
+    out = m(imgs.to(DEV))
+    (out * w.to(DEV)).sum().backward()
+    o64, g64 = _oracle_run(sd, imgs, w, torch.float64)
+    o32, g32 = _oracle_run(sd, imgs, w, torch.float32)
+    assert out.shape == (8, 2048)
+    assert rel_err(out, o64) < 1e-3
+    grads = dict(m.named_parameters())
+    for name in NAMES:
+        ours, torch32 = _l2(grads[name].grad, g64[name]), _l2(g32[name], g64[name])
+        assert ours <= 2.5 * torch32 + 1e-4, (name, ours, torch32)
+
+
+def test_resnet50_trunk_bf16_tracks_oracle():
+    """bf16 activations: ~6 roundings per bottleneck compound to ~1.3x per block at random init (the
+    reference's fp16 autocast path has the same dtype flow with a 3-bit wider mantissa); judged on
+    relative L2 of the pooled features and of the last block's gradients."""
+    m, sd = _resnet_pair(1)
+    m.to(DEV).set_precision("bf16")
+    imgs = torch.randn(8, 3, 128, 128, generator=G(9))
+    w = torch.randn(2048, generator=G(10))
+    out = m(imgs.to(DEV))
+    (out * w.to(DEV)).sum().backward()
+    o64, g64 = _oracle_run(sd, imgs, w, torch.float64)
+    assert _l2(out, o64) < 0.3
+    assert _l2(dict(m.named_parameters())["layer4.2.bn3.bias"].grad, g64["layer4.2.bn3.bias"]) < 0.15
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
