@@ -273,6 +273,23 @@ int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, const float* ga
                    const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
                    float* dbeta, int accumulate, int relu, float* workspace, int dtype,
                    long long rows, int C, void* stream);
+/* SyncBatchNorm (convert_sync_batchnorm: Depth_estimation/train_depth.py:225,
+ * Models/moco_v3/main_moco.py:196) = the same kernels with the exchange step between them:
+ *   forward : ssl4gie_bn_stats (LOCAL mean / biased var) -> caller combines over ranks ->
+ *             ssl4gie_bn_fwd(training = 0) with the global mean / rstd;
+ *   backward: ssl4gie_bn_bwd_reduce (LOCAL sum g, sum g xhat -> sums [2, C]; also dres = g) ->
+ *             caller all-reduces sums -> ssl4gie_bn_bwd_apply with 1 / global row count. */
+int ssl4gie_bn_stats(const void* x, float* mean, float* var, float* workspace, int dtype,
+                     long long rows, int C, void* stream);
+int ssl4gie_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean,
+                          const float* rstd, void* dres, float* sums, int relu, float* workspace,
+                          int dtype, long long rows, int C, void* stream);
+int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma,
+                         const float* mean, const float* rstd, const float* sums, float inv_count,
+                         void* dx, int relu, int dtype, long long rows, int C, void* stream);
+/* MoCo._update_momentum_encoder (moco/builder.py:57-61): dst = dst m + src (1 - m), fp32, over a
+ * whole parameter-arena slice */
+int ssl4gie_ema_update(float* dst, const float* src, float m, long long n, void* stream);
 /* MaxPool2d(3, stride 2, pad 1) with the argmax window position saved (first maximum in row-major
  * scan order); backward in gather form.  Global average pool -> fp32 [B, C] and its gradient. */
 int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* arg, int dtype, int B, int H,

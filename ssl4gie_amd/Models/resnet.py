@@ -38,7 +38,7 @@ class Bottleneck(nn.Module):
 class ResNet50(EngineModule):
     """trunk only: `forward_features` -> channels-last layer4 map (or the 4 stage maps)"""
 
-    def __init__(self, zero_init_residual=False):
+    def __init__(self, zero_init_residual=False, num_classes=None):
         super().__init__()
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
@@ -50,6 +50,8 @@ class ResNet50(EngineModule):
         self.layer3 = self._make_layer(256, 6, stride=2)
         self.layer4 = self._make_layer(512, 3, stride=2)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        if num_classes is not None:  # torchvision's classifier slot (MoCo replaces it by its projector)
+            self.fc = nn.Linear(2048, num_classes)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -110,3 +112,8 @@ class ResNet50(EngineModule):
     def pooled(self, imgs):
         """[B, 2048] fp32: avgpool + flatten of the layer4 map"""
         return AvgPoolFn.apply(self.forward_maps(imgs))
+
+
+def resnet50(num_classes=1000, zero_init_residual=False, **kwargs):
+    """torchvision.models.resnet50 signature subset used by the reference (main_moco.py:185-187)"""
+    return ResNet50(zero_init_residual=zero_init_residual, num_classes=num_classes)

@@ -469,3 +469,94 @@ extern "C" int ssl4gie_avgpool_bwd(const float* dy, void* dx, int dtype, int B, 
     RN_LAUNCH(dtype, avgpool_bwd_kernel, total, dy, (T*)dx, HW, C, total);
     return 0;
 }
+
+// ------------------------------------------------------------------ pieces for SyncBatchNorm / MoCo
+// dst = dst * m + src * (1 - m): MoCo._update_momentum_encoder (moco/builder.py:57-61) over a whole
+// arena slice (base and momentum encoders are laid out identically)
+__global__ void ema_update_kernel(float* __restrict__ dst, const float* __restrict__ src, float m,
+                                  long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4 d = ld4(dst + i), v = ld4(src + i);
+        st4(dst + i, d * m + v * (1.f - m));
+    } else {
+        for (long long j = i; j < n; ++j) dst[j] = dst[j] * m + src[j] * (1.f - m);
+    }
+}
+extern "C" int ssl4gie_ema_update(float* dst, const float* src, float m, long long n, void* stream) {
+    REQUIRE(dst && src && n >= 0);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0,
+                       (hipStream_t)stream, dst, src, m, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+// SyncBatchNorm, forward half: LOCAL batch statistics only (mean, biased var [C]); the caller
+// combines them across ranks (counts may differ) and then calls ssl4gie_bn_fwd(training = 0) with
+// the global mean / rstd.
+__global__ void bn_local_stats_kernel(const float* __restrict__ sums, const float* __restrict__ pivot,
+                                      float* __restrict__ mean, float* __restrict__ var, float count,
+                                      int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float d = sums[c] / count;
+    const float v = sums[C + c] / count - d * d;
+    mean[c] = pivot[c] + d;
+    var[c] = v > 0.f ? v : 0.f;
+}
+extern "C" int ssl4gie_bn_stats(const void* x, float* mean, float* var, float* workspace, int dtype,
+                                long long rows, int C, void* stream) {
+    REQUIRE(x && mean && var && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = bn_parts(rows);
+    dim3 grid((C + 255) / 256, parts), block(256);
+    float* sums = workspace + (size_t)parts * 2 * C;
+    float* pivot = sums + 2 * C;
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, workspace,
+                           pivot, rows, C);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, block, 0, st, (const float*)x, workspace,
+                           pivot, rows, C);
+    LAUNCH_CHECK();
+    int rc = ssl4gie_internal_reduce_partials(workspace, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_local_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, pivot,
+                       mean, var, (float)rows, C);
+    LAUNCH_CHECK();
+    return 0;
+}
+// SyncBatchNorm, backward halves: sums[0][c] = sum g, sums[1][c] = sum g xhat over the LOCAL rows
+// (the caller all-reduces them), then dx with the GLOBAL sums and 1 / (global row count).
+extern "C" int ssl4gie_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean,
+                                     const float* rstd, void* dres, float* sums, int relu,
+                                     float* workspace, int dtype, long long rows, int C,
+                                     void* stream) {
+    REQUIRE(dy && x && mean && rstd && sums && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
+    REQUIRE(!relu || y);
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = bn_parts(rows);
+    dim3 grid((C + 255) / 256, parts), block(256);
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy,
+                           (const bf16_t*)y, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, workspace,
+                           relu, rows, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)dy,
+                           (const float*)y, (const float*)x, mean, rstd, (float*)dres, workspace, relu,
+                           rows, C);
+    LAUNCH_CHECK();
+    return ssl4gie_internal_reduce_partials(workspace, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+}
+extern "C" int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma,
+                                    const float* mean, const float* rstd, const float* sums,
+                                    float inv_count, void* dx, int relu, int dtype, long long rows,
+                                    int C, void* stream) {
+    REQUIRE(dy && x && mean && rstd && sums && dx && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
+    REQUIRE(!relu || y);
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = rows * C;
+    RN_LAUNCH(dtype, bn_bwd_apply_kernel, total / rvn(dtype), (const T*)dy, (const T*)y, (const T*)x,
+              mean, rstd, gamma, sums, (T*)dx, relu, inv_count, C, total);
+    return 0;
+}

@@ -621,3 +621,50 @@ def avgpool_bwd(dy, H, W, dtype):
     _lib.check(_lib.load().ssl4gie_avgpool_bwd(ptr(dy), ptr(dx), code(dtype), B, H * W, C, stream()),
                "avgpool_bwd")
     return dx
+
+
+# ------------------------------------------------------------------ SyncBatchNorm pieces / MoCo EMA
+def bn_stats(x2d):
+    """local batch statistics (mean, biased variance) of the rows of x2d, fp32 [C] each"""
+    _dev(x2d)
+    rows, C = x2d.shape
+    L = _lib.load()
+    mean = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    var = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_stats(ptr(x2d), ptr(mean), ptr(var), ptr(ws), code(x2d.dtype), rows, C,
+                                  stream()), "bn_stats")
+    return mean, var
+
+
+def bn_bwd_reduce(dy2d, y2d, x2d, mean, rstd, relu, want_dres):
+    _dev(dy2d, y2d, x2d, mean, rstd)
+    rows, C = x2d.shape
+    L = _lib.load()
+    sums = torch.empty(2, C, dtype=torch.float32, device=x2d.device)
+    dres = torch.empty_like(x2d) if want_dres else None
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_bwd_reduce(ptr(dy2d), ptr(y2d), ptr(x2d), ptr(mean), ptr(rstd), ptr(dres),
+                                       ptr(sums), int(relu), ptr(ws), code(x2d.dtype), rows, C,
+                                       stream()), "bn_bwd_reduce")
+    return sums, dres
+
+
+def bn_bwd_apply(dy2d, y2d, x2d, gamma, mean, rstd, sums, inv_count, relu):
+    _dev(dy2d, y2d, x2d, gamma, mean, rstd, sums)
+    rows, C = x2d.shape
+    dx = torch.empty_like(x2d)
+    _lib.check(_lib.load().ssl4gie_bn_bwd_apply(ptr(dy2d), ptr(y2d), ptr(x2d), ptr(gamma), ptr(mean),
+                                                ptr(rstd), ptr(sums), float(inv_count), ptr(dx),
+                                                int(relu), code(x2d.dtype), rows, C, stream()),
+               "bn_bwd_apply")
+    return dx
+
+
+def ema_update(dst, src, m):
+    """dst = dst * m + src * (1 - m) on flat fp32 tensors"""
+    _dev(dst, src)
+    _f32(dst, src)
+    assert dst.numel() == src.numel()
+    _lib.check(_lib.load().ssl4gie_ema_update(ptr(dst), ptr(src), float(m), dst.numel(), stream()),
+               "ema_update")

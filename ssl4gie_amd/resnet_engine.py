@@ -59,8 +59,37 @@ class Subsample2Fn(torch.autograd.Function):
         return ops.subsample2_bwd(dy.contiguous(), *ctx.hw)
 
 
+def combine_batch_stats(mean_l, var_l, count_l, group=None):
+    """Exchange step of SyncBatchNorm: per-rank (mean, biased var, count) -> global (mean, biased var,
+    count) by the pooled-variance identity (ranks may hold different row counts).  One all_gather of
+    2C + 1 floats.  Pure torch on [W, 2C+1] floats; runs on gloo for the CPU tests."""
+    import torch.distributed as dist
+    C = mean_l.numel()
+    packed = torch.cat([mean_l, var_l, mean_l.new_tensor([float(count_l)])])
+    world = dist.get_world_size(group)
+    gathered = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(gathered, packed, group=group)
+    g = torch.stack(gathered)  # [W, 2C+1]
+    n = g[:, 2 * C:]           # [W, 1]
+    total = n.sum()
+    mean = (g[:, :C] * n).sum(0) / total
+    var = ((g[:, C:2 * C] + (g[:, :C] - mean) ** 2) * n).sum(0) / total
+    return mean, var, total
+
+
+def _sync_group(bn):
+    import torch.distributed as dist
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
+            and dist.get_world_size(bn.process_group) > 1:
+        return True, bn.process_group
+    return False, None
+
+
 class BatchNormFn(torch.autograd.Function):
-    """nn.BatchNorm2d / BatchNorm1d over the rows of a [..., C] tensor, (+ residual) (+ ReLU)."""
+    """nn.BatchNorm2d / BatchNorm1d / SyncBatchNorm over the rows of a [..., C] tensor, (+ residual)
+    (+ ReLU).  With an nn.SyncBatchNorm holder and world_size > 1 the statistics are global: local
+    statistics kernel -> all_gather + pooled combine -> apply kernel; backward: local reduction
+    kernel -> all_reduce of the 2C sums -> apply kernel (dgamma / dbeta stay local, DDP averages)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, bn, relu, sink: GradSink):
@@ -71,32 +100,58 @@ class BatchNormFn(torch.autograd.Function):
         training = bn.training or bn.running_mean is None
         g = gamma.detach() if gamma is not None else None
         b = beta.detach() if beta is not None else None
-        if training:
+        sync, group = _sync_group(bn)
+        count = float(x2.shape[0])
+        if training and not sync:
             mom = bn.momentum if bn.momentum is not None else 0.1
             y, mean, rstd = ops.bn_fwd(x2, g, b, r2, bn.running_mean, bn.running_var, mom, bn.eps, relu,
                                        True)
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+        elif training:
+            mean_l, var_l = ops.bn_stats(x2)
+            mean, var, total = combine_batch_stats(mean_l, var_l, x2.shape[0], group)
+            count = float(total)
+            rstd = torch.rsqrt(var + bn.eps)
+            if bn.running_mean is not None:
+                mom = bn.momentum if bn.momentum is not None else 0.1
+                with torch.no_grad():
+                    bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(var * (count / max(count - 1.0, 1.0)), alpha=mom)
+            y, _, _ = ops.bn_fwd(x2, g, b, r2, None, None, 0.0, bn.eps, relu, False, mean, rstd)
         else:
             mean = bn.running_mean
             rstd = torch.rsqrt(bn.running_var + bn.eps)  # [C] floats: host-side plumbing
             y, _, _ = ops.bn_fwd(x2, g, b, r2, None, None, 0.0, bn.eps, relu, False, mean, rstd)
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
         ctx.save_for_backward(x2, y if relu else None, gamma, beta, mean, rstd)
-        ctx.cfg = (shp, relu, res is not None, sink, training)
+        ctx.cfg = (shp, relu, res is not None, sink, training, sync, group, count)
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, y, gamma, beta, mean, rstd = ctx.saved_tensors
-        shp, relu, has_res, sink, training = ctx.cfg
+        shp, relu, has_res, sink, training, sync, group, count = ctx.cfg
         if not training:
             raise NotImplementedError("backward through BatchNorm in eval mode (frozen statistics) is "
                                       "not built: the reference freezes trunks under no_grad")
         C = shp[-1]
         (tg, tb), acc, rets = sink.plan([gamma, beta])
-        dx, dres = ops.bn_bwd(dy.contiguous().view(-1, C), y, x2,
-                              gamma.detach() if gamma is not None else None, mean, rstd, relu, has_res,
-                              tg, tb, acc)
+        dy2 = dy.contiguous().view(-1, C)
+        gd = gamma.detach() if gamma is not None else None
+        if not sync:
+            dx, dres = ops.bn_bwd(dy2, y, x2, gd, mean, rstd, relu, has_res, tg, tb, acc)
+        else:
+            import torch.distributed as dist
+            sums, dres = ops.bn_bwd_reduce(dy2, y, x2, mean, rstd, relu, has_res)
+            for tgt, row in ((tb, 0), (tg, 1)):  # parameter gradients are the LOCAL sums
+                if tgt is not None:
+                    if acc:
+                        tgt.add_(sums[row])
+                    else:
+                        tgt.copy_(sums[row])
+            gsums = sums.clone()
+            dist.all_reduce(gsums, group=group)
+            dx = ops.bn_bwd_apply(dy2, y, x2, gd, mean, rstd, gsums, 1.0 / count, relu)
         return (dx.view(shp), rets[0], rets[1], dres.view(shp) if has_res else None, None, None, None)
 
 

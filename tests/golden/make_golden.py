@@ -20,6 +20,7 @@ Fixtures written:
   g_lr_sched.npz      per-iteration warm-up+cosine LR (mae/util/lr_sched.py:9-21)
   g6_dpt_depth.npz    reference DPT_decoder("depth") fwd + SSI loss + grads on seeded taps, B=2
   g7_ssi_loss.npz     reference ScaleAndShiftInvariantLoss(alpha=0.1) value + gradient
+  g8_moco.npz         reference MoCo._build_mlp fwd/bwd, contrastive_loss (1-process gloo), LARS 3 steps
 """
 from __future__ import annotations
 
@@ -305,6 +306,65 @@ def g7_ssi():
     print(f"g7 ssi: loss={float(loss):.6f}")
 
 
+def g8_moco():
+    """the reference's own MoCo glue: MLP builder, InfoNCE loss (in a 1-process gloo group; the only
+    shim is Tensor.cuda -> identity because this container has no GPU) and LARS"""
+    import torch.distributed as dist
+    ref_b = _load_by_path("ref_builder", os.path.join(REF, "Models", "moco_v3", "moco", "builder.py"))
+    ref_o = _load_by_path("ref_lars", os.path.join(REF, "Models", "moco_v3", "moco", "optimizer.py"))
+    out = {}
+    g = torch.Generator("cpu").manual_seed(21)
+    obj = ref_b.MoCo.__new__(ref_b.MoCo)  # _build_mlp does not touch self
+    for tag, args in (("proj2", (2, 64, 128, 32)), ("pred2", (2, 32, 128, 32, False)), ("proj3", (3, 48, 96, 32))):
+        mlp = ref_b.MoCo._build_mlp(obj, *args)
+        with torch.no_grad():
+            for prm in mlp.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g) * (0.2 if prm.dim() > 1 else 1.0))
+        x = torch.randn(16, args[1], generator=g).requires_grad_(True)
+        y = mlp(x)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        for k, v in mlp.state_dict().items():
+            if "running" not in k and "num_batches" not in k:
+                out[f"{tag}/sd/{k}"] = v.numpy()
+        out[f"{tag}/keys"] = np.array(list(mlp.state_dict().keys()))
+        out[f"{tag}/x"] = x.detach().numpy(); out[f"{tag}/y"] = y.detach().numpy()
+        out[f"{tag}/dy"] = dy.numpy(); out[f"{tag}/dx"] = x.grad.numpy()
+        for k, prm in mlp.named_parameters():
+            out[f"{tag}/grad/{k}"] = prm.grad.numpy()
+    # contrastive loss from the reference method itself
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        obj.T = 0.2
+        q = torch.randn(12, 32, generator=g).requires_grad_(True)
+        k = torch.randn(12, 32, generator=g)
+        loss = ref_b.MoCo.contrastive_loss(obj, q, k)
+        loss.backward()
+        out["cl/q"] = q.detach().numpy(); out["cl/k"] = k.numpy(); out["cl/T"] = np.array(0.2)
+        out["cl/loss"] = np.array(float(loss)); out["cl/dq"] = q.grad.numpy()
+    finally:
+        torch.Tensor.cuda = real_cuda
+        dist.destroy_process_group()
+    # LARS: 3 steps on a matrix, a bias vector and a zero matrix
+    ps = [torch.nn.Parameter(torch.randn(8, 16, generator=g)), torch.nn.Parameter(torch.randn(16, generator=g)),
+          torch.nn.Parameter(torch.zeros(4, 4))]
+    opt = ref_o.LARS(ps, lr=0.3, weight_decay=1e-2, momentum=0.9)
+    for i, prm in enumerate(ps):
+        out[f"lars/p0/{i}"] = prm.detach().numpy().copy()
+    for step in range(3):
+        for i, prm in enumerate(ps):
+            prm.grad = torch.randn(prm.shape, generator=g)
+            out[f"lars/g{step}/{i}"] = prm.grad.numpy().copy()
+        opt.step()
+        for i, prm in enumerate(ps):
+            out[f"lars/p{step + 1}/{i}"] = prm.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g8_moco.npz"), **out)
+    print(f"g8 moco: contrastive loss={float(out['cl/loss']):.6f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-curve", action="store_true")
@@ -316,7 +376,7 @@ def main():
     jobs = {
         "g1": lambda: g1_masking(ref_mae), "g2": lambda: g2_patchify(ref_mae), "g3": g3_sincos,
         "g5tiny": lambda: g5_tiny(ref_mae), "g5vitb": lambda: g5_vitb(ref_mae),
-        "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi,
+        "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi, "g8": g8_moco,
         "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
             **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
             "g5_curve_tiny.npz"),

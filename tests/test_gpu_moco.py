@@ -1,0 +1,100 @@
+"""GPU parity of the MoCo-v3 glue: MLP heads against the reference fixture
+(G8), the momentum update, and a whole MoCo_ResNet step against the CPU oracle composition."""
+from functools import partial
+
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ssl4gie_amd import _lib
+    _lib.load()
+
+
+def _moco(T=1.0):
+    from ssl4gie_amd.Models.moco_v3.moco import builder
+    from ssl4gie_amd.Models.resnet import resnet50
+    torch.manual_seed(0)
+    return builder.MoCo_ResNet(partial(resnet50, zero_init_residual=True), 256, 4096, T)
+
+
+@pytest.mark.parametrize("tag,dims", [("proj2", (2, 64, 128, 32, True)), ("pred2", (2, 32, 128, 32, False)),
+                                      ("proj3", (3, 48, 96, 32, True))])
+def test_mlp_head_matches_reference_fixture(tag, dims):
+    g = load_golden("g8_moco.npz")
+    m = _moco()
+    mlp = m._build_mlp(*dims)
+    with torch.no_grad():
+        for k, p in mlp.named_parameters():
+            p.copy_(torch.from_numpy(g[f"{tag}/sd/{k}"]))
+    m.pred_test = mlp  # registered: its parameters join the model's arena
+    m.to(DEV).set_precision("fp32")
+    x = torch.from_numpy(g[f"{tag}/x"]).to(DEV).requires_grad_(True)
+    m._prepare()
+    y = m.run_mlp(m.pred_test, x)
+    y.backward(torch.from_numpy(g[f"{tag}/dy"]).to(DEV))
+    assert rel_err(y, g[f"{tag}/y"]) < 1e-4
+    assert rel_err(x.grad, g[f"{tag}/dx"]) < 1e-3
+    for k, p in m.pred_test.named_parameters():
+        assert rel_err(p.grad, g[f"{tag}/grad/{k}"]) < 1e-3, k
+
+
+def test_momentum_update_is_exact_axpby():
+    m = _moco().to(DEV)
+    m._prepare()
+    with torch.no_grad():
+        for p in m.base_encoder.parameters():
+            p.add_(torch.randn_like(p) * 0.01)
+    before_b = [p.detach().clone() for p in m.base_encoder.parameters()]
+    before_m = [p.detach().clone() for p in m.momentum_encoder.parameters()]
+    m._update_momentum_encoder(0.99)
+    for pb, pm0, pm in zip(before_b, before_m, m.momentum_encoder.parameters()):
+        assert torch.allclose(pm, pm0 * 0.99 + pb * (1.0 - 0.99), rtol=1e-6, atol=1e-8)
+    for pb0, pb in zip(before_b, m.base_encoder.parameters()):
+        assert torch.equal(pb0, pb)
+
+
+def test_moco_resnet_step_vs_oracle():
+    """loss of MoCo_ResNet.forward(x1, x2, m) (fp32 engine) == oracle composition; finite gradients on
+    every trainable parameter, none on the momentum encoder"""
+    from oracle import moco_ref, resnet_ref
+    m = _moco(T=1.0)
+    # give the zero-initialised bn3 gammas a value so that the bottleneck bodies matter
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for mod in m.base_encoder.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.copy_(1 + 0.1 * torch.randn(mod.weight.shape, generator=g))
+        for pb, pm in zip(m.base_encoder.parameters(), m.momentum_encoder.parameters()):
+            pm.copy_(pb)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.to(DEV).set_precision("fp32")
+    x1 = torch.randn(8, 3, 64, 64, generator=g)
+    x2 = torch.randn(8, 3, 64, 64, generator=g)
+    loss = m(x1.to(DEV), x2.to(DEV), 0.99)
+    loss.backward()
+
+    def enc(prefix, x):
+        sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        return moco_ref.mlp_forward(sub, "fc.", resnet_ref.resnet50_pooled(sub, x))
+
+    pred = {k[len("predictor."):]: v for k, v in sd.items() if k.startswith("predictor.")}
+    q1 = moco_ref.mlp_forward(pred, "", enc("base_encoder.", x1))
+    q2 = moco_ref.mlp_forward(pred, "", enc("base_encoder.", x2))
+    k1, k2 = enc("momentum_encoder.", x1), enc("momentum_encoder.", x2)  # EMA of equal weights = identity
+    ref = moco_ref.contrastive_loss(q1, k2, 1.0) + moco_ref.contrastive_loss(q2, k1, 1.0)
+    assert abs(float(loss.detach()) - float(ref)) < 2e-3 * abs(float(ref))
+    for name, p in m.named_parameters():
+        if name.startswith("momentum_encoder."):
+            assert p.grad is None
+        else:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert int(m.base_encoder.bn1.num_batches_tracked) == 2 and int(m.momentum_encoder.bn1.num_batches_tracked) == 2

@@ -178,3 +178,68 @@ def test_dpt_module_schema_matches_reference():
     m = DPT_decoder(num_classes=1, dense="depth")
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dpt_ref.dpt_param_shapes()
     assert sum(p.numel() for p in m.parameters()) == 20065921
+
+
+# ------------------------------------------------------------------ MoCo-v3 glue
+def _g8_sd(g, tag):
+    pre = f"{tag}/sd/"
+    sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+    for k in g[f"{tag}/keys"]:
+        k = str(k)
+        if k.endswith("running_mean"):  # BatchNorm slots are recognised by their buffers
+            sd[k] = torch.zeros(1)
+    return sd
+
+
+@pytest.mark.parametrize("tag", ["proj2", "pred2", "proj3"])
+def test_g8_mlp_oracle_matches_reference(tag):
+    from oracle import moco_ref
+    g = load_golden("g8_moco.npz")
+    sd = {k: (v.requires_grad_(True) if "running" not in k else v) for k, v in _g8_sd(g, tag).items()}
+    x = torch.from_numpy(g[f"{tag}/x"]).requires_grad_(True)
+    y = moco_ref.mlp_forward(sd, "", x)
+    y.backward(torch.from_numpy(g[f"{tag}/dy"]))
+    assert rel_err(y, g[f"{tag}/y"]) < 1e-5
+    assert rel_err(x.grad, g[f"{tag}/dx"]) < 1e-4
+    for k in g.files:
+        if k.startswith(f"{tag}/grad/"):
+            assert rel_err(sd[k[len(tag) + 6:]].grad, g[k]) < 1e-4, k
+
+
+def test_g8_contrastive_loss_and_lars():
+    from oracle import moco_ref
+    from ssl4gie_amd.Models.moco_v3.moco.optimizer import LARS
+    g = load_golden("g8_moco.npz")
+    q = torch.from_numpy(g["cl/q"]).requires_grad_(True)
+    loss = moco_ref.contrastive_loss(q, torch.from_numpy(g["cl/k"]), float(g["cl/T"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["cl/loss"])) < 1e-6
+    assert rel_err(q.grad, g["cl/dq"]) < 1e-5
+    # LARS: oracle restatement and the engine's host-side optimizer, both against the reference's steps
+    ps = [torch.from_numpy(g[f"lars/p0/{i}"]).clone() for i in range(3)]
+    mus = [torch.zeros_like(p) for p in ps]
+    host = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = LARS(host, lr=0.3, weight_decay=1e-2, momentum=0.9)
+    for step in range(3):
+        grads = [torch.from_numpy(g[f"lars/g{step}/{i}"]) for i in range(3)]
+        ps, mus = moco_ref.lars_step(ps, grads, mus, 0.3, 1e-2)
+        for p, gr in zip(host, grads):
+            p.grad = gr.clone()
+        opt.step()
+        for i in range(3):
+            assert rel_err(ps[i], g[f"lars/p{step + 1}/{i}"]) < 1e-6 or float(ps[i].abs().max()) == 0
+            assert torch.allclose(host[i].detach(), torch.from_numpy(g[f"lars/p{step + 1}/{i}"]), rtol=1e-5, atol=1e-7)
+
+
+def test_moco_schema_and_trainable_count():
+    from functools import partial
+    from ssl4gie_amd.Models.moco_v3.moco import builder
+    from ssl4gie_amd.Models.resnet import resnet50
+    m = builder.MoCo_ResNet(partial(resnet50, zero_init_residual=True), 256, 4096, 1.0)
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 35058752
+    ks = set(m.state_dict())
+    assert {"base_encoder.fc.0.weight", "base_encoder.fc.4.running_mean", "momentum_encoder.fc.3.weight",
+            "predictor.0.weight", "predictor.3.weight"} <= ks
+    assert not any(k.startswith("predictor.4") for k in ks)  # predictor has no last BN
+    assert float(m.base_encoder.layer1[0].bn3.weight.abs().max()) == 0.0  # zero_init_residual
+    assert all(not p.requires_grad for p in m.momentum_encoder.parameters())

@@ -83,3 +83,35 @@ def test_bucketed_allreduce_world2():
         assert during >= 2, "buckets must be launched while backward is still running"
         assert total == during + 1
         assert abs(lm - 1.5) < 1e-6
+
+
+def _syncbn_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssl4gie_amd.resnet_engine import combine_batch_stats
+    g = torch.Generator().manual_seed(5)
+    full = torch.randn(7 + 13, 24, generator=g) * 3 + 2  # ranks hold 7 and 13 rows
+    mine = full[:7] if rank == 0 else full[7:]
+    mean, var, total = combine_batch_stats(mine.mean(0), mine.var(0, unbiased=False), mine.shape[0])
+    ok = (torch.allclose(mean, full.mean(0), atol=1e-5) and torch.allclose(var, full.var(0, unbiased=False), atol=1e-4)
+          and float(total) == 20.0)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_syncbn_stat_combine_world2():
+    """exchange step of SyncBatchNorm (uneven per-rank row counts) == statistics of the pooled rows"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29611
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res
