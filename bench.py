@@ -145,6 +145,77 @@ def bench_depth(a):
         dist.destroy_process_group()
 
 
+def bench_moco(a):
+    """configs[2]: MoCo-v3 ResNet50 step (two views, base fwd+bwd x2, momentum fwd x2, EMA, InfoNCE,
+    LARS; main_moco.py:321-370 defaults: dim 256, mlp 4096, T 1.0, m 0.99, lr 0.6 bs/256, wd 1e-6)."""
+    from functools import partial
+    import torch.distributed as dist
+    from ssl4gie_amd import _lib, parallel
+    from ssl4gie_amd.Models.moco_v3.moco import builder
+    from ssl4gie_amd.Models.moco_v3.moco.optimizer import LARS
+    from ssl4gie_amd.Models.resnet import resnet50
+    _lib.load()
+    rank, local, world = parallel.init_from_env()
+    assert world == a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = a.batch
+    torch.manual_seed(0)
+    model = builder.MoCo_ResNet(partial(resnet50, zero_init_residual=True), 256, 4096, 1.0)
+    if world > 1:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)  # main_moco.py:196
+    model.to(dev).set_precision(a.precision)
+    ddp = parallel.DataParallel(model) if world > 1 else None
+    # lr: the reference ramps 0 -> 0.6 bs/256 over 10 warm-up epochs (main_moco.py:420-428); a
+    # throughput run on uncorrelated noise views uses an early-warm-up value
+    opt = LARS([p for p in model.parameters() if p.requires_grad], lr=0.03 * B * world / 256,
+               weight_decay=1e-6, momentum=0.9)
+    g = torch.Generator("cpu").manual_seed(rank)
+    x1 = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    x2 = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = (ddp or model)(x1, x2, 0.99)
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        ips = B * world * a.steps / dt
+        print(json.dumps({
+            "metric": "image pairs/sec (fwd+bwd+LARS) MoCo-v3 ResNet50 224x224 (BASELINE.json configs[2])",
+            "value": round(ips, 1), "unit": "image pairs/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "MoCo_ResNet(resnet50, 256, 4096, T=1.0), m=0.99, two synthetic views "
+                                   "resident in HBM, LARS",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "model_mfma_frac": round(ips / world * 65.57 / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(float(loss.detach()), 5)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,12 +225,14 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--workload", default="mae", choices=["mae", "depth"],
+    ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco"],
                     help="mae = BASELINE.json configs[1] (the headline metric); depth = configs[3] "
                          "(ViT-B + DPT depth finetune step, bs 128/GPU) as an extra measurement")
     a = ap.parse_args()
     if a.workload == "depth":
         return bench_depth(a)
+    if a.workload == "moco":
+        return bench_moco(a)
 
     import torch.distributed as dist
     from ssl4gie_amd import _lib, parallel
