@@ -261,7 +261,7 @@ int ssl4gie_subsample2(const void* x, void* y, int dtype, int B, int H, int W, i
  * statistics in fp32 (biased variance for the normalisation, unbiased for running_var, momentum as
  * nn.BatchNorm: running = (1-m) running + m batch), y = act(xhat gamma + beta (+ res)) with
  * act = ReLU if `relu`; gamma / beta / res / running_* may be NULL.  mean / rstd [C] are outputs
- * kept for backward (with training == 0 they are INPUTS: the caller's running statistics, no
+ * kept for backward; `workspace` (ssl4gie_bn_workspace_bytes) is always required (with training == 0 they are INPUTS: the caller's running statistics, no
  * reduction runs).  Backward: g = relu ? (y > 0 ? dy : 0) : dy; dgamma = sum g xhat, dbeta = sum g,
  * dx = gamma rstd (g - mean(g) - xhat mean(g xhat)); dres (optional) = g. */
 size_t ssl4gie_bn_workspace_bytes(long long rows, int C);
@@ -286,7 +286,8 @@ int ssl4gie_bn_bwd_reduce(const void* dy, const void* y, const void* x, const fl
                           int dtype, long long rows, int C, void* stream);
 int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma,
                          const float* mean, const float* rstd, const float* sums, float inv_count,
-                         void* dx, int relu, int dtype, long long rows, int C, void* stream);
+                         void* dx, int relu, float* workspace, int dtype, long long rows, int C,
+                         void* stream);
 /* MoCo._update_momentum_encoder (moco/builder.py:57-61): dst = dst m + src (1 - m), fp32, over a
  * whole parameter-arena slice */
 int ssl4gie_ema_update(float* dst, const float* src, float m, long long n, void* stream);

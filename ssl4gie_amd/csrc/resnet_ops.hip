@@ -60,18 +60,28 @@ template <> DEVI f32x4 pk<float>(const float (&f)[4]) { return f32x4{f[0], f[1],
 template <typename T>
 __global__ void stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H,
                                    int W, int Ho, int Wo, long long ld, long long total) {
+    // one thread = 8 consecutive columns of one output row (ld % 8 == 0): a 16-B (bf16) store
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const long long m = idx / ld;
-    const int col = (int)(idx % ld);
-    float v = 0.f;
-    if (col < 147) {
-        const int tap = col / 3, c = col % 3, dy = tap / 7, dx = tap % 7;
-        const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((long long)Wo * Ho));
-        const int iy = 2 * oy + dy - 3, ix = 2 * ox + dx - 3;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((size_t)b * 3 + c) * H + iy) * W + ix];
+    const int cpr = (int)(ld >> 3);
+    const long long m = idx / cpr;
+    const int col0 = (int)(idx % cpr) * 8;
+    const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((long long)Wo * Ho));
+    const float* base = img + (size_t)b * 3 * H * W;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int col = col0 + j;
+        v[j] = 0.f;
+        if (col < 147) {
+            const int tap = col / 3, c = col - tap * 3, dy = tap / 7, dx = tap - dy * 7;
+            const int iy = 2 * oy + dy - 3, ix = 2 * ox + dx - 3;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = base[((size_t)c * H + iy) * W + ix];
+        }
     }
-    Elem<T>::st(cols + idx, v);
+    T* dst = cols + (size_t)m * ld + col0;
+#pragma unroll
+    for (int j = 0; j < 8; j += 4) st4(dst + j, f32x4{v[j], v[j + 1], v[j + 2], v[j + 3]});
 }
 
 // ------------------------------------------------------------------ stride-2 row subsampling
@@ -109,7 +119,10 @@ __global__ void subsample2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ 
 // ------------------------------------------------------------------ BatchNorm (training mode)
 // partial[blockIdx.y][0][c] = sum_r x[r, c], partial[..][1][c] = sum_r x^2 over this block's rows
 // (sums are taken about the pivot x[0, c] — written to `pivot` — so that E[d^2] - E[d]^2 does not
-// cancel catastrophically when |mean| >> std)
+// cancel catastrophically when |mean| >> std).
+// Lane mapping: a lane owns 4 channels.  With C >= 256 a wave spans 256 channels of one row and
+// gridDim.x strips cover C; with C < 256 (C/4 = 16 or 32 lanes per row) a wave folds 64 / (C/4) rows
+// per step and the lanes of equal channel group are combined by shuffles at the end.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x,
                                                        float* __restrict__ partial,
@@ -117,20 +130,32 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x,
                                                        int C) {
     __shared__ f32x4 red[3][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + lane) * 4;
+    const int cg = C >> 2;                       // channel groups per row
+    const int lpr = (cg < 64 && !(cg & (cg - 1))) ? cg : 64;  // lanes per row (fold only powers of 2)
+    const int rpw = 64 / lpr;                    // rows per wave step
+    const int c = (blockIdx.x * 64 + (lane % lpr)) * 4;
+    const int rsub = lane / lpr;
     f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
     if (c < C) {
         const f32x4 piv = ld4(x + c);
-        if (blockIdx.y == 0 && wave == 0) st4(pivot + c, piv);
-        for (long long r = (long long)blockIdx.y * 4 + wave; r < rows; r += (long long)gridDim.y * 4) {
+        if (blockIdx.y == 0 && wave == 0 && rsub == 0) st4(pivot + c, piv);
+        for (long long r = ((long long)blockIdx.y * 4 + wave) * rpw + rsub; r < rows;
+             r += (long long)gridDim.y * 4 * rpw) {
             const f32x4 v = ld4(x + (size_t)r * C + c) - piv;
             s += v;
             q += v * v;
         }
     }
+    for (int o = lpr; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] += __shfl_xor(s[j], o, 64);
+            q[j] += __shfl_xor(q[j], o, 64);
+        }
+    }
     if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
     __syncthreads();
-    if (wave == 0 && c < C) {
+    if (wave == 0 && c < C && rsub == 0) {
 #pragma unroll
         for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
         float* p = partial + (size_t)blockIdx.y * 2 * C;
@@ -158,30 +183,55 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
 }
-// y = act(xhat gamma + beta (+ res))
+// per-channel affine of the normalisation: y = x * coef[c] + coef[C + c]
+__global__ void bn_fwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ coef, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float a = rstd[c] * (gamma ? gamma[c] : 1.f);
+    coef[c] = a;
+    coef[C + c] = (beta ? beta[c] : 0.f) - mean[c] * a;
+}
+// dx = coef[c] g + coef[C+c] x + coef[2C+c]   (expansion of gamma rstd (g - s1/n - xhat s2/n))
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ sums,
+                                   float inv_n, float* __restrict__ coef, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float r = rstd[c], a = r * (gamma ? gamma[c] : 1.f);
+    const float s1 = sums[c] * inv_n, s2 = sums[C + c] * inv_n;
+    coef[c] = a;
+    coef[C + c] = -a * r * s2;
+    coef[2 * C + c] = a * (mean[c] * r * s2 - s1);
+}
+// y = act(x coef[c] + coef[C + c] (+ res))
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
-                                const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const T* __restrict__ res,
-                                T* __restrict__ y, int relu, int C, long long total) {
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef,
+                                const T* __restrict__ res, T* __restrict__ y, int relu, int C,
+                                long long total) {
     constexpr int V = V16<T>::N;
     const long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (idx >= total) return;
     const int c = (int)(idx % C);
-    float f[V], r[V];
+    float f[V], r[V], a[V], b[V];
     un<T>(*(const typename V16<T>::raw*)(x + idx), f);
     if (res) un<T>(*(const typename V16<T>::raw*)(res + idx), r);
 #pragma unroll
+    for (int j = 0; j < V; j += 4) {
+        *(f32x4*)(a + j) = ld4(coef + c + j);
+        *(f32x4*)(b + j) = ld4(coef + C + c + j);
+    }
+#pragma unroll
     for (int j = 0; j < V; ++j) {
-        float v = (f[j] - mean[c + j]) * rstd[c + j] * (gamma ? gamma[c + j] : 1.f) +
-                  (beta ? beta[c + j] : 0.f);
+        float v = f[j] * a[j] + b[j];
         if (res) v += r[j];
         f[j] = (relu && v < 0.f) ? 0.f : v;
     }
     *(typename V16<T>::raw*)(y + idx) = pk<T>(f);
 }
 // g = relu ? (y > 0 ? dy : 0) : dy;  partial[blk][0][c] = sum g, [1][c] = sum g * xhat; when the block
-// had a residual input its gradient is g itself (dres, optional)
+// had a residual input its gradient is g itself (dres, optional).  Lane mapping as bn_stats_kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
@@ -189,11 +239,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     float* __restrict__ partial, int relu, long long rows, int C) {
     __shared__ f32x4 red[3][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + lane) * 4;
+    const int cg = C >> 2;
+    const int lpr = (cg < 64 && !(cg & (cg - 1))) ? cg : 64;
+    const int rpw = 64 / lpr;
+    const int c = (blockIdx.x * 64 + (lane % lpr)) * 4;
+    const int rsub = lane / lpr;
     f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
     if (c < C) {
         const f32x4 mu = ld4(mean + c), rs = ld4(rstd + c);
-        for (long long r = (long long)blockIdx.y * 4 + wave; r < rows; r += (long long)gridDim.y * 4) {
+        for (long long r = ((long long)blockIdx.y * 4 + wave) * rpw + rsub; r < rows;
+             r += (long long)gridDim.y * 4 * rpw) {
             const size_t o = (size_t)r * C + c;
             f32x4 g = ld4(dy + o);
             if (relu) {
@@ -207,9 +262,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             q += g * xh;
         }
     }
+    for (int o = lpr; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] += __shfl_xor(s[j], o, 64);
+            q[j] += __shfl_xor(q[j], o, 64);
+        }
+    }
     if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
     __syncthreads();
-    if (wave == 0 && c < C) {
+    if (wave == 0 && c < C && rsub == 0) {
 #pragma unroll
         for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
         float* p = partial + (size_t)blockIdx.y * 2 * C;
@@ -217,27 +279,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         st4(p + C + c, q);
     }
 }
-// dx = gamma rstd (g - sum_g / n - xhat sum_gx / n)
+// dx = coef[c] g + coef[C + c] x + coef[2C + c]
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
-                                    const T* __restrict__ x, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sums, T* __restrict__ dx, int relu,
-                                    float inv_n, int C, long long total) {
+                                    const T* __restrict__ x, const float* __restrict__ coef,
+                                    T* __restrict__ dx, int relu, int C, long long total) {
     constexpr int V = V16<T>::N;
     const long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (idx >= total) return;
     const int c = (int)(idx % C);
-    float g[V], xv[V], yy[V];
+    float g[V], xv[V], yy[V], a[V], b[V], d[V];
     un<T>(*(const typename V16<T>::raw*)(dy + idx), g);
     un<T>(*(const typename V16<T>::raw*)(x + idx), xv);
     if (relu) un<T>(*(const typename V16<T>::raw*)(y + idx), yy);
 #pragma unroll
+    for (int j = 0; j < V; j += 4) {
+        *(f32x4*)(a + j) = ld4(coef + c + j);
+        *(f32x4*)(b + j) = ld4(coef + C + c + j);
+        *(f32x4*)(d + j) = ld4(coef + 2 * C + c + j);
+    }
+#pragma unroll
     for (int j = 0; j < V; ++j) {
         const float gg = (relu && !(yy[j] > 0.f)) ? 0.f : g[j];
-        const float xh = (xv[j] - mean[c + j]) * rstd[c + j];
-        const float gm = gamma ? gamma[c + j] : 1.f;
-        g[j] = gm * rstd[c + j] * (gg - sums[c + j] * inv_n - xh * sums[C + c + j] * inv_n);
+        g[j] = a[j] * gg + b[j] * xv[j] + d[j];
     }
     *(typename V16<T>::raw*)(dx + idx) = pk<T>(g);
 }
@@ -328,16 +392,16 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dy, T* __restrict__
 static bool rdt(int dt) { return dt == SSL4GIE_F32 || dt == SSL4GIE_BF16; }
 static int rvn(int dt) { return dt == SSL4GIE_BF16 ? 8 : 4; }
 static int bn_parts(long long rows) {
-    long long p = (rows + 255) / 256;
+    long long p = (rows + 1023) / 1024;
     return (int)(p < 1 ? 1 : (p > 512 ? 512 : p));
 }
 
 extern "C" int ssl4gie_stem_im2col7x7(const float* img, void* cols, int dtype, int B, int H, int W,
                                       long long ld, void* stream) {
-    REQUIRE(img && cols && rdt(dtype) && B > 0 && H > 0 && W > 0 && ld >= 147);
+    REQUIRE(img && cols && rdt(dtype) && B > 0 && H > 0 && W > 0 && ld >= 147 && ld % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long long total = (long long)B * Ho * Wo * ld;
+    const long long total = (long long)B * Ho * Wo * (ld / 8);
     RN_LAUNCH(dtype, stem_im2col_kernel, total, img, (T*)cols, B, H, W, Ho, Wo, ld, total);
     return 0;
 }
@@ -356,7 +420,7 @@ extern "C" int ssl4gie_subsample2(const void* x, void* y, int dtype, int B, int 
     return 0;
 }
 extern "C" size_t ssl4gie_bn_workspace_bytes(long long rows, int C) {
-    return (((size_t)bn_parts(rows) + 1) * 2 + 1) * C * sizeof(float);
+    return (((size_t)bn_parts(rows) + 1) * 2 + 1 + 3) * C * sizeof(float);  // partials, sums, pivot, coef
 }
 // forward: statistics over the rows of x [rows, C] (biased variance), optional running-stat update,
 // y = act(xhat gamma + beta (+ res)); mean / rstd [C] are kept for backward
@@ -365,34 +429,40 @@ extern "C" int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* be
                               float* running_var, float momentum, float eps, int relu,
                               int training, float* workspace, int dtype, long long rows, int C,
                               void* stream) {
-    REQUIRE(x && y && mean && rstd && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
-    REQUIRE(!training || workspace);
+    REQUIRE(x && y && mean && rstd && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
+    float* coef = workspace;  // workspace: [coef 3C][partials parts x 2C][sums 2C][pivot C]
+    const long long total = rows * C;
     if (!training) {  // evaluation: mean / rstd are INPUTS (running statistics prepared by the caller)
-        const long long total = rows * C;
-        RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, mean, rstd, gamma, beta,
-                  (const T*)res, (T*)y, relu, C, total);
+        hipLaunchKernelGGL(bn_fwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd,
+                           gamma, beta, coef, C);
+        LAUNCH_CHECK();
+        RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, coef, (const T*)res, (T*)y,
+                  relu, C, total);
         return 0;
     }
     const int parts = bn_parts(rows);
     dim3 grid((C + 255) / 256, parts), block(256);
-    float* sums = workspace + (size_t)parts * 2 * C;
+    float* partial = workspace + 3 * (size_t)C;
+    float* sums = partial + (size_t)parts * 2 * C;
     float* pivot = sums + 2 * C;
     if (dtype == SSL4GIE_BF16)
-        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, workspace,
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, partial,
                            pivot, rows, C);
     else
-        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, block, 0, st, (const float*)x, workspace,
+        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, block, 0, st, (const float*)x, partial,
                            pivot, rows, C);
     LAUNCH_CHECK();
-    int rc = ssl4gie_internal_reduce_partials(workspace, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+    int rc = ssl4gie_internal_reduce_partials(partial, sums, parts, 2 * C, (size_t)2 * C, 0, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, pivot, mean,
                        rstd, running_mean, running_var, (float)rows, eps, momentum, C);
     LAUNCH_CHECK();
-    const long long total = rows * C;
-    RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, mean, rstd, gamma, beta,
-              (const T*)res, (T*)y, relu, C, total);
+    hipLaunchKernelGGL(bn_fwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd, gamma,
+                       beta, coef, C);
+    LAUNCH_CHECK();
+    RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, coef, (const T*)res, (T*)y, relu,
+              C, total);
     return 0;
 }
 // backward: dgamma / dbeta (overwritten or accumulated), dx, and (optional) the residual gradient
@@ -405,21 +475,26 @@ extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, cons
     hipStream_t st = (hipStream_t)stream;
     const int parts = bn_parts(rows);
     dim3 grid((C + 255) / 256, parts), block(256);
+    float* coef = workspace;
+    float* partial = workspace + 3 * (size_t)C;
     if (dtype == SSL4GIE_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy,
-                           (const bf16_t*)y, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, workspace,
+                           (const bf16_t*)y, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, partial,
                            relu, rows, C);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)dy,
-                           (const float*)y, (const float*)x, mean, rstd, (float*)dres, workspace, relu,
+                           (const float*)y, (const float*)x, mean, rstd, (float*)dres, partial, relu,
                            rows, C);
     LAUNCH_CHECK();
-    float* sums = workspace + (size_t)parts * 2 * C;
-    int rc = ssl4gie_internal_reduce_partials(workspace, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+    float* sums = partial + (size_t)parts * 2 * C;
+    int rc = ssl4gie_internal_reduce_partials(partial, sums, parts, 2 * C, (size_t)2 * C, 0, st);
     if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd, gamma,
+                       sums, 1.0f / (float)rows, coef, C);
+    LAUNCH_CHECK();
     const long long total = rows * C;
     RN_LAUNCH(dtype, bn_bwd_apply_kernel, total / rvn(dtype), (const T*)dy, (const T*)y, (const T*)x,
-              mean, rstd, gamma, sums, (T*)dx, relu, 1.0f / (float)rows, C, total);
+              coef, (T*)dx, relu, C, total);
     // dbeta = sum g, dgamma = sum g xhat
     if (dbeta) {
         rc = ssl4gie_internal_reduce_partials(sums, dbeta, 1, C, (size_t)2 * C, accumulate, st);
@@ -510,16 +585,17 @@ extern "C" int ssl4gie_bn_stats(const void* x, float* mean, float* var, float* w
     hipStream_t st = (hipStream_t)stream;
     const int parts = bn_parts(rows);
     dim3 grid((C + 255) / 256, parts), block(256);
-    float* sums = workspace + (size_t)parts * 2 * C;
+    float* partial = workspace + 3 * (size_t)C;
+    float* sums = partial + (size_t)parts * 2 * C;
     float* pivot = sums + 2 * C;
     if (dtype == SSL4GIE_BF16)
-        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, workspace,
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, partial,
                            pivot, rows, C);
     else
-        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, block, 0, st, (const float*)x, workspace,
+        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, block, 0, st, (const float*)x, partial,
                            pivot, rows, C);
     LAUNCH_CHECK();
-    int rc = ssl4gie_internal_reduce_partials(workspace, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+    int rc = ssl4gie_internal_reduce_partials(partial, sums, parts, 2 * C, (size_t)2 * C, 0, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_local_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, pivot,
                        mean, var, (float)rows, C);
@@ -537,26 +613,31 @@ extern "C" int ssl4gie_bn_bwd_reduce(const void* dy, const void* y, const void* 
     hipStream_t st = (hipStream_t)stream;
     const int parts = bn_parts(rows);
     dim3 grid((C + 255) / 256, parts), block(256);
+    float* partial = workspace + 3 * (size_t)C;
     if (dtype == SSL4GIE_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy,
-                           (const bf16_t*)y, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, workspace,
+                           (const bf16_t*)y, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, partial,
                            relu, rows, C);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)dy,
-                           (const float*)y, (const float*)x, mean, rstd, (float*)dres, workspace, relu,
+                           (const float*)y, (const float*)x, mean, rstd, (float*)dres, partial, relu,
                            rows, C);
     LAUNCH_CHECK();
-    return ssl4gie_internal_reduce_partials(workspace, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+    return ssl4gie_internal_reduce_partials(partial, sums, parts, 2 * C, (size_t)2 * C, 0, st);
 }
 extern "C" int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma,
                                     const float* mean, const float* rstd, const float* sums,
-                                    float inv_count, void* dx, int relu, int dtype, long long rows,
-                                    int C, void* stream) {
-    REQUIRE(dy && x && mean && rstd && sums && dx && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
+                                    float inv_count, void* dx, int relu, float* workspace, int dtype,
+                                    long long rows, int C, void* stream) {
+    REQUIRE(dy && x && mean && rstd && sums && dx && workspace && rdt(dtype) && rows > 0 && C > 0 &&
+            C % 8 == 0);
     REQUIRE(!relu || y);
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd, gamma,
+                       sums, inv_count, workspace, C);
+    LAUNCH_CHECK();
     const long long total = rows * C;
     RN_LAUNCH(dtype, bn_bwd_apply_kernel, total / rvn(dtype), (const T*)dy, (const T*)y, (const T*)x,
-              mean, rstd, gamma, sums, (T*)dx, relu, inv_count, C, total);
+              workspace, (T*)dx, relu, C, total);
     return 0;
 }

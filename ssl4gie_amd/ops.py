@@ -531,7 +531,7 @@ def stem_im2col7x7(imgs, dtype):
     B, C, H, W = imgs.shape
     assert C == 3
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    ld = k_pad(147, dtype)
+    ld = k_pad(147, dtype) if dtype == torch.bfloat16 else 152  # multiple of 8 columns
     cols = torch.empty(B * Ho * Wo, ld, dtype=dtype, device=imgs.device)
     _lib.check(_lib.load().ssl4gie_stem_im2col7x7(ptr(imgs), ptr(cols), code(dtype), B, H, W, ld,
                                                   stream()), "stem_im2col7x7")
@@ -564,9 +564,7 @@ def bn_fwd(x2d, gamma, beta, res, running_mean, running_var, momentum, eps, relu
     if training:
         mean = torch.empty(C, dtype=torch.float32, device=x2d.device)
         rstd = torch.empty(C, dtype=torch.float32, device=x2d.device)
-        ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
-    else:
-        ws = None
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
     _lib.check(L.ssl4gie_bn_fwd(ptr(x2d), ptr(gamma), ptr(beta), ptr(res), ptr(y), ptr(mean), ptr(rstd),
                                 ptr(running_mean), ptr(running_var), float(momentum), float(eps),
                                 int(relu), int(training), ptr(ws), code(x2d.dtype), rows, C, stream()),
@@ -654,10 +652,11 @@ def bn_bwd_apply(dy2d, y2d, x2d, gamma, mean, rstd, sums, inv_count, relu):
     _dev(dy2d, y2d, x2d, gamma, mean, rstd, sums)
     rows, C = x2d.shape
     dx = torch.empty_like(x2d)
-    _lib.check(_lib.load().ssl4gie_bn_bwd_apply(ptr(dy2d), ptr(y2d), ptr(x2d), ptr(gamma), ptr(mean),
-                                                ptr(rstd), ptr(sums), float(inv_count), ptr(dx),
-                                                int(relu), code(x2d.dtype), rows, C, stream()),
-               "bn_bwd_apply")
+    L = _lib.load()
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_bwd_apply(ptr(dy2d), ptr(y2d), ptr(x2d), ptr(gamma), ptr(mean), ptr(rstd),
+                                      ptr(sums), float(inv_count), ptr(dx), int(relu), ptr(ws),
+                                      code(x2d.dtype), rows, C, stream()), "bn_bwd_apply")
     return dx
 
 
