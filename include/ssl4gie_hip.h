@@ -66,6 +66,26 @@ enum {
     SSL4GIE_EPI_BIAS_GELU_GRAD = 5, /* u = acc + bias[n]; C = gelu'(u); out2 = gelu(u) */
     SSL4GIE_EPI_MUL_AUX = 6         /* C = acc * aux[m,n]                  */
 };
+/* Implicit patch-matrix operand of a 3x3 / pad-1 convolution over a channels-last bf16 map
+ * x [B, H, W, C] (ssl4gie_gemm_desc::conv).  The patch matrix
+ *     P[(b, oy, ox), (dy*3 + dx)*C + c] = act(x[b, oy*s + dy - 1, ox*s + dx - 1, c])   (0 outside)
+ * of ssl4gie_im2col3x3 is never materialised: the 256x256 kernels gather its K-tiles straight
+ * from the map with per-lane LDS-DMA addresses (out-of-image taps read a zero page), act = ReLU
+ * applied to the MFMA fragments when `relu`.  Replaces the cuDNN implicit-GEMM convolutions
+ * behind nn.Conv2d(k=3, p=1) in Models/DPT_decoder.py:212-233,397-447,469-478 and torchvision
+ * Bottleneck.conv2.
+ *   NT (forward / stride-1 data gradient):  A := P, d->A = x, M = B*Ho*Wo, K = 9*C, C % 64 == 0;
+ *       sAm / sAk are ignored.
+ *   TN (weight gradient dW = dY^T P):       B := P, d->B = x, K = B*Ho*Wo (% 64 == 0), N = 9*C,
+ *       C % 8 == 0; sBk / sBn are ignored.
+ * Limits: bf16 operands, stride in {1, 2}, map smaller than 2 GiB, Wo >= 2.  A descriptor that
+ * carries `conv` and does not meet them is rejected with SSL4GIE_EARG (no fallback inside). */
+typedef struct ssl4gie_conv3x3_geom {
+    int B, H, W, C;
+    int stride;
+    int relu;
+} ssl4gie_conv3x3_geom;
+
 typedef struct ssl4gie_gemm_desc {
     int M, N, K;
     int batch1, batch2; /* >=1 */
@@ -90,6 +110,9 @@ typedef struct ssl4gie_gemm_desc {
      * dW = dY^T X (A = dY^T): fused into the 256x256 TN kernel (one extra MFMA against a ones
      * fragment per A fragment), a separate column-sum pass on the other paths.  Needs sAm == 1. */
     float* colsum_a;
+    /* optional: the K-major operand (A of an NT product, B of a TN product) is the implicit 3x3
+     * patch matrix of this map instead of a matrix in memory (see ssl4gie_conv3x3_geom) */
+    const ssl4gie_conv3x3_geom* conv;
 } ssl4gie_gemm_desc;
 size_t ssl4gie_gemm_workspace_bytes(const ssl4gie_gemm_desc* d);
 int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t workspace_bytes,

@@ -18,6 +18,11 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_BIAS_GELU_G
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
 
+class Conv3x3Geom(C.Structure):
+    """ssl4gie_conv3x3_geom: the channels-last map behind an implicit patch-matrix operand"""
+    _fields_ = [("B", i32), ("H", i32), ("W", i32), ("C", i32), ("stride", i32), ("relu", i32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("M", i32), ("N", i32), ("K", i32), ("batch1", i32), ("batch2", i32),
@@ -26,7 +31,7 @@ class GemmDesc(C.Structure):
         ("C", vp), ("ldc", i64), ("sCb1", i64), ("sCb2", i64),
         ("dtype_ab", i32), ("dtype_c", i32), ("alpha", f32), ("epilogue", i32),
         ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("out2", vp),
-        ("accumulate", i32), ("colsum_a", vp),
+        ("accumulate", i32), ("colsum_a", vp), ("conv", C.POINTER(Conv3x3Geom)),
     ]
 
 

@@ -19,6 +19,8 @@
 // Replaces the cuBLAS calls behind nn.Linear in timm Block — reference call
 // sites Models/mae/models_mae.py:39-41,47,53-55,59 and Models/models.py:171-173.
 #include "gemm_internal.h"
+
+#include <mutex>
 #include "prof.h"
 #include <stdlib.h>
 
@@ -741,6 +743,47 @@ static int tn_splits(const ssl4gie_gemm_desc* d) {
     return s;
 }
 
+// ---- implicit 3x3 patch-matrix operand (ssl4gie_gemm_desc::conv)
+bool ssl4gie_internal_conv_geom_ok(const ssl4gie_conv3x3_geom* g) {
+    if (!g || g->B < 1 || g->H < 1 || g->W < 1 || g->C < 8 || g->C % 8 != 0) return false;
+    if (g->stride != 1 && g->stride != 2) return false;
+    const long long Ho = (g->H - 1) / g->stride + 1, Wo = (g->W - 1) / g->stride + 1;
+    if (Wo < 2 || Ho * Wo < 2 || g->H > 32767 || g->W > 32767) return false;
+    // signed 32-bit byte offsets into the map (incl. the row above it), pixel index < 2^31
+    return ((long long)g->B * g->H + 1) * g->W * g->C * 2 < (1LL << 31) &&
+           (long long)g->B * Ho * Wo < (1LL << 31);
+}
+// 256 zero bytes per device, allocated on first use (never freed: lives as long as the library)
+static const void* conv_zero_page(int* rc) {
+    static void* page[64] = {nullptr};
+    static std::mutex mu;
+    int dev = 0;
+    *rc = (int)hipGetDevice(&dev);
+    if (*rc) return nullptr;
+    if (dev < 0 || dev >= 64) { *rc = ARG_ERR; return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!page[dev]) {
+        void* p = nullptr;
+        *rc = (int)hipMalloc(&p, 256);
+        if (*rc) return nullptr;
+        *rc = (int)hipMemset(p, 0, 256);
+        if (!*rc) *rc = (int)hipStreamSynchronize(nullptr);  // visible to every stream from here on
+        if (*rc) return nullptr;
+        page[dev] = p;
+    }
+    return page[dev];
+}
+int ssl4gie_internal_conv_k(const ssl4gie_conv3x3_geom* g, ConvK* k) {
+    if (!ssl4gie_internal_conv_geom_ok(g)) return ARG_ERR;
+    const int Ho = (g->H - 1) / g->stride + 1, Wo = (g->W - 1) / g->stride + 1;
+    k->H = g->H; k->W = g->W; k->C = g->C; k->Wo = Wo; k->HoWo = Ho * Wo; k->stride = g->stride;
+    conv_magic((unsigned)Wo, &k->mg_wo, &k->sh_wo);
+    conv_magic((unsigned)(Ho * Wo), &k->mg_hw, &k->sh_hw);
+    int rc = 0;
+    k->zero = conv_zero_page(&rc);
+    return rc;
+}
+
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 // workspace layout of the TN paths: [slabs (splits > 1)] [column-sum scratch (colsum_a)]
 struct TnPlan {
@@ -787,8 +830,10 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     hipStream_t st = (hipStream_t)stream;
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate};
 
+    REQUIRE(!d->conv || (d->dtype_ab == SSL4GIE_BF16 && d->batch1 * d->batch2 == 1));
     if (nt_ok(d)) {
         if (ssl4gie_internal_nt256_ok(d)) return ssl4gie_internal_nt256_launch(d, st);
+        REQUIRE(!d->conv);  // the gathered operand only exists in the 256x256 kernels
         const int tm = (d->M + BT_M - 1) / BT_M, tn = (d->N + BT_N - 1) / BT_N;
         const int ntiles = tm * tn;
         dim3 grid(ntiles < NT_MAX_WGS ? ntiles : NT_MAX_WGS), block(256);
@@ -817,6 +862,7 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
         const int tm = (d->M + BT_M - 1) / BT_M, tn = (d->N + BT_N - 1) / BT_N;
         const TnPlan p = tn_plan(d);
         const int splits = p.splits;
+        REQUIRE(!d->conv || p.big);
         REQUIRE(p.total == 0 || (workspace && workspace_bytes >= p.total));
         float* slabs = (float*)workspace;
         float* cs_ws = p.cs_bytes ? (float*)((char*)workspace + p.cs_off) : nullptr;
@@ -850,6 +896,7 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
         return 0;
     }
     // generic
+    REQUIRE(!d->conv);
     GemmArgs g;
     g.M = d->M; g.N = d->N; g.K = d->K; g.batch2 = d->batch2;
     g.A = d->A; g.sAm = d->sAm; g.sAk = d->sAk; g.sAb1 = d->sAb1; g.sAb2 = d->sAb2;

@@ -38,6 +38,33 @@ DEVI void p_glds2(const void* sbase, unsigned v0, unsigned v1, unsigned l0, unsi
         : "memory");
 }
 
+// the same with per-lane 64-bit addresses (gathered operands: a lane may point at the zero page)
+DEVI void p_glds2v(const void* a0, const void* a1, unsigned l0, unsigned l1) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(a0), "v"(a1), "s"(l0), "s"(l1)
+        : "memory");
+}
+
+// n / d for n < 2^31 with (mg, sh) from conv_magic
+DEVI unsigned p_fastdiv(unsigned n, unsigned mg, unsigned sh) { return __umulhi(n, mg) >> sh; }
+
+// ReLU on packed bf16: a negative bf16 is a negative int16
+DEVI bf16x8 p_relu8(bf16x8 v) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, v), z));
+}
+
 #define P_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // fp32 outputs of one wave's 128 x 64 sub-tile.  acc[mt][nt]: rows rbase + 16 mt + (l & 15),

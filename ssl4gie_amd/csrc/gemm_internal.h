@@ -14,6 +14,27 @@ struct EpiArgs {
     int accumulate;
 };
 
+// Implicit 3x3 / pad-1 patch-matrix operand (ssl4gie_gemm_desc::conv): device-side geometry with
+// the divisions by Wo and Ho*Wo turned into multiply-high + shift (conv_magic, n < 2^31).
+struct ConvK {
+    int H, W, C, Wo, HoWo, stride;
+    unsigned mg_wo, sh_wo, mg_hw, sh_hw;
+    const void* zero;  // >= 16 zero bytes: the source of every out-of-image tap
+};
+static inline void conv_magic(unsigned d, unsigned* mg, unsigned* sh) {  // d >= 2
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    *mg = (unsigned)((1ull << (31 + s)) / d + 1);
+    *sh = s - 1;
+}
+// pixels of the conv output / whether the gathered 256x256 kernels can run this geometry
+static inline long long conv_rows(const ssl4gie_conv3x3_geom* g) {
+    const long long Ho = (g->H - 1) / g->stride + 1, Wo = (g->W - 1) / g->stride + 1;
+    return (long long)g->B * Ho * Wo;
+}
+bool ssl4gie_internal_conv_geom_ok(const ssl4gie_conv3x3_geom* g);
+int ssl4gie_internal_conv_k(const ssl4gie_conv3x3_geom* g, ConvK* k);  // fills k (zero page incl.)
+
 // 256x256x64 ping-pong NT kernel (gemm_nt256.hip): C[M,N] = A[M,K] B[N,K]^T with the fused
 // epilogues.  `nt256_ok` says whether the descriptor (already known to satisfy the NT fast-path
 // layout rules) is worth / able to run on it; `nt256_launch` enqueues it.

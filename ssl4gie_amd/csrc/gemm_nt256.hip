@@ -125,11 +125,14 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
     }
 }
 
-template <typename TC, int MODE>
+// CONV: 0 = A is a matrix; 1 = A is the implicit 3x3 patch matrix of the map at `A` (geometry cg,
+// header of ssl4gie_conv3x3_geom); 2 = the same with ReLU applied to the A fragments.
+template <typename TC, int MODE, int CONV>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
     TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e,
-    int dbg_skip_epilogue /* ablation knob: 1 = no epilogue (timing only, wrong output) */) {
+    int dbg_skip_epilogue /* ablation knob: 1 = no epilogue (timing only, wrong output) */,
+    ConvK cg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -153,6 +156,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     // scalars on purpose: an indexed array can end up in scratch, and a scratch reload is a VMEM
     // load whose compiler-inserted wait would drain the LDS-DMA stream)
     unsigned v0_0 = 0, v0_1 = 0, v1_0 = 0, v1_1 = 0, v2_0 = 0, v2_1 = 0, v3_0 = 0, v3_1 = 0;
+    // CONV: v1_* / v3_* hold the (signed) byte offset of tap (0, 0) of the lane's output pixel and
+    // y1_* / y3_* its coordinates (y0 << 16 | x0 & 0xffff, y0 = oy*s - 1, x0 = ox*s - 1)
+    unsigned y1_0 = 0, y1_1 = 0, y3_0 = 0, y3_1 = 0;
+    const int c_H = cg.H, c_W = cg.W, c_C = cg.C, c_Wo = cg.Wo, c_HoWo = cg.HoWo, c_s = cg.stride;
+    const unsigned c_mgw = cg.mg_wo, c_shw = cg.sh_wo, c_mgh = cg.mg_hw, c_shh = cg.sh_hw;
+    const char* c_zero = (const char*)cg.zero;
+    const int c_cpt = c_C / P_BK;  // K-tiles per tap
     auto point_at = [&](int ti) {
         const int tile = pos + ti * G;
         const int sm0 = (tile / tiles_n) * P_BM, sn0 = (tile % tiles_n) * P_BN;
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             if (is_a) {
                 int ra = sm0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
                 ra = ra < M ? ra : M - 1;
+                if constexpr (CONV != 0) return (unsigned)ra;  // decomposed below
                 return (unsigned)(((long long)ra * lda + c * 8) * 2);
             }
             int rb = sn0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
@@ -172,9 +183,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         v1_0 = offs(0, 0, true);  v1_1 = offs(1, 0, true);   // A_h0
         v2_0 = offs(0, 1, false); v2_1 = offs(1, 1, false);  // B_h1
         v3_0 = offs(0, 1, true);  v3_1 = offs(1, 1, true);   // A_h1
+        if constexpr (CONV != 0) {
+            auto pix = [&](unsigned& v, unsigned& yx, int i) {
+                const int lr = (wave * 2 + i) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ p_swz(lr);
+                const unsigned m = v;
+                const unsigned b = p_fastdiv(m, c_mgh, c_shh);
+                const unsigned r = m - b * (unsigned)c_HoWo;
+                const unsigned oy = p_fastdiv(r, c_mgw, c_shw);
+                const unsigned ox = r - oy * (unsigned)c_Wo;
+                const int y0 = (int)oy * c_s - 1, x0 = (int)ox * c_s - 1;
+                v = (unsigned)(((((int)b * c_H + y0) * c_W + x0) * c_C + c * 8) * 2);
+                yx = ((unsigned)y0 << 16) | ((unsigned)x0 & 0xffffu);
+            };
+            pix(v1_0, y1_0, 0); pix(v1_1, y1_1, 1);
+            pix(v3_0, y3_0, 0); pix(v3_1, y3_1, 1);
+        }
     };
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + wave * 2048);
     int s_ktg = 0, s_kt = 0, s_ti = 0;  // stream cursor: global K-tile, K-tile in tile, tile
+    int s_dy = 0, s_dx = 0, s_cib = 0;  // CONV: tap and 64-channel block of the cursor's K-tile
     // issue half-tile J (0 B_h0, 1 A_h0, 2 B_h1, 3 A_h1) of the stream's current K-tile
     auto issue = [&](auto Jc) {
         constexpr int J = decltype(Jc)::value;
@@ -183,12 +211,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             const bf16_t* base = ((J & 1) ? A : B) + (size_t)s_kt * P_BK;
             const unsigned va = J == 0 ? v0_0 : J == 1 ? v1_0 : J == 2 ? v2_0 : v3_0;
             const unsigned vb = J == 0 ? v0_1 : J == 1 ? v1_1 : J == 2 ? v2_1 : v3_1;
-            p_glds2(base, va, vb, dst, dst + 1024);
+            if constexpr (CONV != 0 && (J & 1)) {
+                const unsigned ya = J == 1 ? y1_0 : y3_0, yb = J == 1 ? y1_1 : y3_1;
+                const int tapoff = ((s_dy * c_W + s_dx) * c_C + s_cib * P_BK) * 2;
+                auto src = [&](unsigned o, unsigned yx) -> const char* {
+                    const int y = ((int)yx >> 16) + s_dy, x = (int)(short)(yx & 0xffffu) + s_dx;
+                    const bool ok = (unsigned)y < (unsigned)c_H && (unsigned)x < (unsigned)c_W;
+                    return ok ? (const char*)A + (long long)((int)o + tapoff) : c_zero;
+                };
+                p_glds2v(src(va, ya), src(vb, yb), dst, dst + 1024);
+            } else {
+                p_glds2(base, va, vb, dst, dst + 1024);
+            }
         }
         if (J == 3) {
             ++s_ktg;
+            if constexpr (CONV != 0) {
+                if (++s_cib == c_cpt) {
+                    s_cib = 0;
+                    if (++s_dx == 3) { s_dx = 0; ++s_dy; }
+                }
+            }
             if (++s_kt == nk) {
                 s_kt = 0;
+                s_dy = 0; s_dx = 0; s_cib = 0;
                 if (++s_ti < my_tiles) point_at(s_ti);
             }
         }
@@ -224,6 +270,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     auto mma = [&](auto QMc, auto QNc, bf16x8 (&bb)[2][2]) {
         constexpr int QM = decltype(QMc)::value, QN = decltype(QNc)::value;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (CONV == 2 && QM == QN) {  // P0 / P2 have just loaded `a`
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[mi][ks] = p_relu8(a[mi][ks]);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -341,12 +393,18 @@ static int nt256_mode() {  // SSL4GIE_NT256: "0" never, "1" whenever possible, u
 
 bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
     const int mode = nt256_mode();
-    if (mode == 0) return false;
+    if (mode == 0 && !d->conv) return false;
     // 32-bit per-lane byte offsets; whole K-tiles; 16-byte row segments on the output
-    if ((long long)d->M * d->sAm * 2 >= (1LL << 32) || (long long)d->N * d->sBn * 2 >= (1LL << 32))
+    if ((!d->conv && (long long)d->M * d->sAm * 2 >= (1LL << 32)) ||
+        (long long)d->N * d->sBn * 2 >= (1LL << 32))
         return false;
     if (d->K % P_BK != 0 || d->N % 8 != 0 || d->ldc % 8 != 0) return false;
     const int ep = d->epilogue;
+    if (d->conv)  // gathered A: bf16 outputs with bias / plain only, whole K-tiles inside a tap
+        return ssl4gie_internal_conv_geom_ok(d->conv) && d->conv->C % P_BK == 0 &&
+               d->K == 9 * d->conv->C && (long long)d->M == conv_rows(d->conv) &&
+               d->dtype_c == SSL4GIE_BF16 && !d->accumulate &&
+               (ep == SSL4GIE_EPI_BIAS || ep == SSL4GIE_EPI_NONE);
     if (d->dtype_c == SSL4GIE_BF16) {
         if (ep == SSL4GIE_EPI_BIAS_RESIDUAL || d->accumulate) return false;
     } else {
@@ -367,10 +425,16 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate};
     static int skip_epi = -1;  // SSL4GIE_NT256_NOEPI=1: ablation (K-loop only; outputs are garbage)
     if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] == '1') ? 1 : 0; }
+    ConvK ck{};
+    if (d->conv) {
+        const int rc = ssl4gie_internal_conv_k(d->conv, &ck);
+        if (rc) return rc;
+    }
     ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
-#define P_LAUNCH(TC_, MODE_)                                                                       \
+#define P_LAUNCH(TC_, MODE_) P_LAUNCH_C(TC_, MODE_, 0)
+#define P_LAUNCH_C(TC_, MODE_, CONV_)                                                              \
     do {                                                                                           \
-        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_>;                                             \
+        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_>;                                      \
         static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
         if (!attr_set) {                                                                           \
             HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
@@ -379,9 +443,15 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         }                                                                                          \
         hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAm,         \
                            (const bf16_t*)d->B, d->sBn, (TC_*)d->C, d->ldc, d->M, d->N, d->K, tn,  \
-                           ntiles, e, skip_epi);                                                    \
+                           ntiles, e, skip_epi, ck);                                                \
     } while (0)
-    if (d->dtype_c == SSL4GIE_BF16) {
+    if (d->conv) {
+        const bool relu = d->conv->relu != 0, bias = d->epilogue == SSL4GIE_EPI_BIAS;
+        if (bias && relu) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_BIAS, 2);
+        else if (bias) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_BIAS, 1);
+        else if (relu) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_NONE, 2);
+        else P_LAUNCH_C(bf16_t, SSL4GIE_EPI_NONE, 1);
+    } else if (d->dtype_c == SSL4GIE_BF16) {
         switch (d->epilogue) {
             case SSL4GIE_EPI_BIAS: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS); break;
             case SSL4GIE_EPI_BIAS_GELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU); break;
@@ -400,6 +470,7 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         }
     }
 #undef P_LAUNCH
+#undef P_LAUNCH_C
     LAUNCH_CHECK();
     return 0;
 }

@@ -43,12 +43,14 @@ DEVI bf16x8 q_frag(const char* img, int krow0, int x0, int lane) {
 // COLSUM: the workgroups of the first tile column (n0 == 0) also produce colsum[m] = sum_k At[k][m]
 // (the bias gradient): wave (wr, wc) multiplies its wc-th A fragment of each quadrant against a
 // ones fragment — 2 extra MFMAs in P0 and in P2 — and writes 2 x 16 sums.
-template <bool COLSUM>
+// CONV: 0 = Bt is a matrix; 1 = Bt is the implicit 3x3 patch matrix of the map at `Bt` (k-row =
+// output pixel, column = (tap, channel); ssl4gie_conv3x3_geom); 2 = with ReLU on the B fragments.
+template <bool COLSUM, int CONV>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     const bf16_t* __restrict__ At, long long ldat, const bf16_t* __restrict__ Bt, long long ldbt,
     float* __restrict__ C, long long ldc, float* __restrict__ slabs, int M, int N, int K,
     int tiles_n, int ntiles, int splits, float alpha, int accumulate, float* __restrict__ colsum,
-    float* __restrict__ colsum_part) {
+    float* __restrict__ colsum_part, ConvK cg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -64,6 +66,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     // ---- LDS-DMA stream: this lane's source element offsets (without the k-row term of the
     // K-tile, which advances the wave-uniform base): piece i covers k-rows 4 (2 wave + i) .. +3
     unsigned v0_0, v0_1, v1_0, v1_1, v2_0, v2_1, v3_0, v3_1;
+    // CONV: v0_* / v2_* hold the lane's tap as ((dy*W + dx)*C + ci)*2 | dy << 2 | dx (the byte
+    // offset is a multiple of 16); the pixel of k-row piece i of the cursor's K-tile is kept as
+    // o_i (byte offset of its tap (0,0)) and yx_i (y0 << 16 | x0 & 0xffff)
+    const int c_H = cg.H, c_W = cg.W, c_C = cg.C, c_Wo = cg.Wo, c_HoWo = cg.HoWo, c_s = cg.stride;
+    const unsigned c_mgw = cg.mg_wo, c_shw = cg.sh_wo, c_mgh = cg.mg_hw, c_shh = cg.sh_hw;
+    const char* c_zero = (const char*)cg.zero;
+    int o_0 = 0, o_1 = 0;
+    unsigned yx_0 = 0, yx_1 = 0;
     {
         const int mch = (M >> 3) - 1, nch = (N >> 3) - 1;  // last valid 16-B chunk of a row
         auto offs = [&](int i, int h, bool is_a) -> unsigned {
@@ -76,6 +86,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
             }
             int ch = ((n0 + (c >> 2) * 64 + h * 32) >> 3) + (c & 3);
             ch = ch < nch ? ch : nch;
+            if constexpr (CONV != 0) {
+                const int n = ch * 8, tap = n / c_C, ci = n - tap * c_C;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                return (unsigned)((((dy * c_W + dx) * c_C + ci) * 2) | (dy << 2) | dx);
+            }
             return (unsigned)(((long long)kr * ldbt + ch * 8) * 2);
         };
         v0_0 = offs(0, 0, false); v0_1 = offs(1, 0, false);  // B_h0
@@ -93,7 +108,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
             const bf16_t* base = (J & 1) ? At + krow * ldat : Bt + krow * ldbt;
             const unsigned va = J == 0 ? v0_0 : J == 1 ? v1_0 : J == 2 ? v2_0 : v3_0;
             const unsigned vb = J == 0 ? v0_1 : J == 1 ? v1_1 : J == 2 ? v2_1 : v3_1;
-            p_glds2(base, va, vb, dst, dst + 1024);
+            if constexpr (CONV != 0 && !(J & 1)) {
+                if (J == 0) {  // decompose the two k-rows (output pixels) of this K-tile once
+                    auto pix = [&](int i, int& o, unsigned& yx) {
+                        const unsigned m = (unsigned)krow + (wave * 2 + i) * 4 + (lane >> 4);
+                        const unsigned b = p_fastdiv(m, c_mgh, c_shh);
+                        const unsigned r = m - b * (unsigned)c_HoWo;
+                        const unsigned oy = p_fastdiv(r, c_mgw, c_shw);
+                        const unsigned ox = r - oy * (unsigned)c_Wo;
+                        const int y0 = (int)oy * c_s - 1, x0 = (int)ox * c_s - 1;
+                        o = ((((int)b * c_H + y0) * c_W + x0) * c_C) * 2;
+                        yx = ((unsigned)y0 << 16) | ((unsigned)x0 & 0xffffu);
+                    };
+                    pix(0, o_0, yx_0);
+                    pix(1, o_1, yx_1);
+                }
+                auto src = [&](unsigned tapv, int o, unsigned yx) -> const char* {
+                    const int y = ((int)yx >> 16) + (int)((tapv >> 2) & 3);
+                    const int x = (int)(short)(yx & 0xffffu) + (int)(tapv & 3);
+                    const bool ok = (unsigned)y < (unsigned)c_H && (unsigned)x < (unsigned)c_W;
+                    return ok ? (const char*)Bt + (long long)(o + (int)(tapv & ~15u)) : c_zero;
+                };
+                p_glds2v(src(va, o_0, yx_0), src(vb, o_1, yx_1), dst, dst + 1024);
+            } else {
+                p_glds2(base, va, vb, dst, dst + 1024);
+            }
         }
         if (J == 3) ++s_kt;
     };
@@ -125,6 +164,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     auto mma = [&](auto QMc, auto QNc, bf16x8 (&bb)[2][2]) {
         constexpr int QM = decltype(QMc)::value, QN = decltype(QNc)::value;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (CONV == 2 && QM == 0) {  // P0 has just loaded b0, P1 b1
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bb[ni][ks] = p_relu8(bb[ni][ks]);
+        }
         if constexpr (COLSUM && QM == QN) {  // P0 and P2: the phases that have just loaded `a`
             if (do_cs) {
                 auto cs = [&](bf16x8 (&af)[2]) {
@@ -251,8 +296,12 @@ static int tn256_mode() {  // SSL4GIE_TN256: "0" never, "1" whenever possible, u
 
 bool ssl4gie_internal_tn256_ok(const ssl4gie_gemm_desc* d) {
     const int mode = tn256_mode();
-    if (mode == 0) return false;
+    if (mode == 0 && !d->conv) return false;
     if (d->K % P_BK != 0 || d->K < P_BK) return false;
+    if (d->conv)
+        return ssl4gie_internal_conv_geom_ok(d->conv) && d->conv->C % 8 == 0 &&
+               d->N == 9 * d->conv->C && (long long)d->K == conv_rows(d->conv) &&
+               (long long)d->K * d->sAk * 2 < (1LL << 32);
     if ((long long)d->K * d->sAk * 2 >= (1LL << 32) || (long long)d->K * d->sBk * 2 >= (1LL << 32))
         return false;  // 32-bit per-lane byte offsets are relative to a per-K-tile base: generous
     if (mode == 1) return true;
@@ -274,9 +323,14 @@ int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, float* slabs, floa
     const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + P_BN - 1) / P_BN;
     const int splits = ssl4gie_internal_tn256_splits(d);
     dim3 grid(tm * tn * splits), block(512);
-#define Q_LAUNCH(CS_)                                                                              \
+    ConvK ck{};
+    if (d->conv) {
+        const int rc = ssl4gie_internal_conv_k(d->conv, &ck);
+        if (rc) return rc;
+    }
+#define Q_LAUNCH(CS_, CONV_)                                                                       \
     do {                                                                                           \
-        auto kfn = gemm_bf16_tn256_kernel<CS_>;                                                    \
+        auto kfn = gemm_bf16_tn256_kernel<CS_, CONV_>;                                             \
         static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
         if (!attr_set) {                                                                           \
             HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
@@ -286,10 +340,18 @@ int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, float* slabs, floa
         hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAk,         \
                            (const bf16_t*)d->B, d->sBk, (float*)d->C, d->ldc, slabs, d->M, d->N,   \
                            d->K, tn, tm * tn, splits, d->alpha, d->accumulate, d->colsum_a,        \
-                           colsum_part);                                                           \
+                           colsum_part, ck);                                                       \
     } while (0)
-    if (d->colsum_a) Q_LAUNCH(true);
-    else Q_LAUNCH(false);
+    const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
+    if (d->colsum_a) {
+        if (cv == 0) Q_LAUNCH(true, 0);
+        else if (cv == 1) Q_LAUNCH(true, 1);
+        else Q_LAUNCH(true, 2);
+    } else {
+        if (cv == 0) Q_LAUNCH(false, 0);
+        else if (cv == 1) Q_LAUNCH(false, 1);
+        else Q_LAUNCH(false, 2);
+    }
 #undef Q_LAUNCH
     LAUNCH_CHECK();
     return 0;

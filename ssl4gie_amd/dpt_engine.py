@@ -15,10 +15,24 @@ HIP.  Reference: Models/DPT_decoder.py (lines cited per node).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
 from .engine import GradSink, LPCache
+
+
+# SSL4GIE_IMPLICIT_CONV=0 forces the materialised patch matrix (A/B measurements, parity tests)
+_IMPLICIT = os.environ.get("SSL4GIE_IMPLICIT_CONV", "1") != "0"
+
+
+def _fills_chip(x, stride, n_out):
+    """the gathered NT kernel only exists with 256x256 tiles: below ~100 tiles (ResNet layer4's
+    7x7 maps) the 128x128 kernel over a (small) materialised patch matrix keeps more CUs busy"""
+    B, H, W, _ = x.shape
+    Ho, Wo = ops.conv_out_hw(H, W, stride)
+    return ((B * Ho * Wo + 255) // 256) * ((n_out + 255) // 256) >= 96
 
 
 def _derived(lp: LPCache, p: torch.Tensor, tag: str, dtype, fn):
@@ -81,11 +95,16 @@ class Conv3x3Fn(torch.autograd.Function):
         ld = ops.k_pad(9 * Cin, dt)
         w2 = _derived(lp, weight, f"c3:{ld}", dt,
                       lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), ld))
-        cols = ops.im2col3x3(x, stride, relu_in, ld)
-        y = ops.linear_fwd(cols, w2, bias.detach() if bias is not None else None, out_dtype=dt)
-        Ho, Wo = ops.conv_out_hw(H, W, stride)
+        x = x.contiguous()
+        b = bias.detach() if bias is not None else None
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (stride, relu_in, sink, lp, ld)
+        if _IMPLICIT and ld == 9 * Cin and _fills_chip(x, stride, Cout) and \
+                ops.conv3x3_implicit_ok(x, stride, Cout):
+            return ops.conv3x3_fwd(x, w2, b, stride, relu_in)  # patch matrix gathered in the GEMM
+        cols = ops.im2col3x3(x, stride, relu_in, ld)
+        y = ops.linear_fwd(cols, w2, b, out_dtype=dt)
+        Ho, Wo = ops.conv_out_hw(H, W, stride)
         return y.view(B, Ho, Wo, Cout)
 
     @staticmethod
@@ -99,12 +118,15 @@ class Conv3x3Fn(torch.autograd.Function):
         dy2 = dy.view(-1, Cout)
         (tw, tb), acc, rets = sink.plan([weight, bias])
         if tw is not None:
-            cols = ops.im2col3x3(x, stride, relu_in, ld)  # recomputed, not kept
             fuse_b = tb is not None and not acc  # the bias gradient rides on the same product
-            dw2 = ops.linear_bwd_weight(dy2, cols, bias_out=tb if fuse_b else None)
+            if _IMPLICIT and ops.conv3x3_implicit_ok(x, stride, Cout, wgrad=True):
+                dw2 = ops.conv3x3_bwd_weight(dy2, x, stride, relu_in, bias_out=tb if fuse_b else None)
+            else:
+                cols = ops.im2col3x3(x, stride, relu_in, ld)  # recomputed, not kept
+                dw2 = ops.linear_bwd_weight(dy2, cols, bias_out=tb if fuse_b else None)
+                del cols
             if tb is not None and not fuse_b:
                 ops.colsum(dy2, out=tb, accumulate=True)
-            del cols
             _write_grad(tw, dw2[:, :9 * Cin].view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), acc)
         elif tb is not None:
             ops.colsum(dy2, out=tb, accumulate=acc)
@@ -114,8 +136,13 @@ class Conv3x3Fn(torch.autograd.Function):
                 ld2 = ops.k_pad(9 * Cout, dt)
                 wd = _derived(lp, weight, f"c3d:{ld2}", dt,
                               lambda w: _pad_cols(w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout), ld2))
-                dcols = ops.im2col3x3(dy, 1, False, ld2)
-                dxr = ops.linear_fwd(dcols, wd, None, out_dtype=dt).view(B, H, W, Cin)
+                dy4 = dy.view(B, H, W, Cout)
+                if _IMPLICIT and ld2 == 9 * Cout and _fills_chip(dy4, 1, Cin) and \
+                        ops.conv3x3_implicit_ok(dy4, 1, Cin):
+                    dxr = ops.conv3x3_fwd(dy4, wd, None, 1, False)
+                else:
+                    dcols = ops.im2col3x3(dy4, 1, False, ld2)
+                    dxr = ops.linear_fwd(dcols, wd, None, out_dtype=dt).view(B, H, W, Cin)
             else:
                 w2 = _derived(lp, weight, f"c3:{ld}", dt,
                               lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), ld))

@@ -421,6 +421,75 @@ def im2col3x3(x, stride=1, relu=False, ld=None):
     return cols
 
 
+def conv3x3_implicit_ok(x, stride, n_out=None, wgrad=False):
+    """whether the gathered 256x256 GEMM kernels take this map (ssl4gie_conv3x3_geom limits)"""
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        return False
+    B, H, W, C = x.shape
+    Ho, Wo = conv_out_hw(H, W, stride)
+    if stride not in (1, 2) or Wo < 2 or (B * H + 1) * W * C * 2 >= 2 ** 31:
+        return False
+    if wgrad:  # contraction over pixels in whole K-tiles; dy rows addressed with 32-bit offsets
+        return C % 8 == 0 and (B * Ho * Wo) % 64 == 0 and n_out % 8 == 0 and \
+            B * Ho * Wo * n_out * 2 < 2 ** 32
+    return C % 64 == 0 and n_out % 8 == 0
+
+
+def _geom(x, stride, relu):
+    B, H, W, C_ = x.shape
+    g = _lib.Conv3x3Geom()
+    g.B, g.H, g.W, g.C, g.stride, g.relu = B, H, W, C_, stride, int(relu)
+    return g
+
+
+def conv3x3_fwd(x, w2, bias=None, stride=1, relu=False):
+    """y[(b,oy,ox), co] = sum_k P[(b,oy,ox), k] w2[co, k] (+ bias), P = implicit patch matrix of the
+    bf16 map x [B,H,W,C] (never materialised; ssl4gie_gemm_desc.conv), w2 [Cout, 9C]."""
+    _dev(x, w2, bias)
+    B, H, W, Cin = _nhwc(x)
+    Cout, K = w2.shape
+    assert K == 9 * Cin and w2.dtype == x.dtype and w2.is_contiguous()
+    assert conv3x3_implicit_ok(x, stride, Cout)
+    Ho, Wo = conv_out_hw(H, W, stride)
+    M = B * Ho * Wo
+    d = _desc(M, Cout, K, code(x.dtype), code(x.dtype))
+    g = _geom(x, stride, relu)
+    d.conv = C.pointer(g)
+    d.A, d.sAm, d.sAk = ptr(x), K, 1
+    d.B, d.sBk, d.sBn = ptr(w2), 1, K
+    y = torch.empty(M, Cout, dtype=x.dtype, device=x.device)
+    d.C, d.ldc = ptr(y), Cout
+    if bias is not None:
+        _f32(bias)
+        assert bias.numel() == Cout
+        d.epilogue, d.bias = _lib.EPI_BIAS, ptr(bias)
+    gemm_raw(d, x.device)
+    return y.view(B, Ho, Wo, Cout)
+
+
+def conv3x3_bwd_weight(dy2d, x, stride=1, relu=False, bias_out=None):
+    """dW2[co, k] = sum_pixels dy[(b,oy,ox), co] P[(b,oy,ox), k] (fp32 [Cout, 9C]); with `bias_out`
+    the bias gradient rides on the same product."""
+    _dev(dy2d, x, bias_out)
+    B, H, W, Cin = _nhwc(x)
+    T, Cout = dy2d.shape
+    Ho, Wo = conv_out_hw(H, W, stride)
+    assert T == B * Ho * Wo and dy2d.dtype == x.dtype and dy2d.is_contiguous()
+    assert conv3x3_implicit_ok(x, stride, Cout, wgrad=True)
+    out = torch.empty(Cout, 9 * Cin, dtype=torch.float32, device=x.device)
+    d = _desc(Cout, 9 * Cin, T, code(x.dtype), F32)
+    g = _geom(x, stride, relu)
+    d.conv = C.pointer(g)
+    d.A, d.sAm, d.sAk = ptr(dy2d), 1, Cout
+    d.B, d.sBk, d.sBn = ptr(x), 9 * Cin, 1
+    d.C, d.ldc = ptr(out), 9 * Cin
+    if bias_out is not None:
+        assert bias_out.dtype == torch.float32 and bias_out.numel() == Cout
+        d.colsum_a = ptr(bias_out)
+    gemm_raw(d, x.device)
+    return out
+
+
 def col2im3x3(dcols, B, H, W, C, stride):
     _dev(dcols)
     dx = torch.empty(B, H, W, C, dtype=dcols.dtype, device=dcols.device)

@@ -1,0 +1,54 @@
+"""3x3 convolution timings on one GPU: implicit patch matrix (gathered inside the 256x256 GEMM
+kernels) against the materialised im2col + GEMM path, forward and weight gradient, at the DPT
+decoder / ResNet-50 geometries of the benchmark configurations.  python tools/conv_bench.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ssl4gie_amd import ops
+
+CASES = [  # name, B, H, W, Cin, Cout, stride
+    ("dpt refinenet 256>256 @112 b64", 64, 112, 112, 256, 256, 1),
+    ("dpt refinenet 256>256 @56  b64", 64, 56, 56, 256, 256, 1),
+    ("dpt out_conv0 256>128 @112 b64", 64, 112, 112, 256, 128, 1),
+    ("dpt out_conv2 128>32  @224 b64", 64, 224, 224, 128, 32, 1),
+    ("r50 layer1    64>64   @56 b128", 128, 56, 56, 64, 64, 1),
+    ("r50 layer2    128>128 @28 b128", 128, 28, 28, 128, 128, 1),
+    ("r50 layer3    256>256 @14 b128", 128, 14, 14, 256, 256, 1),
+    ("r50 layer4    512>512 @7  b128", 128, 7, 7, 512, 512, 1),
+    ("r50 layer2.0  128>128 @56s2 b128", 128, 56, 56, 128, 128, 2),
+]
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3  # us
+
+
+def main():
+    print(f"{'case':36s} {'fwd impl':>9s} {'fwd mat':>9s} {'TF impl':>8s} | {'wg impl':>9s} {'wg mat':>9s} {'TF impl':>8s}")
+    for name, B, H, W, Ci, Co, s in CASES:
+        x = torch.randn(B, H, W, Ci, device="cuda").bfloat16()
+        w2 = (torch.randn(Co, 9 * Ci, device="cuda") * 0.02).bfloat16()
+        bias = torch.zeros(Co, device="cuda")
+        Ho, Wo = ops.conv_out_hw(H, W, s)
+        dy = torch.randn(B * Ho * Wo, Co, device="cuda").bfloat16()
+        fl = 2.0 * B * Ho * Wo * Co * 9 * Ci
+        fi = timeit(lambda: ops.conv3x3_fwd(x, w2, bias, s, True))
+        fm = timeit(lambda: ops.linear_fwd(ops.im2col3x3(x, s, True), w2, bias))
+        if ops.conv3x3_implicit_ok(x, s, Co, wgrad=True):
+            wi = timeit(lambda: ops.conv3x3_bwd_weight(dy, x, s, True, bias_out=bias))
+        else:
+            wi = float("nan")
+        wm = timeit(lambda: ops.linear_bwd_weight(dy, ops.im2col3x3(x, s, True), bias_out=bias))
+        print(f"{name:36s} {fi:9.1f} {fm:9.1f} {fl / fi / 1e6:8.1f} | {wi:9.1f} {wm:9.1f} {fl / wi / 1e6:8.1f}")
+        del x, w2, dy
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
