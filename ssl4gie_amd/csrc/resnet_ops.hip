@@ -120,47 +120,98 @@ __global__ void subsample2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ 
 // partial[blockIdx.y][0][c] = sum_r x[r, c], partial[..][1][c] = sum_r x^2 over this block's rows
 // (sums are taken about the pivot x[0, c] — written to `pivot` — so that E[d^2] - E[d]^2 does not
 // cancel catastrophically when |mean| >> std).
-// Lane mapping: a lane owns 4 channels.  With C >= 256 a wave spans 256 channels of one row and
-// gridDim.x strips cover C; with C < 256 (C/4 = 16 or 32 lanes per row) a wave folds 64 / (C/4) rows
-// per step and the lanes of equal channel group are combined by shuffles at the end.
+// Lane mapping (both reductions): a lane owns V = 16 B / sizeof(T) channels (one dwordx4 load).  With
+// C / V >= 64 a wave spans 64 V channels of one row and gridDim.x strips cover C; with fewer
+// (power-of-two) channel groups a wave folds 64 / (C / V) rows per step and lanes of equal channel
+// group are combined by shuffles at the end.  A wave step therefore reads 1 KiB of contiguous
+// memory, and four steps are in flight per lane (the pass is pure HBM streaming: ~4 KiB per wave
+// outstanding x 16 waves per CU is what it takes to cover the latency).
+struct BnLanes {
+    int lpr, rpw, c, rsub;
+};
+template <int V>
+DEVI BnLanes bn_lanes(int C, int lane) {
+    BnLanes m;
+    const int cg = C / V;
+    m.lpr = (cg < 64 && !(cg & (cg - 1))) ? cg : 64;  // fold only powers of two
+    m.rpw = 64 / m.lpr;
+    m.c = (blockIdx.x * 64 + (lane % m.lpr)) * V;
+    m.rsub = lane / m.lpr;
+    return m;
+}
+// combine the folded rows of a wave, then the 4 waves of the block; result in wave 0, rsub == 0
+template <int V>
+DEVI void bn_block_reduce(float (&s)[V], float (&q)[V], float (*red)[2][64][V], int lpr, int lane,
+                          int wave) {
+    for (int o = lpr; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            s[j] += __shfl_xor(s[j], o, 64);
+            q[j] += __shfl_xor(q[j], o, 64);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { red[wave - 1][0][lane][j] = s[j]; red[wave - 1][1][lane][j] = q[j]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s[j] += red[w][0][lane][j]; q[j] += red[w][1][lane][j]; }
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x,
                                                        float* __restrict__ partial,
                                                        float* __restrict__ pivot, long long rows,
                                                        int C) {
-    __shared__ f32x4 red[3][2][64];
+    constexpr int V = V16<T>::N;
+    typedef typename V16<T>::raw raw_t;
+    __shared__ float red[3][2][64][V];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cg = C >> 2;                       // channel groups per row
-    const int lpr = (cg < 64 && !(cg & (cg - 1))) ? cg : 64;  // lanes per row (fold only powers of 2)
-    const int rpw = 64 / lpr;                    // rows per wave step
-    const int c = (blockIdx.x * 64 + (lane % lpr)) * 4;
-    const int rsub = lane / lpr;
-    f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
-    if (c < C) {
-        const f32x4 piv = ld4(x + c);
-        if (blockIdx.y == 0 && wave == 0 && rsub == 0) st4(pivot + c, piv);
-        for (long long r = ((long long)blockIdx.y * 4 + wave) * rpw + rsub; r < rows;
-             r += (long long)gridDim.y * 4 * rpw) {
-            const f32x4 v = ld4(x + (size_t)r * C + c) - piv;
-            s += v;
-            q += v * v;
-        }
-    }
-    for (int o = lpr; o < 64; o <<= 1) {
+    const BnLanes m = bn_lanes<V>(C, lane);
+    float s[V], q[V];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] += __shfl_xor(s[j], o, 64);
-            q[j] += __shfl_xor(q[j], o, 64);
-        }
-    }
-    if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
-    __syncthreads();
-    if (wave == 0 && c < C && rsub == 0) {
+    for (int j = 0; j < V; ++j) s[j] = q[j] = 0.f;
+    if (m.c < C) {
+        float piv[V];
+        un<T>(*(const raw_t*)(x + m.c), piv);
+        if (blockIdx.y == 0 && wave == 0 && m.rsub == 0) {
 #pragma unroll
-        for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
+            for (int j = 0; j < V; ++j) pivot[m.c + j] = piv[j];
+        }
+        auto acc = [&](const raw_t& v) {
+            float f[V];
+            un<T>(v, f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float d = f[j] - piv[j];
+                s[j] += d;
+                q[j] += d * d;
+            }
+        };
+        const long long step = (long long)gridDim.y * 4 * m.rpw;
+        long long r = ((long long)blockIdx.y * 4 + wave) * m.rpw + m.rsub;
+        const T* px = x + m.c;
+        for (; r + 3 * step < rows; r += 4 * step) {
+            const raw_t v0 = *(const raw_t*)(px + (size_t)r * C);
+            const raw_t v1 = *(const raw_t*)(px + (size_t)(r + step) * C);
+            const raw_t v2 = *(const raw_t*)(px + (size_t)(r + 2 * step) * C);
+            const raw_t v3 = *(const raw_t*)(px + (size_t)(r + 3 * step) * C);
+            acc(v0); acc(v1); acc(v2); acc(v3);
+        }
+        for (; r < rows; r += step) acc(*(const raw_t*)(px + (size_t)r * C));
+    }
+    bn_block_reduce<V>(s, q, red, m.lpr, lane, wave);
+    if (wave == 0 && m.c < C && m.rsub == 0) {
         float* p = partial + (size_t)blockIdx.y * 2 * C;
-        st4(p + c, s);
-        st4(p + C + c, q);
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+            st4(p + m.c + j, f32x4{s[j], s[j + 1], s[j + 2], s[j + 3]});
+            st4(p + C + m.c + j, f32x4{q[j], q[j + 1], q[j + 2], q[j + 3]});
+        }
     }
 }
 // sums [2][C] -> mean, rstd (biased variance, as F.batch_norm normalises with), and the running
@@ -231,52 +282,69 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     *(typename V16<T>::raw*)(y + idx) = pk<T>(f);
 }
 // g = relu ? (y > 0 ? dy : 0) : dy;  partial[blk][0][c] = sum g, [1][c] = sum g * xhat; when the block
-// had a residual input its gradient is g itself (dres, optional).  Lane mapping as bn_stats_kernel.
+// had a residual input its gradient is g itself (dres, optional).  Lane mapping as bn_stats_kernel,
+// two rows (x 2-3 streams) in flight per lane.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dres,
     float* __restrict__ partial, int relu, long long rows, int C) {
-    __shared__ f32x4 red[3][2][64];
+    constexpr int V = V16<T>::N;
+    typedef typename V16<T>::raw raw_t;
+    __shared__ float red[3][2][64][V];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cg = C >> 2;
-    const int lpr = (cg < 64 && !(cg & (cg - 1))) ? cg : 64;
-    const int rpw = 64 / lpr;
-    const int c = (blockIdx.x * 64 + (lane % lpr)) * 4;
-    const int rsub = lane / lpr;
-    f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
-    if (c < C) {
-        const f32x4 mu = ld4(mean + c), rs = ld4(rstd + c);
-        for (long long r = ((long long)blockIdx.y * 4 + wave) * rpw + rsub; r < rows;
-             r += (long long)gridDim.y * 4 * rpw) {
-            const size_t o = (size_t)r * C + c;
-            f32x4 g = ld4(dy + o);
+    const BnLanes m = bn_lanes<V>(C, lane);
+    float s[V], q[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = q[j] = 0.f;
+    if (m.c < C) {
+        float mu[V], rs[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { mu[j] = mean[m.c + j]; rs[j] = rstd[m.c + j]; }
+        auto acc = [&](const raw_t& gv, const raw_t& yv, const raw_t& xv, size_t o) {
+            float g[V], xx[V];
+            un<T>(gv, g);
+            un<T>(xv, xx);
             if (relu) {
-                const f32x4 yy = ld4(y + o);
+                float yy[V];
+                un<T>(yv, yy);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+                for (int j = 0; j < V; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
             }
-            if (dres) st4(dres + o, g);
-            const f32x4 xh = (ld4(x + o) - mu) * rs;
-            s += g;
-            q += g * xh;
+            if (dres) *(raw_t*)(dres + o) = relu ? pk<T>(g) : gv;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                s[j] += g[j];
+                q[j] += g[j] * ((xx[j] - mu[j]) * rs[j]);
+            }
+        };
+        const long long step = (long long)gridDim.y * 4 * m.rpw;
+        long long r = ((long long)blockIdx.y * 4 + wave) * m.rpw + m.rsub;
+        for (; r + step < rows; r += 2 * step) {
+            const size_t o0 = (size_t)r * C + m.c, o1 = (size_t)(r + step) * C + m.c;
+            const raw_t g0 = *(const raw_t*)(dy + o0), g1 = *(const raw_t*)(dy + o1);
+            const raw_t x0 = *(const raw_t*)(x + o0), x1 = *(const raw_t*)(x + o1);
+            raw_t y0 = g0, y1 = g1;
+            if (relu) { y0 = *(const raw_t*)(y + o0); y1 = *(const raw_t*)(y + o1); }
+            acc(g0, y0, x0, o0);
+            acc(g1, y1, x1, o1);
+        }
+        for (; r < rows; r += step) {
+            const size_t o0 = (size_t)r * C + m.c;
+            const raw_t g0 = *(const raw_t*)(dy + o0), x0 = *(const raw_t*)(x + o0);
+            raw_t y0 = g0;
+            if (relu) y0 = *(const raw_t*)(y + o0);
+            acc(g0, y0, x0, o0);
         }
     }
-    for (int o = lpr; o < 64; o <<= 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] += __shfl_xor(s[j], o, 64);
-            q[j] += __shfl_xor(q[j], o, 64);
-        }
-    }
-    if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
-    __syncthreads();
-    if (wave == 0 && c < C && rsub == 0) {
-#pragma unroll
-        for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
+    bn_block_reduce<V>(s, q, red, m.lpr, lane, wave);
+    if (wave == 0 && m.c < C && m.rsub == 0) {
         float* p = partial + (size_t)blockIdx.y * 2 * C;
-        st4(p + c, s);
-        st4(p + C + c, q);
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+            st4(p + m.c + j, f32x4{s[j], s[j + 1], s[j + 2], s[j + 3]});
+            st4(p + C + m.c + j, f32x4{q[j], q[j + 1], q[j + 2], q[j + 3]});
+        }
     }
 }
 // dx = coef[c] g + coef[C + c] x + coef[2C + c]
@@ -391,9 +459,15 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dy, T* __restrict__
 // =====================================================================================
 static bool rdt(int dt) { return dt == SSL4GIE_F32 || dt == SSL4GIE_BF16; }
 static int rvn(int dt) { return dt == SSL4GIE_BF16 ? 8 : 4; }
-static int bn_parts(long long rows) {
-    long long p = (rows + 1023) / 1024;
-    return (int)(p < 1 ? 1 : (p > 512 ? 512 : p));
+// grid of the two BatchNorm reductions: strips of 64 lanes x V channels over C (y: row partitions).
+// ~64K elements per workgroup, at most 1024 partitions (the partials are parts x 2C floats)
+static int bn_strips(int C, int dtype) {
+    const int v = rvn(dtype);
+    return (C / v + 63) / 64;
+}
+static int bn_parts(long long rows, int C) {
+    long long p = ((rows * C) >> 16) / ((C + 511) / 512);
+    return (int)(p < 1 ? 1 : (p > 1024 ? 1024 : p));
 }
 
 extern "C" int ssl4gie_stem_im2col7x7(const float* img, void* cols, int dtype, int B, int H, int W,
@@ -420,7 +494,7 @@ extern "C" int ssl4gie_subsample2(const void* x, void* y, int dtype, int B, int 
     return 0;
 }
 extern "C" size_t ssl4gie_bn_workspace_bytes(long long rows, int C) {
-    return (((size_t)bn_parts(rows) + 1) * 2 + 1 + 3) * C * sizeof(float);  // partials, sums, pivot, coef
+    return (((size_t)bn_parts(rows, C) + 1) * 2 + 1 + 3) * C * sizeof(float);  // partials, sums, pivot, coef
 }
 // forward: statistics over the rows of x [rows, C] (biased variance), optional running-stat update,
 // y = act(xhat gamma + beta (+ res)); mean / rstd [C] are kept for backward
@@ -441,8 +515,8 @@ extern "C" int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* be
                   relu, C, total);
         return 0;
     }
-    const int parts = bn_parts(rows);
-    dim3 grid((C + 255) / 256, parts), block(256);
+    const int parts = bn_parts(rows, C);
+    dim3 grid(bn_strips(C, dtype), parts), block(256);
     float* partial = workspace + 3 * (size_t)C;
     float* sums = partial + (size_t)parts * 2 * C;
     float* pivot = sums + 2 * C;
@@ -473,8 +547,8 @@ extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, cons
     REQUIRE(dy && x && mean && rstd && dx && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
     REQUIRE(!relu || y);
     hipStream_t st = (hipStream_t)stream;
-    const int parts = bn_parts(rows);
-    dim3 grid((C + 255) / 256, parts), block(256);
+    const int parts = bn_parts(rows, C);
+    dim3 grid(bn_strips(C, dtype), parts), block(256);
     float* coef = workspace;
     float* partial = workspace + 3 * (size_t)C;
     if (dtype == SSL4GIE_BF16)
@@ -583,8 +657,8 @@ extern "C" int ssl4gie_bn_stats(const void* x, float* mean, float* var, float* w
                                 long long rows, int C, void* stream) {
     REQUIRE(x && mean && var && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
-    const int parts = bn_parts(rows);
-    dim3 grid((C + 255) / 256, parts), block(256);
+    const int parts = bn_parts(rows, C);
+    dim3 grid(bn_strips(C, dtype), parts), block(256);
     float* partial = workspace + 3 * (size_t)C;
     float* sums = partial + (size_t)parts * 2 * C;
     float* pivot = sums + 2 * C;
@@ -611,8 +685,8 @@ extern "C" int ssl4gie_bn_bwd_reduce(const void* dy, const void* y, const void* 
     REQUIRE(dy && x && mean && rstd && sums && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
     REQUIRE(!relu || y);
     hipStream_t st = (hipStream_t)stream;
-    const int parts = bn_parts(rows);
-    dim3 grid((C + 255) / 256, parts), block(256);
+    const int parts = bn_parts(rows, C);
+    dim3 grid(bn_strips(C, dtype), parts), block(256);
     float* partial = workspace + 3 * (size_t)C;
     if (dtype == SSL4GIE_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy,
