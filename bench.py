@@ -16,7 +16,8 @@ Extra objects on the line:
                 summed over its launches) / summed launch durations, measured with HIP events on
                 the launch stream by the library's launch profiler over `--prof-steps` further
                 steps of the same workload (kept out of the timed region so that event records do
-                not perturb `value`).  peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).
+                not perturb `value`; the weight-gradient side stream is folded back onto the main
+                stream for those steps so that every launch is timed alone on the chip).  peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).
   cpu_baseline  the CPU oracle (oracle/mae_ref.py: fp32 torch restatement of the reference's
                 MaskedAutoencoderViT step, validated against reference-generated fixtures) timed
                 on this box's host cores at bs=8 (BASELINE.json configs[0]); rank 0, N=1 only.
@@ -288,6 +289,9 @@ def main():
     roof = None
     kinds = ["gemm_bf16_nt", "gemm_bf16_tn", "attn_fwd_bf16", "attn_bwd_bf16", "gemm_generic"]
     if a.prof_steps > 0:
+        # per-kernel durations are taken with each launch alone on the chip: the weight-gradient
+        # side stream (ssl4gie_set_wgrad_stream) is folded back for these steps only
+        L.ssl4gie_set_wgrad_stream(0)
         _lib.check(L.ssl4gie_prof_begin(2000 * a.prof_steps), "prof_begin")
         for _ in range(a.prof_steps):
             step()
@@ -296,6 +300,7 @@ def main():
         nl = (ctypes.c_longlong * 5)()
         _lib.check(L.ssl4gie_prof_collect(ms, fl, nl), "prof_collect")
         L.ssl4gie_prof_end()
+        L.ssl4gie_set_wgrad_stream(0 if os.environ.get("SSL4GIE_WGRAD_STREAM") == "0" else 1)
         per = {k: {"launches_per_step": nl[i] // a.prof_steps,
                    "ms_per_step": round(ms[i] / a.prof_steps, 3),
                    "avg_launch_us": round(1e3 * ms[i] / max(nl[i], 1), 2),

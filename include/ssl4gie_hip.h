@@ -225,6 +225,13 @@ int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* 
                       const float* x_in, const float* dx_out, const void* dx_out_lp,
                       float* dx_in, void* dx_in_lp, int accumulate, void* workspace,
                       void* stream);
+/* The four weight-gradient products of ssl4gie_block_bwd are enqueued on a library-owned
+ * non-blocking side stream (one per device, created on first use) and ordered against `stream`
+ * with events only: each waits for its dY producer, and `stream` waits for the last of them
+ * before any later work — to the caller the call still behaves as if everything ran on `stream`.
+ * on = 0 folds them back onto `stream` (also: environment SSL4GIE_WGRAD_STREAM=0); bench.py does
+ * that while it measures per-kernel durations. */
+int ssl4gie_set_wgrad_stream(int on);
 
 /* ---------------------------------------------------------------- DPT decoder glue (channels-last)
  * Replaces the torch ops around the convolutions of Models/DPT_decoder.py (depth variant): the

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "ssl4gie_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_set_wgrad_stream": (i32, [i32]),
     "ssl4gie_prof_begin": (i32, [i32]),
     "ssl4gie_prof_collect": (i32, [vp, vp, vp]),
     "ssl4gie_prof_end": (i32, []),

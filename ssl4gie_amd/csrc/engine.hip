@@ -16,9 +16,17 @@
 
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 #include "prof.h"
 
 extern "C" int ssl4gie_abi_version(void) { return 1; }
+
+namespace { extern int g_wgrad_stream; }
+// 1: block weight gradients on the library's side stream (default), 0: everything on the caller's
+extern "C" int ssl4gie_set_wgrad_stream(int on) {
+    g_wgrad_stream = on ? 1 : 0;
+    return 0;
+}
 
 // ---- launch profiler (bench only; see prof.h)
 ProfState g_prof = {false, 0, 0, nullptr, nullptr, nullptr};
@@ -62,6 +70,46 @@ extern "C" int ssl4gie_prof_end(void) {
 }
 
 namespace {
+
+// ---- weight-gradient side stream
+// The four dW products of a block do not feed the data-gradient chain, and the chain's NT GEMMs
+// often leave CUs idle (150 or 394 output tiles on 256 CUs): the dW products run on a second,
+// non-blocking stream so the dispatcher can fill those CUs.  Ordering is by events only (no host
+// synchronisation): each dW waits for the event recorded after its dY producer, and the caller's
+// stream waits for the last dW before ssl4gie_block_bwd's work is considered complete, so from
+// outside the call nothing changes.  One stream + event set per device, created on first use and
+// kept for the life of the library.  SSL4GIE_WGRAD_STREAM=0 (or ssl4gie_set_wgrad_stream(0))
+// folds everything back onto the caller's stream — used when per-kernel durations are measured.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+int g_wgrad_stream = -1;  // -1: read the environment on first use
+SideStream* side_stream() {
+    if (g_wgrad_stream < 0) {
+        const char* e = getenv("SSL4GIE_WGRAD_STREAM");
+        g_wgrad_stream = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!g_wgrad_stream) return nullptr;
+    static SideStream per_dev[64];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    SideStream* ss = &per_dev[dev];
+    if (!ss->s) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 0; i < 5; ++i) {
+            if (hipEventCreateWithFlags(&ss->ev[i], hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamDestroy(st);
+                return nullptr;
+            }
+        }
+        ss->s = st;
+    }
+    return ss;
+}
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t esize(int dt) { return dt == SSL4GIE_BF16 ? 2 : 4; }
@@ -210,41 +258,61 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     void* gws = ws + L.gemm_ws;
     const void* dy = (dt == SSL4GIE_F32) ? (const void*)dx_out : dx_out_lp;
     ssl4gie_gemm_desc e, wg;
+    // weight gradients go to the side stream when there is one (see SideStream)
+    hipStream_t main_st = (hipStream_t)stream;
+    SideStream* ss = side_stream();
+    void* wst = ss ? (void*)ss->s : stream;
+    int evi = 0;
+    auto fork = [&]() -> int {  // side stream: wait for everything enqueued on the caller's so far
+        if (!ss) return 0;
+        HIP_RET(hipEventRecord(ss->ev[evi], main_st));
+        HIP_RET(hipStreamWaitEvent(ss->s, ss->ev[evi], 0));
+        ++evi;
+        return 0;
+    };
 
     // ---- fc2
+    RC(fork());
+    wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, g->bfc2, dt, accumulate);
+    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, wst));
     memset(&e, 0, sizeof(e));
     e.C = du; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_MUL_AUX; e.aux = a->u;
     RC(linear_bwd_data(dy, w->wfc2, w->wfc2_t, T, D, F, dt, e, stream));
-    wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, g->bfc2, dt, accumulate);
-    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
     // ---- fc1
+    RC(fork());
+    wg = wgrad_desc(F, D, T, du, a->h2, g->wfc1, g->bfc1, dt, accumulate);
+    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, wst));
     memset(&e, 0, sizeof(e));
     e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(du, w->wfc1, w->wfc1_t, T, F, D, dt, e, stream));
-    wg = wgrad_desc(F, D, T, du, a->h2, g->wfc1, g->bfc1, dt, accumulate);
-    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
     // ---- LN2 (adds the residual gradient dx_out)
     RC(ssl4gie_layernorm_bwd(dh, dt, a->xmid, w->ln2_g, a->mean2, a->rstd2, dx_out, dxmid,
                              dt == SSL4GIE_F32 ? nullptr : dxmid_lp, dt, g->ln2_g, g->ln2_b,
                              accumulate, ln_ws, T, D, stream));
     // ---- proj
+    RC(fork());
+    wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
+    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, wst));
     memset(&e, 0, sizeof(e));
     e.C = dattn; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(dxmid_lp, w->wproj, w->wproj_t, T, D, D, dt, e, stream));
-    wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
-    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
     // ---- attention
     RC(ssl4gie_attn_bwd(a->qkv, a->attn, dattn, a->lse, dqkv, dt, d->B, d->N, d->H, D / d->H,
                         ws + L.attn_ws, stream));
     // ---- qkv
+    RC(fork());
+    wg = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
+    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, wst));
     memset(&e, 0, sizeof(e));
     e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(dqkv, w->wqkv, w->wqkv_t, T, 3 * D, D, dt, e, stream));
-    wg = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
-    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, stream));
     // ---- LN1 (adds the residual gradient dxmid)
     RC(ssl4gie_layernorm_bwd(dh, dt, x_in, w->ln1_g, a->mean1, a->rstd1, dxmid, dx_in,
                              dt == SSL4GIE_F32 ? nullptr : dx_in_lp, dt, g->ln1_g, g->ln1_b,
                              accumulate, ln_ws, T, D, stream));
+    if (ss) {  // join: the caller's stream continues after the last weight gradient
+        HIP_RET(hipEventRecord(ss->ev[4], ss->s));
+        HIP_RET(hipStreamWaitEvent(main_st, ss->ev[4], 0));
+    }
     return 0;
 }
