@@ -217,6 +217,82 @@ def bench_moco(a):
         dist.destroy_process_group()
 
 
+def bench_bt(a):
+    """configs[4]: Barlow Twins on a ViT-B trunk, two views of 512 images per GPU, projector
+    8192-8192-8192, lambda 0.0051, LARS (the build's own specification of the published method —
+    the reference has no Barlow Twins trainer); the exchange is the all-reduce of
+    the 8192 x 8192 cross-correlation."""
+    import torch.distributed as dist
+    from ssl4gie_amd import _lib, parallel
+    from ssl4gie_amd.Models.barlow_twins import BarlowTwins
+    from ssl4gie_amd.Models.moco_v3 import vits
+    from ssl4gie_amd.Models.moco_v3.moco.optimizer import LARS
+    _lib.load()
+    rank, local, world = parallel.init_from_env()
+    assert world == a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = a.batch if a.batch != 256 else 512
+    torch.manual_seed(0)
+    bb = vits.vit_base(num_classes=8)
+    del bb.head
+    model = BarlowTwins(bb, 768, "8192-8192-8192", lambd=0.0051)
+    if world > 1:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    model.to(dev).set_precision(a.precision)
+    ddp = parallel.DataParallel(model) if world > 1 else None
+    opt = LARS([p for p in model.parameters() if p.requires_grad], lr=0.02 * B * world / 256,
+               weight_decay=1.5e-6, momentum=0.9)
+    g = torch.Generator("cpu").manual_seed(rank)
+    y1 = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    y2 = (y1.cpu() + 0.5 * torch.randn(B, 3, 224, 224, generator=g)).to(dev)  # correlated views
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = (ddp or model)(y1, y2)
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        ips = B * world * a.steps / dt
+        # SURVEY §8d: 212.44 GFLOP per image (two views, trunk + projector, fwd+bwd) + the three
+        # 8192 x 8192 x B cross-correlation products (c, dz_A, dz_B) = 6 * 8192^2 FLOP per image
+        gflop_img = 212.44 + 6 * 8192 * 8192 / 1e9
+        print(json.dumps({
+            "metric": "images/sec (two views, fwd+bwd+LARS) Barlow Twins ViT-B 224x224 (BASELINE.json configs[4])",
+            "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "BarlowTwins(ViT-B trunk, projector 8192-8192-8192, lambda 0.0051), two "
+                                   "synthetic views resident in HBM, LARS; own specification (absent "
+                                   "from the reference)",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "model_mfma_frac": round(ips / world * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(float(loss.detach()), 5)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,12 +302,14 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco"],
+    ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco", "bt"],
                     help="mae = BASELINE.json configs[1] (the headline metric); depth = configs[3] "
                          "(ViT-B + DPT depth finetune step, bs 128/GPU) as an extra measurement")
     a = ap.parse_args()
     if a.workload == "depth":
         return bench_depth(a)
+    if a.workload == "bt":
+        return bench_bt(a)
     if a.workload == "moco":
         return bench_moco(a)
 

@@ -121,22 +121,40 @@ class GradSink:
 
     def __init__(self, arena: Optional[ParamArena]):
         self.arena = arena
+        # parameters whose arena slice has been written in the current backward pass while p.grad is
+        # still None — i.e. autograd is holding the slice view as their (so far only) contribution
+        self._written = set()
+
+    def new_pass(self):
+        """called at the top of every forward: whatever follows belongs to a new backward pass"""
+        self._written.clear()
 
     def plan(self, params: Sequence[Optional[torch.Tensor]]):
-        """-> (targets, accumulate, returns) ; targets[i] is the tensor the kernel writes."""
+        """-> (targets, accumulate, returns) ; targets[i] is the tensor the kernel writes.
+
+        A parameter used more than once in one forward (both views of MoCo / Barlow Twins go
+        through the same encoder and heads) is seen here once per use within a single backward
+        pass, with p.grad still None: the first use writes the arena slice and hands the slice view
+        to autograd, every later use ACCUMULATES into the slice in place and contributes None —
+        autograd holds the first contribution by reference, so the leaf ends up with the sum."""
         live = [p for p in params if p is not None and p.requires_grad]
         arena = self.arena
         if arena is not None and all(arena.owns(p) for p in live):
             views = {id(p): arena.grad_view(p) for p in live}
+            tg = [views[id(p)] if (p is not None and p.requires_grad) else None for p in params]
             has = [p.grad is not None for p in live]
             if live and all(has):
                 if not all(p.grad.data_ptr() == views[id(p)].data_ptr() for p in live):
                     raise RuntimeError("p.grad was replaced by a tensor outside the gradient arena")
-                tg = [views[id(p)] if (p is not None and p.requires_grad) else None for p in params]
                 return tg, True, [None] * len(params)
             if any(has):
                 raise RuntimeError("mixed .grad state (some None, some set) is not supported")
-            tg = [views[id(p)] if (p is not None and p.requires_grad) else None for p in params]
+            seen = [id(p) in self._written for p in live]
+            if live and all(seen):
+                return tg, True, [None] * len(params)
+            if any(seen):
+                raise RuntimeError("parameters of one node were written by different earlier nodes")
+            self._written.update(id(p) for p in live)
             return tg, False, list(tg)
         tg = [torch.empty_like(p) if (p is not None and p.requires_grad) else None for p in params]
         return tg, False, list(tg)
@@ -495,6 +513,7 @@ class EngineModule(nn.Module):
         """Call once at the top of forward(): validates the arena (cheap pointer checks)."""
         _lib.load()
         self.arena()
+        self.sink().new_pass()
 
     def sink(self) -> GradSink:
         if self._root is not None:

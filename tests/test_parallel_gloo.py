@@ -115,3 +115,45 @@ def test_syncbn_stat_combine_world2():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def _bt_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssl4gie_amd.Models.barlow_twins import cross_corr_loss_terms, exchange_cross_corr
+    from oracle import bt_ref
+    g = torch.Generator().manual_seed(9)
+    z1 = torch.randn(24, 16, generator=g, dtype=torch.float64)
+    z2 = z1 + 0.3 * torch.randn(24, 16, generator=g, dtype=torch.float64)
+    ref = bt_ref.barlow_loss(z1, z2, 0.0051)
+    # SyncBN semantics: normalise with the statistics of the pooled batch, then shard the rows
+    zn1 = F.batch_norm(z1, None, None, None, None, True)
+    zn2 = F.batch_norm(z2, None, None, None, None, True)
+    rows = slice(0, 10) if rank == 0 else slice(10, 24)  # uneven shards
+    c = zn1[rows].t() @ zn2[rows] / 24
+    exchange_cross_corr(c)
+    loss, dc = cross_corr_loss_terms(c, 0.0051)
+    full = zn1.t() @ zn2 / 24
+    ok = torch.allclose(c, full, atol=1e-12) and abs(float(loss) - float(ref)) < 1e-9 * abs(float(ref))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_barlow_twins_cross_corr_exchange_world2():
+    """config 5's collective: per-rank correlation blocks summed over ranks == the pooled-batch
+    correlation, and the loss on it == the oracle's single-process loss"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bt_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res
