@@ -7,46 +7,55 @@ depth variant), same `forward(activations) -> [B, 1, 224, 224]`.
 The `nn.Conv2d` / `nn.ConvTranspose2d` children only hold parameters; the arithmetic runs on
 libssl4gie_hip.so through `ssl4gie_amd.dpt_engine` with channels-last maps (the ViT's token-major
 rows ARE the 14x14 channels-last map, so `Slice -> Transpose -> Unflatten` costs one cast).
-Scope of this round: `dense="depth"` with `use_readout="ignore"` (what `ViT_from_MAE(dense="depth")`
-builds, reference models.py:408); the "seg" variant (BatchNorm fusion blocks + Dropout) is the next
-SURVEY §8(f) row and raises NotImplementedError.
+Both heads are built with `use_readout="ignore"` (the reference's default, models.py:408):
+  * dense="depth": fusion blocks without BatchNorm, head 3x3 -> x2 -> 3x3 -> ReLU -> 1x1 -> Sigmoid;
+  * dense="seg" (reference :461,483-497): BatchNorm2d after both convolutions of
+    every ResidualConvUnit (convolutions without bias), head 3x3(no bias) -> BatchNorm2d -> ReLU ->
+    Dropout(0.1) -> 1x1 -> bilinear x2, output [B, num_classes, 224, 224] logits.  BatchNorm runs on
+    the channels-last rows with the ResNet BatchNorm kernels (ReLU and the unit's residual add
+    fused; SyncBatchNorm-capable); Dropout is torch's own op inside the autograd graph (it draws
+    from torch's RNG exactly like the reference's nn.Dropout).
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
-from ..dpt_engine import (AddFn, Conv3x3Fn, ConvTransposeFn, DepthHeadFn, TokensToMapFn,
+from ..dpt_engine import (AddFn, Conv3x3Fn, ConvTransposeFn, DepthHeadFn, SegHeadFn, TokensToMapFn,
                           Upsample2xFn)
 from ..engine import EngineModule, LinearFn
+from ..resnet_engine import BatchNormFn
 
 
 class _RCU(nn.Module):
-    """ResidualConvUnit_custom container (bn=False): conv1, conv2 3x3 with bias."""
+    """ResidualConvUnit_custom container: conv1, conv2 3x3 (bias = not bn) [+ bn1, bn2]."""
 
-    def __init__(self, features):
+    def __init__(self, features, bn=False):
         super().__init__()
-        self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
-        self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
+        self.bn = bn
+        self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=not bn)
+        self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=not bn)
+        if bn:
+            self.bn1 = nn.BatchNorm2d(features)
+            self.bn2 = nn.BatchNorm2d(features)
 
 
 class _Fusion(nn.Module):
     """FeatureFusionBlock_custom container: out_conv 1x1, resConfUnit1, resConfUnit2."""
 
-    def __init__(self, features):
+    def __init__(self, features, bn=False):
         super().__init__()
         self.out_conv = nn.Conv2d(features, features, 1, 1, 0, bias=True)
-        self.resConfUnit1 = _RCU(features)
-        self.resConfUnit2 = _RCU(features)
+        self.resConfUnit1 = _RCU(features, bn)
+        self.resConfUnit2 = _RCU(features, bn)
 
 
 class DPT_decoder(EngineModule):
     def __init__(self, num_classes=1, dense="seg", vit_features=768, features=[96, 192, 384, 768],
                  fusion_features=256, use_readout="ignore", size=[224, 224], patch_size=[16, 16]):
         super().__init__()
-        if dense != "depth":
-            raise NotImplementedError('DPT_decoder(dense="seg") (BatchNorm fusion blocks, reference '
-                                      'DPT_decoder.py:461,483-497) is a later §8(f) row of this build')
+        if dense not in ("depth", "seg"):
+            raise ValueError(f"dense must be 'depth' or 'seg', got {dense!r}")
         if use_readout != "ignore":
             raise NotImplementedError("only use_readout='ignore' (the reference's default) is built")
         f = features
@@ -63,17 +72,27 @@ class DPT_decoder(EngineModule):
         self.layer2_rn = nn.Conv2d(f[1], fusion_features, 3, 1, 1, bias=False)
         self.layer3_rn = nn.Conv2d(f[2], fusion_features, 3, 1, 1, bias=False)
         self.layer4_rn = nn.Conv2d(f[3], fusion_features, 3, 1, 1, bias=False)
-        self.refinenet1 = _Fusion(fusion_features)
-        self.refinenet2 = _Fusion(fusion_features)
-        self.refinenet3 = _Fusion(fusion_features)
-        self.refinenet4 = _Fusion(fusion_features)
-        # depth head: indices 1 (Interpolate), 3 (ReLU), 5 (Sigmoid) are parameter-free
-        self.output_conv = nn.Sequential(nn.Conv2d(fusion_features, fusion_features // 2, 3, 1, 1),
-                                         nn.Identity(),
-                                         nn.Conv2d(fusion_features // 2, 32, 3, 1, 1),
-                                         nn.Identity(),
-                                         nn.Conv2d(32, 1, 1, 1, 0),
-                                         nn.Identity())
+        use_bn = dense == "seg"
+        self.refinenet1 = _Fusion(fusion_features, use_bn)
+        self.refinenet2 = _Fusion(fusion_features, use_bn)
+        self.refinenet3 = _Fusion(fusion_features, use_bn)
+        self.refinenet4 = _Fusion(fusion_features, use_bn)
+        if dense == "depth":
+            # indices 1 (Interpolate), 3 (ReLU), 5 (Sigmoid) are parameter-free
+            self.output_conv = nn.Sequential(nn.Conv2d(fusion_features, fusion_features // 2, 3, 1, 1),
+                                             nn.Identity(),
+                                             nn.Conv2d(fusion_features // 2, 32, 3, 1, 1),
+                                             nn.Identity(),
+                                             nn.Conv2d(32, 1, 1, 1, 0),
+                                             nn.Identity())
+        else:
+            # indices 2 (ReLU), 3 (Dropout), 5 (Interpolate) are parameter-free
+            self.output_conv = nn.Sequential(nn.Conv2d(fusion_features, fusion_features, 3, 1, 1, bias=False),
+                                             nn.BatchNorm2d(fusion_features),
+                                             nn.Identity(),
+                                             nn.Dropout(0.1, False),
+                                             nn.Conv2d(fusion_features, num_classes, 1),
+                                             nn.Identity())
         self.dense = dense
         self.grid = (size[0] // patch_size[0], size[1] // patch_size[1])
 
@@ -87,8 +106,19 @@ class DPT_decoder(EngineModule):
         return Conv3x3Fn.apply(x, conv.weight, conv.bias, conv.stride[0], relu_in, self.sink(),
                                self.lp_cache)
 
+    def _bn(self, x, bn, relu=False, res=None):
+        """BatchNorm2d over the rows of a channels-last map (+ residual) (+ ReLU)"""
+        shp = x.shape
+        C = shp[-1]
+        r2 = res.contiguous().view(-1, C) if res is not None else None
+        y = BatchNormFn.apply(x.contiguous().view(-1, C), bn.weight, bn.bias, r2, bn, relu, self.sink())
+        return y.view(shp)
+
     def _rcu(self, x, rcu: _RCU):
-        """out = conv2(relu(conv1(relu(x)))) + x  (reference :212-233)"""
+        """out = [bn2](conv2(relu([bn1](conv1(relu(x)))))) + x  (reference :212-233)"""
+        if rcu.bn:
+            out = self._bn(self._c3(x, rcu.conv1, relu_in=True), rcu.bn1, relu=True)
+            return self._bn(self._c3(out, rcu.conv2), rcu.bn2, res=x)  # the skip add rides on bn2
         out = self._c3(x, rcu.conv1, relu_in=True)
         out = self._c3(out, rcu.conv2, relu_in=True)
         return AddFn.apply(out, x)
@@ -128,6 +158,10 @@ class DPT_decoder(EngineModule):
         p2 = self._fusion(self.refinenet2, p3, l2)
         p1 = self._fusion(self.refinenet1, p2, l1)
         oc = self.output_conv
+        if self.dense == "seg":
+            h = self._bn(self._c3(p1, oc[0]), oc[1], relu=True)
+            h = nn.functional.dropout(h, oc[3].p, self.training)
+            return SegHeadFn.apply(h, oc[4].weight, oc[4].bias, self.sink(), self.lp_cache)
         h = self._c3(p1, oc[0])
         h = Upsample2xFn.apply(h)
         h = self._c3(h, oc[2])

@@ -13,9 +13,9 @@ lin_head.*`; ViT_from_MAE keeps `decoder_pos_embed`, reference :395-399).  The u
 (patch-embed GEMM, cls/pos assembly, 12 blocks with taps after blocks 2/5/8/11, final LayerNorm,
 linear head) runs on libssl4gie_hip.so.
 
-Scope of this round: `dense=None` and `dense="depth"` (DPT decoder on the
-four tap tensors, `Models/DPT_decoder.py`) are complete; `dense="seg"` and `det=True` (windowed
-attention + ViTDet FPN, §8f) raise NotImplementedError.
+Scope (SURVEY §8, rows a8-a12 + §8f rank 2): `dense=None`, `dense="depth"` and `dense="seg"` (DPT
+decoder on the four tap tensors, `Models/DPT_decoder.py`) are complete; `det=True` (windowed
+attention + ViTDet FPN, §8f rank 1) raises NotImplementedError.
 """
 from __future__ import annotations
 

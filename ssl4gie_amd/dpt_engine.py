@@ -240,3 +240,57 @@ class DepthHeadFn(torch.autograd.Function):
         dx = ops.depth_head_bwd(x2, weight.detach().reshape(-1).contiguous(), y,
                                 dy.contiguous().view(-1).float(), dw, db, acc)
         return dx.view(B, H, W, -1), rets[0], rets[1], None
+
+
+class SegHeadFn(torch.autograd.Function):
+    """Conv2d(C, num_classes, 1) -> bilinear x2 (output_conv.4-.5 of the seg head, :483-497) ->
+    fp32 logits [B, num_classes, 2H, 2W].  num_classes is tiny (1 for the binary task): the 1x1
+    convolution runs as a GEMM against the weight padded to 8 output channels so that the map stays
+    16-byte aligned through the bilinear kernel; the padding channels are dropped at the end."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sink: GradSink, lp: LPCache):
+        B, H, W, C = x.shape
+        nc = weight.shape[0]
+        ncp = (nc + 7) // 8 * 8
+        dt = x.dtype
+        x2 = x.contiguous().view(-1, C)
+
+        def pad_w(w):
+            out = w.new_zeros(ncp, C)
+            out[:nc] = w.reshape(nc, C)
+            return out
+        w8 = _derived(lp, weight, f"seg:{ncp}", dt, pad_w)
+        b8 = torch.zeros(ncp, dtype=torch.float32, device=x.device)
+        b8[:nc] = bias.detach()
+        y = ops.linear_fwd(x2, w8, b8, out_dtype=dt)
+        up = ops.bilinear2x_fwd(y.view(B, H, W, ncp))
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.cfg = (B, H, W, nc, ncp, sink, lp)
+        return up[..., :nc].permute(0, 3, 1, 2).float().contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        B, H, W, nc, ncp, sink, lp = ctx.cfg
+        C = x2.shape[1]
+        dt = x2.dtype
+        g = torch.zeros(B, 2 * H, 2 * W, ncp, dtype=dt, device=dy.device)
+        g[..., :nc] = dy.permute(0, 2, 3, 1)
+        dy8 = ops.bilinear2x_bwd(g).view(-1, ncp)
+        (tw, tb), acc, rets = sink.plan([weight, bias])
+        if tw is not None:
+            db8 = torch.empty(ncp, dtype=torch.float32, device=dy.device)
+            dw8 = ops.linear_bwd_weight(dy8, x2, bias_out=db8)
+            _write_grad(tw, dw8[:nc].view_as(tw), acc)
+            if tb is not None:
+                _write_grad(tb, db8[:nc], acc)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            def pad_w(w):
+                out = w.new_zeros(ncp, C)
+                out[:nc] = w.reshape(nc, C)
+                return out
+            w8 = _derived(lp, weight, f"seg:{ncp}", dt, pad_w)
+            dx = ops.linear_bwd_data(dy8, w8).view(B, H, W, C)
+        return dx, rets[0], rets[1], None, None

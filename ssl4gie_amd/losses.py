@@ -76,3 +76,19 @@ class ScaleAndShiftInvariantLoss(nn.Module):
                                           mask[:, ::step, ::step])
             total = total + self.alpha * reg
         return total
+
+
+class SoftDiceLoss(torch.nn.Module):
+    """Mirror of `Binary_segmentation/Metrics/losses.py:5-24` (host-side loss reduction): soft Dice
+    on sigmoid(logits), mean over the batch."""
+
+    def __init__(self, smooth=1e-8):
+        super().__init__()
+        self.smooth = smooth
+
+    def forward(self, logits, targets):
+        num = targets.size(0)
+        m1 = torch.sigmoid(logits).view(num, -1)
+        m2 = targets.view(num, -1)
+        score = 2.0 * ((m1 * m2).sum(1) + self.smooth) / ((m1 * m1).sum(1) + (m2 * m2).sum(1) + self.smooth)
+        return 1 - score.sum() / num

@@ -292,6 +292,55 @@ def g6_dpt():
     print(f"g6 dpt: loss={float(loss):.6f} out mean={float(out.mean()):.4f}; params without grad: {missing}")
 
 
+def g9_dpt_seg():
+    """the reference's DPT_decoder(dense="seg") (BatchNorm fusion blocks) + its SoftDiceLoss, fwd and
+    bwd in training mode; Dropout.p is set to 0 (its mask is RNG state, not arithmetic)"""
+    from oracle import dpt_ref
+    ref_dpt = _load_by_path("ref_dpt", os.path.join(REF, "Models", "DPT_decoder.py"))
+    ref_loss = _load_by_path("ref_seg_losses", os.path.join(REF, "Binary_segmentation", "Metrics", "losses.py"))
+    sd = dpt_ref.seg_state_dict(seed=5)
+    m = ref_dpt.DPT_decoder(num_classes=1, dense="seg")
+    ref_shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()
+                  if "running" not in k and "num_batches" not in k}
+    assert ref_shapes == dpt_ref.seg_param_shapes(), set(ref_shapes) ^ set(dpt_ref.seg_param_shapes())
+    m.load_state_dict(sd, strict=False)
+    m.output_conv[3].p = 0.0
+    m.train()
+    acts, _ = dpt_inputs(13)
+    g = torch.Generator("cpu").manual_seed(14)
+    target = (torch.rand(2, 1, 224, 224, generator=g) < 0.3).float()
+    acts = [a.requires_grad_(True) for a in acts]
+    out = m(acts)
+    loss = ref_loss.SoftDiceLoss()(out, target)
+    loss.backward()
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    acts_o = [a.detach().clone().requires_grad_(True) for a in acts]
+    out_o = dpt_ref.seg_forward(sdo, acts_o)
+    loss_o = dpt_ref.soft_dice_loss(out_o, target)
+    loss_o.backward()
+    np.testing.assert_allclose(out_o.detach().numpy(), out.detach().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(float(loss_o), float(loss), rtol=1e-5)
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    missing = sorted(k for k, p in m.named_parameters() if p.grad is None)
+    for k in ("layer1_rn.weight", "refinenet1.resConfUnit2.bn2.weight", "output_conv.4.weight"):
+        err = float((sdo[k].grad - grads[k]).norm() / grads[k].norm())  # fp32 order-of-summation noise
+        assert err < 5e-3, (k, err)
+    out_d = {"out": out.detach().numpy(), "loss": np.array(float(loss)), "target": target.numpy().astype(np.uint8),
+             "no_grad_params": np.array(missing), "seed_weights": np.array(5), "seed_inputs": np.array(13),
+             "state_dict_keys": np.array(sorted(m.state_dict().keys())),
+             "grad_names": np.array(sorted(grads)),
+             "grad_norms": np.array([float(grads[k].norm()) for k in sorted(grads)], dtype=np.float64),
+             "running_mean/output_conv.1": m.output_conv[1].running_mean.numpy()}
+    for k, gr in grads.items():
+        if gr.numel() <= 4096:
+            out_d[f"grad/{k}"] = gr.numpy()
+    for i, a in enumerate(acts):
+        out_d[f"act_grad_norm/{i}"] = np.array(float(a.grad.norm()))
+        out_d[f"act_grad_slice/{i}"] = a.grad[:, :4, :64].numpy()
+    np.savez_compressed(os.path.join(HERE, "g9_dpt_seg.npz"), **out_d)
+    print(f"g9 dpt seg: loss={float(loss):.6f} out mean={float(out.mean()):.4f}; params without grad: {missing}")
+
+
 def g7_ssi():
     ref_loss = _load_by_path("ref_losses", os.path.join(REF, "Depth_estimation", "Metrics", "losses.py"))
     g = torch.Generator("cpu").manual_seed(5)
@@ -376,7 +425,7 @@ def main():
     jobs = {
         "g1": lambda: g1_masking(ref_mae), "g2": lambda: g2_patchify(ref_mae), "g3": g3_sincos,
         "g5tiny": lambda: g5_tiny(ref_mae), "g5vitb": lambda: g5_vitb(ref_mae),
-        "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi, "g8": g8_moco,
+        "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi, "g8": g8_moco, "g9": g9_dpt_seg,
         "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
             **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
             "g5_curve_tiny.npz"),

@@ -157,6 +157,46 @@ def test_g6_dpt_oracle_matches_reference_fixture():
         assert rel_err(acts[i].grad[:, :4, :64], g[f"act_grad_slice/{i}"]) < 1e-3  # fp32 conv reduction order
 
 
+def test_g9_dpt_seg_oracle_matches_reference_fixture():
+    """oracle/dpt_ref.py seg restatement against outputs of the reference's own
+    DPT_decoder(dense="seg") + SoftDiceLoss (training-mode BatchNorm, Dropout.p = 0)"""
+    from oracle import dpt_ref
+    g = load_golden("g9_dpt_seg.npz")
+    sd = {k: v.requires_grad_(True) for k, v in dpt_ref.seg_state_dict(int(g["seed_weights"])).items()}
+    acts, _ = _dpt_inputs(int(g["seed_inputs"]))
+    acts = [a.requires_grad_(True) for a in acts]
+    target = torch.from_numpy(g["target"]).float()
+    out = dpt_ref.seg_forward(sd, acts)
+    loss = dpt_ref.soft_dice_loss(out, target)
+    loss.backward()
+    assert rel_err(out, g["out"]) < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    for name, ref_norm in zip(g["grad_names"], g["grad_norms"]):
+        got = float(sd[str(name)].grad.norm())
+        assert abs(got - ref_norm) <= 5e-3 * max(ref_norm, 1e-12), name
+    for i in range(4):
+        assert rel_err(acts[i].grad[:, :4, :64], g[f"act_grad_slice/{i}"]) < 5e-3
+
+
+def test_dpt_seg_module_schema_and_dice_loss_mirror():
+    """state_dict keys of the engine's DPT_decoder(dense="seg") == the reference class's (incl.
+    BatchNorm buffers); host-side SoftDiceLoss mirror == oracle"""
+    from oracle import dpt_ref
+    from ssl4gie_amd.Models.DPT_decoder import DPT_decoder
+    from ssl4gie_amd.losses import SoftDiceLoss
+    g = load_golden("g9_dpt_seg.npz")
+    m = DPT_decoder(num_classes=1, dense="seg")
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()
+              if "running" not in k and "num_batches" not in k}
+    assert shapes == dpt_ref.seg_param_shapes()
+    logits = torch.randn(3, 1, 32, 32, generator=torch.Generator().manual_seed(1)).requires_grad_(True)
+    tgt = (torch.rand(3, 1, 32, 32, generator=torch.Generator().manual_seed(2)) < 0.4).float()
+    a = SoftDiceLoss()(logits, tgt)
+    b = dpt_ref.soft_dice_loss(logits.detach(), tgt)
+    assert abs(float(a) - float(b)) < 1e-7
+
+
 def test_g7_ssi_loss_oracle_and_host_mirror():
     from oracle import dpt_ref
     from ssl4gie_amd.losses import ScaleAndShiftInvariantLoss
