@@ -45,3 +45,55 @@ def resnet50_features(sd, imgs):
 
 def resnet50_pooled(sd, imgs):
     return resnet50_features(sd, imgs).mean((2, 3))
+
+
+# ------------------------------------------------------------------ dense decoder of the ResNet path
+# Reference: Models/models.py:14-60 (ResNet_Dec_Block / ResNet_Dec_Level), :88-107 (decoder_levels,
+# output_conv), :128-135 (decode).  models.py itself cannot be imported here (it imports timm and
+# torchvision at module level, both absent), so like the trunk this restatement is anchored by torch
+# op semantics only: PARITY UNPINNED.
+def _bnb(sd, p, x, eps=1e-5):
+    return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, eps)
+
+
+def dec_block(sd, p, x, fusion):
+    identity = x
+    if fusion:
+        identity = _bnb(sd, p + ".identity.1", F.conv2d(x, sd[p + ".identity.0.weight"], sd[p + ".identity.0.bias"]))
+    q = p + ".process"
+    out = F.relu(_bnb(sd, q + ".1", F.conv2d(x, sd[q + ".0.weight"], sd[q + ".0.bias"])))
+    out = F.relu(_bnb(sd, q + ".4", F.conv2d(out, sd[q + ".3.weight"], sd[q + ".3.bias"], padding=1)))
+    out = _bnb(sd, q + ".7", F.conv2d(out, sd[q + ".6.weight"], sd[q + ".6.bias"]))
+    return F.relu(out + identity)
+
+
+def dec_level(sd, p, x_low, x_high, n_blocks=3):
+    r = _bnb(sd, p + ".chan_reduce.1", F.conv2d(x_low, sd[p + ".chan_reduce.0.weight"], sd[p + ".chan_reduce.0.bias"]))
+    x = torch.cat((F.interpolate(r, scale_factor=2, mode="bilinear", align_corners=True), x_high), 1)
+    for j in range(n_blocks):
+        x = dec_block(sd, f"{p}.blocks.{j}", x, j == 0)
+    return x
+
+
+def resnet50_stage_maps(sd, imgs):
+    x = F.conv2d(imgs, sd["conv1.weight"], stride=2, padding=3)
+    x = F.relu(_bn(sd, "bn1", x))
+    x = F.max_pool2d(x, 3, 2, 1)
+    maps = []
+    for li, (planes, blocks, stride) in enumerate(LAYERS, start=1):
+        for j in range(blocks):
+            x = bottleneck(sd, f"layer{li}.{j}", x, stride if j == 0 else 1, j == 0)
+        maps.append(x)
+    return maps
+
+
+def resnet50_dense(sd, imgs):
+    """ResNet_from_Any(dense=...)._forward_impl: stage maps -> 3 decoder levels -> output_conv"""
+    m = resnet50_stage_maps(sd, imgs)
+    out = dec_level(sd, "decoder_levels.0", m[-1], m[-2])
+    out = dec_level(sd, "decoder_levels.1", out, m[-3])
+    out = dec_level(sd, "decoder_levels.2", out, m[-4])
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
+    h = F.conv2d(up(out), sd["output_conv.1.weight"], sd["output_conv.1.bias"], padding=1)
+    h = F.conv2d(up(h), sd["output_conv.3.weight"], sd["output_conv.3.bias"], padding=1)
+    return torch.sigmoid(F.conv2d(F.relu(h), sd["output_conv.5.weight"], sd["output_conv.5.bias"]))

@@ -203,19 +203,53 @@ def moco_sincos_pos_embed(embed_dim, grid_size, temperature=10000.):
     return torch.cat([torch.zeros(1, 1, embed_dim), emb], dim=1)
 
 
+class ResNet_Dec_Block(nn.Module):
+    """parameter container of the reference's decoder bottleneck (models.py:14-41): identity branch
+    (1x1 conv + BN when the input is the 2C-wide concatenation) and process = 1x1 -> BN -> ReLU ->
+    3x3 -> BN -> ReLU -> 1x1 -> BN; same Sequential indices, hence the same state_dict keys."""
+
+    def __init__(self, channels, fusion=False):
+        super().__init__()
+        if fusion:
+            self.identity = nn.Sequential(nn.Conv2d(channels * 2, channels, 1), nn.BatchNorm2d(channels))
+            conv1 = nn.Conv2d(channels * 2, channels // 4, 1)
+        else:
+            self.identity = nn.Identity()
+            conv1 = nn.Conv2d(channels, channels // 4, 1)
+        self.process = nn.Sequential(conv1, nn.BatchNorm2d(channels // 4), nn.ReLU(),
+                                     nn.Conv2d(channels // 4, channels // 4, 3, padding=1),
+                                     nn.BatchNorm2d(channels // 4), nn.ReLU(),
+                                     nn.Conv2d(channels // 4, channels, 1), nn.BatchNorm2d(channels))
+        self.relu = nn.ReLU()
+
+
+class ResNet_Dec_Level(nn.Module):
+    """models.py:44-60: chan_reduce (1x1 conv + BN) -> bilinear x2 -> cat with the skip map -> blocks"""
+
+    def __init__(self, channels, n_blocks):
+        super().__init__()
+        self.chan_reduce = nn.Sequential(nn.Conv2d(channels * 2, channels, 1), nn.BatchNorm2d(channels))
+        self.up = nn.Identity()  # nn.Upsample holds no tensors
+        blocks = [ResNet_Dec_Block(channels, fusion=True)]
+        for _ in range(1, n_blocks):
+            blocks.append(ResNet_Dec_Block(channels, fusion=False))
+        self.blocks = nn.Sequential(*blocks)
+
+
 class ResNet_from_Any(ResNet50):
     """Reference `Models/models.py:63-152`: torchvision ResNet50 with `fc = Identity` (no `fc.*` keys:
-    the reference assigns Identity before its strict load, :77-80), optional linear head.  The dense
-    decoder of the ResNet path (`ResNet_Dec_Level`, :16-60, :88-135) is a later SURVEY §8(f) row."""
+    the reference assigns Identity before its strict load, :77-80), optional linear head, and — when
+    `dense` — the U-Net-style decoder over the four stage maps (`decoder_levels.{0-2}.*`,
+    `output_conv.*`, :88-135): every convolution is a GEMM of libssl4gie_hip.so on channels-last
+    maps (1x1 = Linear with bias, 3x3 = implicit GEMM), BatchNorm fuses the ReLU / residual add,
+    bilinear x2 and the ReLU -> 1x1 -> Sigmoid tail are the DPT kernels; the channel concatenation
+    is a torch.cat on the last (channel) axis."""
 
     def __init__(self, weight_path, head, num_classes, frozen, dense, ImageNet_weights=False):
         super().__init__()
         if ImageNet_weights:
             raise RuntimeError("ImageNet weights are downloaded by the reference (models.py:70-75); no "
                                "network here — load a state_dict instead")
-        if dense:
-            raise NotImplementedError("the ResNet dense decoder (reference models.py:88-135) is a later "
-                                      "§8(f) row of this build")
         self.fc = nn.Identity()
         if weight_path is not None:
             self.load_state_dict(torch.load(weight_path, map_location="cpu"))
@@ -224,11 +258,66 @@ class ResNet_from_Any(ResNet50):
             self.lin_head = nn.Linear(2048, num_classes)
         self.frozen = frozen
         self.dense = dense
+        if dense:
+            self.decoder_levels = nn.ModuleList([ResNet_Dec_Level(1024, 3), ResNet_Dec_Level(512, 3),
+                                                 ResNet_Dec_Level(256, 3)])
+            # indices 0, 2 (Upsample), 4 (ReLU), 6 (Sigmoid) are parameter-free
+            self.output_conv = nn.Sequential(nn.Identity(), nn.Conv2d(256, 128, 3, 1, 1), nn.Identity(),
+                                             nn.Conv2d(128, 32, 3, 1, 1), nn.Identity(),
+                                             nn.Conv2d(32, 1, 1, 1, 0), nn.Identity())
+
+    # ------------------------------------------------------------------ dense decoder
+    def _c1b(self, x, conv):
+        """Conv2d(k=1) with bias on a channels-last map"""
+        B, H, W, C = x.shape
+        y = LinearFn.apply(x.reshape(-1, C), conv.weight, conv.bias, self.dtype_, self.dtype_,
+                           self.sink(), self.lp_cache)
+        return y.view(B, H, W, -1)
+
+    def _dec_block(self, x, blk: ResNet_Dec_Block):
+        from ..dpt_engine import Conv3x3Fn
+        identity = x
+        if not isinstance(blk.identity, nn.Identity):
+            identity = self._bn(self._c1b(x, blk.identity[0]), blk.identity[1], False)
+        p = blk.process
+        out = self._bn(self._c1b(x, p[0]), p[1], True)
+        out = Conv3x3Fn.apply(out, p[3].weight, p[3].bias, 1, False, self.sink(), self.lp_cache)
+        out = self._bn(out, p[4], True)
+        out = self._c1b(out, p[6])
+        return self._bn(out, p[7], True, res=identity)  # relu(bn(out) + identity)
+
+    def _dec_level(self, lvl: ResNet_Dec_Level, x_low, x_high):
+        from ..dpt_engine import Upsample2xFn
+        up = Upsample2xFn.apply(self._bn(self._c1b(x_low, lvl.chan_reduce[0]), lvl.chan_reduce[1], False))
+        x = torch.cat((up, x_high), dim=3)  # channels-last: torch.cat(dim=1) of the NCHW reference
+        for blk in lvl.blocks:
+            x = self._dec_block(x, blk)
+        return x
+
+    def decode(self, fmaps):
+        """models.py:128-135 on channels-last maps -> fp32 [B, 1, H, W]"""
+        from ..dpt_engine import Conv3x3Fn, DepthHeadFn, Upsample2xFn
+        out = self._dec_level(self.decoder_levels[0], fmaps[-1], fmaps[-2])
+        for i in range(1, len(self.decoder_levels)):
+            out = self._dec_level(self.decoder_levels[i], out, fmaps[-i - 2])
+        oc = self.output_conv
+        h = Upsample2xFn.apply(out)
+        h = Conv3x3Fn.apply(h, oc[1].weight, oc[1].bias, 1, False, self.sink(), self.lp_cache)
+        h = Upsample2xFn.apply(h)
+        h = Conv3x3Fn.apply(h, oc[3].weight, oc[3].bias, 1, False, self.sink(), self.lp_cache)
+        return DepthHeadFn.apply(h, oc[5].weight, oc[5].bias, self.sink())
 
     def forward_features(self, x):
-        return self.forward_maps(x)
+        return self.forward_maps(x, all_stages=bool(self.dense))
 
     def forward(self, imgs):
+        if self.dense:
+            if self.frozen:
+                with torch.no_grad():
+                    fmaps = self.forward_maps(imgs, all_stages=True)
+            else:
+                fmaps = self.forward_maps(imgs, all_stages=True)
+            return self.decode(fmaps)
         if self.frozen:
             with torch.no_grad():
                 x = self.pooled(imgs)
