@@ -331,7 +331,10 @@ def main():
     except Exception:
         opt = torch.optim.AdamW(param_groups(model), lr=1.5e-4, betas=(0.9, 0.95))
 
-    g = torch.Generator("cpu").manual_seed(0 + rank)  # seed + rank (main_pretrain.py:116)
+    # seed + rank (main_pretrain.py:116); SSL4GIE_BENCH_SAME_DATA=1 feeds every rank the same batch,
+    # which makes the N-rank run numerically comparable to N=1 (tools/gpu_rehearse_dp.sh)
+    same = os.environ.get("SSL4GIE_BENCH_SAME_DATA") == "1"
+    g = torch.Generator("cpu").manual_seed(0 if same else rank)
     imgs = torch.randn(a.batch, 3, 224, 224, generator=g).pin_memory().to(dev, non_blocking=True)
 
     def step():

@@ -131,9 +131,13 @@ def init_from_env(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        # rehearsal on a box with fewer GPUs than ranks (SSL4GIE_DIST_BACKEND=gloo): ranks share devices
+        local = local % torch.cuda.device_count()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SSL4GIE_DIST_BACKEND") or \
+                ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
