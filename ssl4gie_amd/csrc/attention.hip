@@ -333,6 +333,310 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------ long sequences (N % 128 == 0)
+// Streaming ("flash") variants for hd = 64 and sequences that do not fit LDS (the detection
+// backbone's global-attention blocks at 1024^2: N = 4096, reference models.py:281-285,310-336).
+// A workgroup of 8 waves owns 128 queries (forward, dQ) or 128 keys (dK/dV) — their MFMA
+// fragments stay in registers — and streams the other side through LDS in blocks of 128 rows:
+// two images (K,V resp. Q,dO) x two buffers = 64 KiB, next block prefetched into registers while
+// the current one is consumed, one __syncthreads per block.  Forward keeps the running row
+// maximum / sum per query lane (online softmax, exp2 domain) and rescales the O^T accumulators;
+// backward recomputes P from the saved log-sum-exp, with delta_q = sum_d dO O from a small
+// pre-pass kernel.  No N x N tensor reaches HBM, no atomics, fixed summation order.
+#define LONG_WAVES 8
+#define LONG_BLK 128
+struct LongRegs {
+    u32x4 a[2], b[2];
+};
+// rows row0 .. row0+127 of two [*, 64] bf16 operands (row strides rsa / rsb elements)
+DEVI void long_load(LongRegs& r, const bf16_t* A, long long rsa, const bf16_t* Bp, long long rsb,
+                    int row0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 64 * LONG_WAVES, row = idx >> 3, c = idx & 7;
+        r.a[i] = *(const u32x4*)(A + (size_t)(row0 + row) * rsa + c * 8);
+        r.b[i] = *(const u32x4*)(Bp + (size_t)(row0 + row) * rsb + c * 8);
+    }
+}
+DEVI void long_store(const LongRegs& r, char* imgA, char* imgB, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 64 * LONG_WAVES, row = idx >> 3, c = idx & 7;
+        *(u32x4*)(imgA + img_off<64>(row, c)) = r.a[i];
+        *(u32x4*)(imgB + img_off<64>(row, c)) = r.b[i];
+    }
+}
+
+__global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_fwd_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H,
+    float scale) {
+    constexpr int HD = 64, KS = 2, DT = 4, NKT = LONG_BLK / 16, IMG = LONG_BLK * HD * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | V]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int D = H * HD;
+    const long long rs = 3LL * D;
+    const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
+    const int q0 = blockIdx.x * LONG_BLK + wave * 16;
+    const int q = q0 + (lane & 15);
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(qb, rs, q, ks, lane);
+    const float c = scale * 1.44269504088896340736f;
+    float m = -INFINITY, lsum = 0.f;
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0, 0, 0, 0};
+    const int nkb = N / LONG_BLK;
+    LongRegs r;
+    long_load(r, qb + D, rs, qb + 2 * D, rs, 0, tid);
+    long_store(r, smem, smem + IMG, tid);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const char* Kimg = smem + (kb & 1) * 2 * IMG;
+        const char* Vimg = Kimg + IMG;
+        if (kb + 1 < nkb) long_load(r, qb + D, rs, qb + 2 * D, rs, (kb + 1) * LONG_BLK, tid);
+        f32x4 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            s[kt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                s[kt] = MFMA16(row_frag<HD>(Kimg, kt * 16, ks, lane), qf[ks], s[kt]);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) mx = fmaxf(mx, s[kt][rr]);
+        mx = fmaxf(m, group_max(mx));
+        const float alpha = __builtin_amdgcn_exp2f((m - mx) * c);  // 0 on the first block (m = -inf)
+        const float mc = mx * c;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float pp = __builtin_amdgcn_exp2f(s[kt][rr] * c - mc);
+                s[kt][rr] = pp;
+                sum += pp;
+            }
+        lsum = lsum * alpha + sum;
+        m = mx;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+#pragma unroll
+        for (int kp = 0; kp < NKT / 2; ++kp) {
+            const bf16x8 pf = pack8(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt] = MFMA16(tr_frag<HD>(Vimg, kp * 32, dt * 16, lane), pf, o[dt]);
+        }
+        if (kb + 1 < nkb) {
+            char* nK = smem + ((kb + 1) & 1) * 2 * IMG;
+            long_store(r, nK, nK + IMG, tid);
+        }
+        __syncthreads();
+    }
+    const float l = group_sum(lsum);
+    const float inv = 1.0f / l;
+    bf16_t* orow = out + ((size_t)b * N + q) * D + h * HD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) st4(orow + dt * 16, o[dt] * inv);
+    if (g == 0) lse[((size_t)b * H + h) * N + q] = m * scale + __logf(l);
+}
+
+// delta[b, h, q] = sum_d dO[b, q, h, d] O[b, q, h, d]   (8 lanes per (row, head), 16 B each)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out,
+                                                         const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, long long rows,
+                                                         int N, int H) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (row, head, chunk)
+    const long long rh = idx >> 3;
+    const int ch = (int)(idx & 7);
+    if (rh >= rows * H) return;
+    const long long row = rh / H;
+    const int h = (int)(rh % H);
+    const size_t off = ((size_t)row * H + h) * 64 + ch * 8;
+    const u32x4 v = *(const u32x4*)(dout + off), o = *(const u32x4*)(out + off);
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dot += __uint_as_float(v[j] << 16) * __uint_as_float(o[j] << 16);
+        dot += __uint_as_float(v[j] & 0xffff0000u) * __uint_as_float(o[j] & 0xffff0000u);
+    }
+    dot += __shfl_xor(dot, 4, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot += __shfl_xor(dot, 1, 64);
+    if (ch == 0) {
+        const long long bb = row / N, n = row % N;
+        delta[((size_t)bb * H + h) * N + n] = dot;
+    }
+}
+
+// dQ: the workgroup owns 128 queries and streams K, V
+__global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dq_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    constexpr int HD = 64, KS = 2, DT = 4, IMG = LONG_BLK * HD * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int D = H * HD;
+    const long long rs = 3LL * D;
+    const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
+    const bf16_t* dob = dout + (size_t)b * N * D + h * HD;
+    const int q = blockIdx.x * LONG_BLK + wave * 16 + (lane & 15);
+    const float LOG2E = 1.44269504088896340736f;
+    const float c = scale * LOG2E;
+    bf16x8 qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = row_frag_global(qb, rs, q, ks, lane);
+        dof[ks] = row_frag_global(dob, D, q, ks, lane);
+    }
+    const float l2 = lse[((size_t)b * H + h) * N + q] * LOG2E;
+    const float dl = delta[((size_t)b * H + h) * N + q];
+    f32x4 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
+    const int nkb = N / LONG_BLK;
+    LongRegs r;
+    long_load(r, qb + D, rs, qb + 2 * D, rs, 0, tid);
+    long_store(r, smem, smem + IMG, tid);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const char* Kimg = smem + (kb & 1) * 2 * IMG;
+        const char* Vimg = Kimg + IMG;
+        if (kb + 1 < nkb) long_load(r, qb + D, rs, qb + 2 * D, rs, (kb + 1) * LONG_BLK, tid);
+#pragma unroll 1
+        for (int kp = 0; kp < LONG_BLK / 32; ++kp) {
+            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = MFMA16(row_frag<HD>(Kimg, kp * 32, ks, lane), qf[ks], s0);
+                s1 = MFMA16(row_frag<HD>(Kimg, kp * 32 + 16, ks, lane), qf[ks], s1);
+                p0 = MFMA16(row_frag<HD>(Vimg, kp * 32, ks, lane), dof[ks], p0);
+                p1 = MFMA16(row_frag<HD>(Vimg, kp * 32 + 16, ks, lane), dof[ks], p1);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float pa = __builtin_amdgcn_exp2f(s0[rr] * c - l2);
+                const float pb = __builtin_amdgcn_exp2f(s1[rr] * c - l2);
+                s0[rr] = pa * (p0[rr] - dl);  // dS^T
+                s1[rr] = pb * (p1[rr] - dl);
+            }
+            const bf16x8 dsf = pack8(s0, s1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                dq[dt] = MFMA16(tr_frag<HD>(Kimg, kp * 32, dt * 16, lane), dsf, dq[dt]);
+        }
+        if (kb + 1 < nkb) {
+            char* nK = smem + ((kb + 1) & 1) * 2 * IMG;
+            long_store(r, nK, nK + IMG, tid);
+        }
+        __syncthreads();
+    }
+    bf16_t* dr = dqkv + (size_t)b * N * rs + h * HD + (size_t)q * rs + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) st4(dr + dt * 16, dq[dt] * scale);
+}
+
+// dK, dV: the workgroup owns 128 keys and streams Q, dO (+ the lse / delta rows of the block)
+__global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dkv_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    constexpr int HD = 64, KS = 2, DT = 4, IMG = LONG_BLK * HD * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][Q | dO], then [buf][lse | delta]
+    float* stat = (float*)(smem + 4 * IMG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int D = H * HD;
+    const long long rs = 3LL * D;
+    const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
+    const bf16_t* dob = dout + (size_t)b * N * D + h * HD;
+    const float* lrow = lse + ((size_t)b * H + h) * N;
+    const float* drow = delta + ((size_t)b * H + h) * N;
+    const int key = blockIdx.x * LONG_BLK + wave * 16 + (lane & 15);
+    const float LOG2E = 1.44269504088896340736f;
+    const float c = scale * LOG2E;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = row_frag_global(qb + D, rs, key, ks, lane);
+        vf[ks] = row_frag_global(qb + 2 * D, rs, key, ks, lane);
+    }
+    f32x4 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        dk[dt] = f32x4{0, 0, 0, 0};
+        dv[dt] = f32x4{0, 0, 0, 0};
+    }
+    const int nqb = N / LONG_BLK;
+    LongRegs r;
+    float st_next = 0.f;  // threads 0..127: lse * log2e, 128..255: delta of the next block
+    auto stat_load = [&](int blk) {
+        if (tid < LONG_BLK) st_next = lrow[blk * LONG_BLK + tid] * LOG2E;
+        else if (tid < 2 * LONG_BLK) st_next = drow[blk * LONG_BLK + tid - LONG_BLK];
+    };
+    long_load(r, qb, rs, dob, D, 0, tid);
+    stat_load(0);
+    long_store(r, smem, smem + IMG, tid);
+    if (tid < 2 * LONG_BLK) stat[tid] = st_next;
+    __syncthreads();
+    for (int qbk = 0; qbk < nqb; ++qbk) {
+        const char* Qimg = smem + (qbk & 1) * 2 * IMG;
+        const char* Oimg = Qimg + IMG;
+        const float* lse_s = stat + (qbk & 1) * 2 * LONG_BLK;
+        const float* del_s = lse_s + LONG_BLK;
+        if (qbk + 1 < nqb) {
+            long_load(r, qb, rs, dob, D, (qbk + 1) * LONG_BLK, tid);
+            stat_load(qbk + 1);
+        }
+#pragma unroll 1
+        for (int qp = 0; qp < LONG_BLK / 32; ++qp) {
+            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = MFMA16(row_frag<HD>(Qimg, qp * 32, ks, lane), kf[ks], s0);
+                s1 = MFMA16(row_frag<HD>(Qimg, qp * 32 + 16, ks, lane), kf[ks], s1);
+                p0 = MFMA16(row_frag<HD>(Oimg, qp * 32, ks, lane), vf[ks], p0);
+                p1 = MFMA16(row_frag<HD>(Oimg, qp * 32 + 16, ks, lane), vf[ks], p1);
+            }
+            const int qa = qp * 32 + 4 * g;
+            const f32x4 la = *(const f32x4*)(lse_s + qa), lb = *(const f32x4*)(lse_s + qa + 16);
+            const f32x4 da = *(const f32x4*)(del_s + qa), db = *(const f32x4*)(del_s + qa + 16);
+            f32x4 pa, pb, dsa, dsb;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                pa[rr] = __builtin_amdgcn_exp2f(s0[rr] * c - la[rr]);
+                pb[rr] = __builtin_amdgcn_exp2f(s1[rr] * c - lb[rr]);
+                dsa[rr] = pa[rr] * (p0[rr] - da[rr]);
+                dsb[rr] = pb[rr] * (p1[rr] - db[rr]);
+            }
+            const bf16x8 pf = pack8(pa, pb), dsf = pack8(dsa, dsb);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = MFMA16(tr_frag<HD>(Oimg, qp * 32, dt * 16, lane), pf, dv[dt]);
+                dk[dt] = MFMA16(tr_frag<HD>(Qimg, qp * 32, dt * 16, lane), dsf, dk[dt]);
+            }
+        }
+        if (qbk + 1 < nqb) {
+            char* nQ = smem + ((qbk + 1) & 1) * 2 * IMG;
+            long_store(r, nQ, nQ + IMG, tid);
+            if (tid < 2 * LONG_BLK) stat[((qbk + 1) & 1) * 2 * LONG_BLK + tid] = st_next;
+        }
+        __syncthreads();
+    }
+    bf16_t* dr = dqkv + (size_t)b * N * rs + h * HD + (size_t)key * rs + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        st4(dr + D + dt * 16, dk[dt] * scale);
+        st4(dr + 2 * D + dt * 16, dv[dt]);
+    }
+}
+
 // ------------------------------------------------------------------ f32 row kernels
 // one wave per row; rows of `cols` floats (cols <= a few thousand)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s,
@@ -391,9 +695,11 @@ static ssl4gie_gemm_desc bdesc(int M, int N, int K, int B, int H) {
     return d;
 }
 
+static bool attn_long(int N, int hd) { return N > 256 && N % LONG_BLK == 0 && hd == 64; }
+
 extern "C" size_t ssl4gie_attn_workspace_bytes(int dtype, int B, int N, int H, int hd) {
-    (void)hd;
-    if (dtype == SSL4GIE_BF16) return 0;
+    if (dtype == SSL4GIE_BF16)  // long sequences: delta[b, h, q] of the backward pass
+        return attn_long(N, hd) ? (size_t)B * H * N * sizeof(float) : 0;
     return (size_t)2 * B * H * N * N * sizeof(float);  // scores + dscores
 }
 
@@ -432,6 +738,20 @@ extern "C" int ssl4gie_attn_fwd(const void* qkv, void* out, float* lse, int dtyp
     const int D = H * hd;
     if (dtype == SSL4GIE_BF16) {
         REQUIRE(hd == 32 || hd == 64);
+        if (attn_long(N, hd)) {
+            const int lds = 4 * LONG_BLK * 64 * 2;
+            static bool attr = false;
+            if (!attr) {
+                HIP_RET(hipFuncSetAttribute((const void*)attn_long_fwd_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                attr = true;
+            }
+            ProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * hd, st);
+            hipLaunchKernelGGL(attn_long_fwd_kernel, dim3(N / LONG_BLK, B * H), dim3(64 * LONG_WAVES),
+                               lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+            LAUNCH_CHECK();
+            return 0;
+        }
         REQUIRE(N <= 256);
 #define FWD(HD_)                                                                      \
     if (N <= 64) return launch_fwd<HD_, 4>(qkv, out, lse, B, N, H, scale, st);        \
@@ -472,6 +792,33 @@ extern "C" int ssl4gie_attn_bwd(const void* qkv, const void* out, const void* do
     const int D = H * hd;
     if (dtype == SSL4GIE_BF16) {
         REQUIRE(hd == 32 || hd == 64);
+        if (attn_long(N, hd)) {
+            REQUIRE(workspace);
+            float* delta = (float*)workspace;
+            const long long rows = (long long)B * N;
+            const long long items = rows * H * 8;
+            hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                               (const bf16_t*)out, (const bf16_t*)dout, delta, rows, N, H);
+            LAUNCH_CHECK();
+            const int lds_q = 4 * LONG_BLK * 64 * 2, lds_kv = lds_q + 4 * LONG_BLK * (int)sizeof(float);
+            static bool attr = false;
+            if (!attr) {
+                HIP_RET(hipFuncSetAttribute((const void*)attn_long_bwd_dq_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_q));
+                HIP_RET(hipFuncSetAttribute((const void*)attn_long_bwd_dkv_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
+                attr = true;
+            }
+            ProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * hd, st);
+            dim3 grid(N / LONG_BLK, B * H), block(64 * LONG_WAVES);
+            hipLaunchKernelGGL(attn_long_bwd_dq_kernel, grid, block, lds_q, st, (const bf16_t*)qkv,
+                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(attn_long_bwd_dkv_kernel, grid, block, lds_kv, st, (const bf16_t*)qkv,
+                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+            LAUNCH_CHECK();
+            return 0;
+        }
         REQUIRE(N <= 256);
 #define BWD(HD_)                                                                               \
     if (N <= 64) return launch_bwd<HD_, 4>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);     \

@@ -247,6 +247,41 @@ def test_attention_bf16_fused(N, hd):
         assert rel_err(got[:, :, i], ref[:, :, i]) < 3e-2, f"d{name}"
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 512, 3), (1, 1024, 2), (1, 4096, 1)])
+def test_attention_bf16_long_sequences(B, N, H):
+    """streaming kernels (N % 128 == 0, hd 64): the detection backbone's global attention"""
+    from ssl4gie_amd import ops
+    hd = 64
+    qkv = (torch.randn(B, N, 3 * H * hd, generator=G(6)) * 1.5).to(BF)
+    do = torch.randn(B, N, H * hd, generator=G(7)).to(BF)
+    t = qkv.double().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(t, B, N, H, hd)
+    o, lse = ops.attn_fwd(qkv.to(DEV), B, N, H, hd)
+    assert rel_err(o.float(), o_ref.detach()) < 1.5e-2
+    assert rel_err(lse, lse_ref.detach()) < 2e-3
+    o_ref.backward(do.double())
+    dqkv = ops.attn_bwd(qkv.to(DEV), o, do.to(DEV), lse, B, N, H, hd)
+    D = H * hd
+    ref = t.grad.reshape(B, N, 3, D)
+    got = dqkv.float().cpu().reshape(B, N, 3, D)
+    for i, name in enumerate("qkv"):
+        assert rel_err(got[:, :, i], ref[:, :, i]) < 3e-2, f"d{name}"
+
+
+def test_attention_f32_long_sequence():
+    from ssl4gie_amd import ops
+    B, N, H, hd = 1, 384, 2, 64
+    qkv = torch.randn(B, N, 3 * H * hd, generator=G(8))
+    do = torch.randn(B, N, H * hd, generator=G(9))
+    t = qkv.double().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(t, B, N, H, hd)
+    o_ref.backward(do.double())
+    o, lse = ops.attn_fwd(qkv.to(DEV), B, N, H, hd)
+    assert rel_err(o, o_ref.detach()) < 1e-5 and rel_err(lse, lse_ref.detach()) < 1e-5
+    dqkv = ops.attn_bwd(qkv.to(DEV), o, do.to(DEV), lse, B, N, H, hd)
+    assert rel_err(dqkv, t.grad) < 2e-5
+
+
 def test_attention_bf16_one_hot_exact():
     """V = one-hot rows, scores forced to pick one key: O must equal the selected V row exactly."""
     from ssl4gie_amd import ops
