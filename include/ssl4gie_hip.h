@@ -330,6 +330,27 @@ int ssl4gie_maxpool3x3s2_bwd(const void* dy, const unsigned char* arg, void* dx,
 int ssl4gie_avgpool_fwd(const void* x, float* y, int dtype, int B, int HW, int C, void* stream);
 int ssl4gie_avgpool_bwd(const float* dy, void* dx, int dtype, int B, int HW, int C, void* stream);
 
+/* ---------------------------------------------------------------- detection pyramid glue (channels-last)
+ * ViTDet_FPN (Models/models.py:213-259) around its GEMM-shaped convolutions:
+ * maxpool2x2: nn.MaxPool2d(2) (:218); backward recomputes the window's first maximum from x.
+ * gelu_map: nn.GELU (:241), exact erf form; dy != NULL gives dy * gelu'(x).
+ * map_layernorm: nn.LayerNorm((C, H, W)) (:220-222 ...): per-image statistics over all M = H*W*C
+ *   elements (biased variance, eps inside the sqrt) and a per-ELEMENT affine; w / bias / dw / db
+ *   are fp32 [M] in the map's own (channels-last) element order.  mean / rstd [B] are kept for
+ *   backward.  M % 8 == 0. */
+int ssl4gie_maxpool2x2_fwd(const void* x, void* y, int dtype, int B, int H, int W, int C,
+                           void* stream);
+int ssl4gie_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W,
+                           int C, void* stream);
+int ssl4gie_gelu_map(const void* x, const void* dy, void* out, int dtype, long long n, void* stream);
+size_t ssl4gie_map_layernorm_workspace_bytes(int B);
+int ssl4gie_map_layernorm_fwd(const void* x, const float* w, const float* bias, void* y, float* mean,
+                              float* rstd, float eps, float* workspace, int dtype, int B, long long M,
+                              void* stream);
+int ssl4gie_map_layernorm_bwd(const void* x, const void* dy, const float* w, const float* mean,
+                              const float* rstd, void* dx, float* dw, float* db, int accumulate,
+                              float* workspace, int dtype, int B, long long M, void* stream);
+
 /* ---------------------------------------------------------------- launch profiler (bench.py)
  * HIP events on the launch stream around every launch of the heavy kernels, used for the
  * `roofline` object of the bench line.  Process-global, not thread-safe, off by default.

@@ -25,6 +25,9 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from collections import OrderedDict
+
+from .. import ops
 from ..engine import EngineModule, LinearFn, PatchEmbedFn
 from .DPT_decoder import DPT_decoder
 from .resnet import ResNet50
@@ -51,9 +54,13 @@ class _ViTBackbone(EngineModule):
         self.norm = norm_layer(embed_dim)
 
     def _finish(self, head, num_classes, frozen, dense, det, fixed_size, out_token):
-        if det:
-            raise NotImplementedError("det=True (WindowedAttention + ViTDet_FPN, reference "
-                                      "models.py:155-259) is a later §8(f) row of this build")
+        if det:  # reference models.py:281-285, 302-307 (and :409-414, :522-527)
+            assert fixed_size % (16 * WINDOW) == 0, "fixed_size must be a multiple of 256"
+            self.fixed_size = fixed_size
+            self.fpn = self.adopt(ViTDet_FPN(grid=fixed_size // 16, dim=self.embed_dim))
+            self.out_channels = 256
+            self.patch_embed.img_size = (fixed_size, fixed_size)
+            del self.cls_token
         self.head_flag = head
         if head:
             self.lin_head = nn.Linear(self.embed_dim, num_classes)
@@ -77,6 +84,47 @@ class _ViTBackbone(EngineModule):
             return tap_out  # fp32 [B, 1+L, D] each; final norm skipped (reference :456)
         return self._ln(tok, self.norm, out_dtype=torch.float32)
 
+    # ------------------------------------------------------------------ detection trunk
+    def _pos_embed_interp(self):
+        """reference :310-320: the 14 x 14 grid part of pos_embed resized bilinearly
+        (align_corners=True) to the fixed_size / 16 grid -> [1, g*g, D] (torch ops: a 768 x 64 x 64
+        table, differentiable w.r.t. the parameter)"""
+        g = self.fixed_size // 16
+        D = self.embed_dim
+        p2 = self.pos_embed[:, 1:, :].transpose(1, 2).reshape(1, D, 14, 14)
+        p2 = nn.functional.interpolate(p2, size=(g, g), mode="bilinear", align_corners=True)
+        return p2.reshape(1, D, g * g).transpose(1, 2)
+
+    def _trunk_det(self, imgs):
+        """reference forward_features with det=True (:325-338).  The 16 x 16-token windows of
+        WindowedAttention (:155-210) are realised by ORDER: tokens are embedded directly in
+        window-major order (`perm`, the reference's own index construction), so a windowed block is
+        the plain block executor on [B * windows, 256, D] and a global block the same executor on
+        [B, N, D] (attention is permutation-equivariant, LayerNorm / MLP are per token); the inverse
+        permutation is applied once, after the final norm."""
+        from ..engine import PatchEmbedDetFn
+        self._prepare()
+        assert imgs.shape[2:] == (self.fixed_size, self.fixed_size), "input size mismatch"
+        g = self.fixed_size // 16
+        B, N, D = imgs.shape[0], g * g, self.embed_dim
+        perm, inv = window_permutation(g, WINDOW, imgs.device)
+        y = PatchEmbedDetFn.apply(imgs.float(), self.patch_embed.proj.weight, self.patch_embed.proj.bias,
+                                  perm.unsqueeze(0).repeat(B, 1), 16, self.dtype_, self.sink(), self._lp)
+        x = y.view(B, N, D) + self._pos_embed_interp()[:, perm]
+        nw = N // (WINDOW * WINDOW)
+        i = 0
+        while i < len(self.blocks):
+            windowed = i in WINDOWED_BLOCKS
+            j = i
+            while j < len(self.blocks) and (j in WINDOWED_BLOCKS) == windowed:
+                j += 1
+            shape = (B * nw, WINDOW * WINDOW, D) if windowed else (B, N, D)
+            x, _ = self._blocks(self.blocks[i:j], x.reshape(shape).contiguous(), self.num_heads,
+                                self.norm.eps)
+            i = j
+        x = self._ln(x.reshape(B, N, D), self.norm, out_dtype=torch.float32)
+        return x[:, inv]
+
     def _readout(self, x):
         if self.out_token == "cls":
             x = x[:, 0]
@@ -87,6 +135,8 @@ class _ViTBackbone(EngineModule):
         return x
 
     def forward_features(self, x, dense=None):
+        if self.det:
+            return self._trunk_det(x)
         return self._trunk(x, self.dense if dense is None else dense)
 
     def forward(self, imgs):
@@ -97,7 +147,89 @@ class _ViTBackbone(EngineModule):
             x = self.forward_features(imgs)
         if self.dense:  # reference models.py:346-347, 464-465, 566-567
             return self.decoder(x)
+        if self.det:  # :355-356
+            return self.fpn(x)
         return self._readout(x)
+
+
+WINDOW = 16                                   # WindowedAttention(window_size=16), models.py:163
+WINDOWED_BLOCKS = (0, 1, 3, 4, 6, 7, 9, 10)   # models.py:282
+_PERM_CACHE = {}
+
+
+def window_permutation(s, window=WINDOW, device="cpu"):
+    """perm / inv_perm of WindowedAttention.forward (models.py:179-191): token indices of the s x s
+    grid gathered window by window (row-major windows, row-major inside a window)."""
+    key = (s, window, str(device))
+    if key not in _PERM_CACHE:
+        idxs = torch.arange(s * s).reshape(s, s)
+        perm = torch.cat([idxs[i:i + window, j:j + window].reshape(-1)
+                          for i in range(0, s, window) for j in range(0, s, window)])
+        _PERM_CACHE[key] = (perm.to(device), torch.argsort(perm).to(device))
+    return _PERM_CACHE[key]
+
+
+class ViTDet_FPN(EngineModule):
+    """Reference `ViTDet_FPN` (models.py:213-259) on the engine: same Sequential layout, hence the
+    same state_dict keys (`fpn1.1.weight`, `fpn4.5.bias`, ...).  `grid` is the token grid of the
+    backbone (64 for the reference's hard-coded 1024 x 1024 input: LayerNorm shapes (256,32,32) ...
+    (256,256,256)); smaller grids scale every LayerNorm shape proportionally (used by the tests).
+    Output: OrderedDict {"0": l4, "1": l3, "2": l2, "3": l1, "pool"} of fp32 NCHW maps."""
+
+    def __init__(self, grid=64, dim=768, out=256):
+        super().__init__()
+        g = grid
+        self.fpn1 = nn.Sequential(nn.Identity(), nn.Conv2d(dim, out, 1), nn.LayerNorm((out, g // 2, g // 2)),
+                                  nn.Conv2d(out, out, 3, padding=1), nn.LayerNorm((out, g // 2, g // 2)))
+        self.fpn2 = nn.Sequential(nn.Conv2d(dim, out, 1), nn.LayerNorm((out, g, g)),
+                                  nn.Conv2d(out, out, 3, padding=1), nn.LayerNorm((out, g, g)))
+        self.fpn3 = nn.Sequential(nn.ConvTranspose2d(dim, dim, 2, 2), nn.Conv2d(dim, out, 1),
+                                  nn.LayerNorm((out, 2 * g, 2 * g)), nn.Conv2d(out, out, 3, padding=1),
+                                  nn.LayerNorm((out, 2 * g, 2 * g)))
+        self.fpn4 = nn.Sequential(nn.ConvTranspose2d(dim, dim, 2, 2), nn.LayerNorm((dim, 2 * g, 2 * g)),
+                                  nn.Identity(), nn.ConvTranspose2d(dim, dim, 2, 2), nn.Conv2d(dim, out, 1),
+                                  nn.LayerNorm((out, 4 * g, 4 * g)), nn.Conv2d(out, out, 3, padding=1),
+                                  nn.LayerNorm((out, 4 * g, 4 * g)))
+        self.grid = g
+
+    # ------------------------------------------------------------------ building blocks
+    def _c1(self, x, conv):
+        B, H, W, C = x.shape
+        y = LinearFn.apply(x.reshape(-1, C), conv.weight, conv.bias, self.dtype_, self.dtype_,
+                           self.sink(), self.lp_cache)
+        return y.view(B, H, W, -1)
+
+    def _c3(self, x, conv):
+        from ..dpt_engine import Conv3x3Fn
+        return Conv3x3Fn.apply(x, conv.weight, conv.bias, 1, False, self.sink(), self.lp_cache)
+
+    def _ct(self, x, ct):
+        from ..dpt_engine import ConvTransposeFn
+        B, H, W, C = x.shape
+        return ConvTransposeFn.apply(x.reshape(-1, C), ct.weight, ct.bias, B, H, W, self.sink(),
+                                     self.lp_cache)
+
+    def _mln(self, x, ln):
+        from ..det_engine import MapLayerNormFn
+        return MapLayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, self.sink(), self.lp_cache)
+
+    def forward(self, x):
+        """x: fp32 tokens [B, g*g, C] in row-major grid order"""
+        from ..det_engine import GeluMapFn, MaxPool2Fn
+        self._prepare()
+        B, N, C = x.shape
+        g = int(N ** 0.5)
+        m = x.to(self.dtype_).reshape(B, g, g, C)  # token-major rows ARE the channels-last map
+        f1, f2, f3, f4 = self.fpn1, self.fpn2, self.fpn3, self.fpn4
+        l1 = self._mln(self._c3(self._mln(self._c1(MaxPool2Fn.apply(m), f1[1]), f1[2]), f1[3]), f1[4])
+        l2 = self._mln(self._c3(self._mln(self._c1(m, f2[0]), f2[1]), f2[2]), f2[3])
+        l3 = self._mln(self._c3(self._mln(self._c1(self._ct(m, f3[0]), f3[1]), f3[2]), f3[3]), f3[4])
+        h = GeluMapFn.apply(self._mln(self._ct(m, f4[0]), f4[1]))
+        l4 = self._mln(self._c3(self._mln(self._c1(self._ct(h, f4[3]), f4[4]), f4[5]), f4[6]), f4[7])
+        nchw = lambda t: t.permute(0, 3, 1, 2).float()
+        l1o = nchw(l1)
+        pool = l1o[:, :, ::2, ::2]  # max_pool2d(kernel_size=1, stride=2)
+        return OrderedDict([("0", nchw(l4)), ("1", nchw(l3)), ("2", nchw(l2)), ("3", l1o), ("pool", pool)])
 
 
 class ViT_from_MAE(_ViTBackbone):

@@ -108,6 +108,12 @@ PROTOTYPES = {
     "ssl4gie_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_maxpool2x2_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_maxpool2x2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_gelu_map": (i32, [vp, vp, vp, i32, i64, vp]),
+    "ssl4gie_map_layernorm_workspace_bytes": (sz, [i32]),
+    "ssl4gie_map_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i64, vp]),
+    "ssl4gie_map_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i64, vp]),
     "ssl4gie_set_wgrad_stream": (i32, [i32]),
     "ssl4gie_prof_begin": (i32, [i32]),
     "ssl4gie_prof_collect": (i32, [vp, vp, vp]),

@@ -394,20 +394,61 @@ class PatchEmbedFn(torch.autograd.Function):
         x = ops.tokens_assemble(y, cls.detach().contiguous().view(-1),
                                 pos.detach().contiguous().view(-1, pos.shape[-1]), B, nsel_eff,
                                 ids=ids)
-        ctx.save_for_backward(cols, weight, bias, cls)
+        ctx.save_for_backward(cols, weight, bias, cls, pos)
         ctx.sink, ctx.dtype = sink, dtype
+        # a trainable position table (timm's default; the MAE / MoCo tables are fixed) gets its
+        # gradient only on the unmasked path, where row j of every image meets pos[j]
+        ctx.pos_grad = pos.requires_grad and ids is None
+        if pos.requires_grad and ids is not None:
+            raise NotImplementedError("masked patch embedding with a trainable pos_embed")
         return x
 
     @staticmethod
     def backward(ctx, dx):
-        cols, weight, bias, cls = ctx.saved_tensors
-        (tw, tb, tc), acc, rets = ctx.sink.plan([weight, bias, cls])
-        dy = ops.tokens_assemble_bwd(dx.contiguous(), ctx.dtype, dcls_out=tc, accumulate=acc)
+        cols, weight, bias, cls, pos = ctx.saved_tensors
+        plist = [weight, bias, cls] + ([pos] if ctx.pos_grad else [])
+        tgs, acc, rets = ctx.sink.plan(plist)
+        tw, tb, tc = tgs[:3]
+        dx = dx.contiguous()
+        if ctx.pos_grad and tgs[3] is not None:
+            dpos = dx.sum(0, keepdim=True)  # [1, 1 + L, D]
+            if acc:
+                tgs[3].add_(dpos)
+            else:
+                tgs[3].copy_(dpos)
+        dy = ops.tokens_assemble_bwd(dx, ctx.dtype, dcls_out=tc, accumulate=acc)
         if tw is not None:
             ops.linear_bwd_weight(dy, cols, out=tw, accumulate=acc, bias_out=tb)
         elif tb is not None:
             ops.colsum(dy, out=tb, accumulate=acc)
-        return (None, rets[0], rets[1], rets[2]) + (None,) * 7
+        return (None, rets[0], rets[1], rets[2], rets[3] if ctx.pos_grad else None) + (None,) * 6
+
+
+class PatchEmbedDetFn(torch.autograd.Function):
+    """PatchEmbed conv (k=s=p) of the detection trunk: gather the patches in the order `ids` asks
+    for (window-major) + GEMM with bias -> fp32 [B*N, D]; no cls token, the position table is added
+    by the caller (reference models.py:326-328 with det=True)."""
+
+    @staticmethod
+    def forward(ctx, imgs, weight, bias, ids, p, dtype, sink, lp):
+        cols = ops.patch_gather(imgs.contiguous(), p, ids=ids.contiguous(), out_dtype=dtype)
+        w, _ = lp.get(weight, dtype)
+        y = ops.linear_fwd(cols, w, bias.detach(), out_dtype=torch.float32)
+        ctx.save_for_backward(cols, weight, bias)
+        ctx.sink, ctx.dtype = sink, dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, weight, bias = ctx.saved_tensors
+        (tw, tb), acc, rets = ctx.sink.plan([weight, bias])
+        dy = dy.contiguous()
+        dyl = dy if ctx.dtype == torch.float32 else ops.cast(dy, ctx.dtype)
+        if tw is not None:
+            ops.linear_bwd_weight(dyl, cols, out=tw, accumulate=acc, bias_out=tb)
+        elif tb is not None:
+            ops.colsum(dyl, out=tb, accumulate=acc)
+        return (None, rets[0], rets[1]) + (None,) * 5
 
 
 class DecoderAssembleFn(torch.autograd.Function):

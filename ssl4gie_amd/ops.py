@@ -736,3 +736,61 @@ def ema_update(dst, src, m):
     assert dst.numel() == src.numel()
     _lib.check(_lib.load().ssl4gie_ema_update(ptr(dst), ptr(src), float(m), dst.numel(), stream()),
                "ema_update")
+
+
+# ------------------------------------------------------------------ detection pyramid glue (channels-last)
+def maxpool2x2_fwd(x):
+    B, H, W, C_ = _nhwc(x)
+    y = torch.empty(B, H // 2, W // 2, C_, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().ssl4gie_maxpool2x2_fwd(ptr(x), ptr(y), code(x.dtype), B, H, W, C_, stream()),
+               "maxpool2x2_fwd")
+    return y
+
+
+def maxpool2x2_bwd(x, dy):
+    B, H, W, C_ = _nhwc(x)
+    _dev(dy)
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().ssl4gie_maxpool2x2_bwd(ptr(x), ptr(dy), ptr(dx), code(x.dtype), B, H, W, C_,
+                                                  stream()), "maxpool2x2_bwd")
+    return dx
+
+
+def gelu_map(x, dy=None):
+    """gelu(x) (exact erf form), or dy * gelu'(x) when dy is given"""
+    _dev(x, dy)
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().ssl4gie_gelu_map(ptr(x), ptr(dy), ptr(out), code(x.dtype), x.numel(), stream()),
+               "gelu_map")
+    return out
+
+
+def map_layernorm_fwd(x, w, bias, eps=1e-5):
+    """nn.LayerNorm over everything but the batch axis; w / bias fp32 in x's element order"""
+    _dev(x, w, bias)
+    _f32(w)
+    _f32(bias)
+    B = x.shape[0]
+    M = x.numel() // B
+    assert w.numel() == M and bias.numel() == M and x.is_contiguous()
+    L = _lib.load()
+    y = torch.empty_like(x)
+    mean = torch.empty(B, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.ssl4gie_map_layernorm_workspace_bytes(B), dtype=torch.uint8, device=x.device)
+    _lib.check(L.ssl4gie_map_layernorm_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), ptr(mean), ptr(rstd), eps,
+                                           ptr(ws), code(x.dtype), B, M, stream()), "map_layernorm_fwd")
+    return y, mean, rstd
+
+
+def map_layernorm_bwd(x, dy, w, mean, rstd, dw=None, db=None, accumulate=False):
+    _dev(x, dy, w, mean, rstd, dw, db)
+    B = x.shape[0]
+    M = x.numel() // B
+    L = _lib.load()
+    dx = torch.empty_like(x)
+    ws = torch.empty(L.ssl4gie_map_layernorm_workspace_bytes(B), dtype=torch.uint8, device=x.device)
+    _lib.check(L.ssl4gie_map_layernorm_bwd(ptr(x), ptr(dy), ptr(w), ptr(mean), ptr(rstd), ptr(dx), ptr(dw),
+                                           ptr(db), int(accumulate), ptr(ws), code(x.dtype), B, M,
+                                           stream()), "map_layernorm_bwd")
+    return dx
