@@ -217,6 +217,77 @@ def bench_moco(a):
         dist.destroy_process_group()
 
 
+def bench_det(a):
+    """detection ViT-B backbone (windowed + global attention, N = 4096) + ViTDet
+    FPN at 1024 x 1024, fwd + bwd + AdamW with a synthetic quadratic loss on the five pyramid maps
+    (RPN / RoI heads are torchvision Python in the reference and out of scope)."""
+    import torch.distributed as dist
+    from ssl4gie_amd import _lib, parallel
+    from ssl4gie_amd.Models import models
+    _lib.load()
+    rank, local, world = parallel.init_from_env()
+    assert world == a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = a.batch if a.batch != 256 else 4
+    torch.manual_seed(0)
+    model = models.VisionTransformer_from_Any(False, 0, False, None, True, 1024, 768, 12, 12, "cls")
+    model.to(dev).set_precision(a.precision)
+    ddp = parallel.DataParallel(model) if world > 1 else None
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
+    g = torch.Generator("cpu").manual_seed(rank)
+    imgs = torch.randn(B, 3, 1024, 1024, generator=g).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = (ddp or model)(imgs)
+        loss = sum((v * v).mean() for v in out.values())
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        ips = B * world * a.steps / dt
+        # GEMM-shaped MACs per image: 12 blocks x 4096 tokens x 12 D^2, windowed attention
+        # 8 x 2 N 256 D, global attention 4 x 2 N^2 D, patch embed, pyramid convolutions
+        D, N = 768, 4096
+        gmac = (12 * N * 12 * D * D + 8 * 2 * N * 256 * D + 4 * 2 * N * N * D + N * D * D
+                + 2 * (N * D * 4 * D) + 2 * (4 * N * D * 4 * D) + (N // 4 + N + 4 * N + 16 * N) * D * 256
+                + (N // 4 + N + 4 * N + 16 * N) * 9 * 256 * 256) / 1e9
+        print(json.dumps({
+            "metric": "images/sec (fwd+bwd+AdamW) detection ViT-B backbone + ViTDet FPN 1024x1024 (SURVEY 8f-1)",
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "VisionTransformer_from_Any(det=True, fixed_size=1024) + ViTDet_FPN, "
+                                   "synthetic images resident in HBM, quadratic loss on the pyramid maps",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "gflop_per_image_fwd_bwd": round(6 * gmac, 1),
+            "model_mfma_frac": round(ips / world * 6 * gmac / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(float(loss.detach()), 5)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_bt(a):
     """configs[4]: Barlow Twins on a ViT-B trunk, two views of 512 images per GPU, projector
     8192-8192-8192, lambda 0.0051, LARS (the build's own specification of the published method —
@@ -302,7 +373,7 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco", "bt"],
+    ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco", "bt", "det"],
                     help="mae = BASELINE.json configs[1] (the headline metric); depth = configs[3] "
                          "(ViT-B + DPT depth finetune step, bs 128/GPU) as an extra measurement")
     a = ap.parse_args()
@@ -310,6 +381,8 @@ def main():
         return bench_depth(a)
     if a.workload == "bt":
         return bench_bt(a)
+    if a.workload == "det":
+        return bench_det(a)
     if a.workload == "moco":
         return bench_moco(a)
 
