@@ -330,6 +330,13 @@ int ssl4gie_maxpool3x3s2_bwd(const void* dy, const unsigned char* arg, void* dx,
 int ssl4gie_avgpool_fwd(const void* x, float* y, int dtype, int B, int HW, int C, void* stream);
 int ssl4gie_avgpool_bwd(const float* dy, void* dx, int dtype, int B, int HW, int C, void* stream);
 
+/* ---------------------------------------------------------------- input pipeline
+ * transforms.ToTensor() + transforms.Normalize(mean, std) (Depth_estimation/Data/dataloaders.py:
+ * 55-63) on the device: uint8 HWC [B, H, W, 3] -> fp32 NCHW [B, 3, H, W] = (x / 255 - mean) / std.
+ * mean / std are HOST arrays of 3 floats; H*W % 4 == 0. */
+int ssl4gie_normalize_u8(const unsigned char* img, float* out, const float* mean, const float* std,
+                         int B, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- detection pyramid glue (channels-last)
  * ViTDet_FPN (Models/models.py:213-259) around its GEMM-shaped convolutions:
  * maxpool2x2: nn.MaxPool2d(2) (:218); backward recomputes the window's first maximum from x.

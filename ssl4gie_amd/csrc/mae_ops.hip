@@ -437,3 +437,41 @@ extern "C" int ssl4gie_mae_loss(const float* pred, const float* img, const float
     LAUNCH_CHECK();
     return 0;
 }
+
+
+// ------------------------------------------------------------------ input pipeline
+// transforms.ToTensor() + transforms.Normalize(mean, std) (Depth_estimation/Data/dataloaders.py:
+// 55-63) on the device: uint8 HWC images [B, H, W, 3] -> fp32 NCHW [B, 3, H, W],
+// out = (x / 255 - mean[c]) / std[c].  One thread per 4 pixels of a row (12 bytes in, 3 x 16 B out).
+__global__ void normalize_u8_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
+                                    f32x4 scale, f32x4 shift, int HW, long long total4) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const long long b = idx / (HW / 4);
+    const int p = (int)(idx % (HW / 4)) * 4;
+    const unsigned* src = (const unsigned*)(img + ((size_t)b * HW + p) * 3);  // 12 bytes, 4-B aligned
+    const unsigned w0 = src[0], w1 = src[1], w2 = src[2];
+    unsigned char px[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { px[j] = (w0 >> (8 * j)) & 0xff; px[4 + j] = (w1 >> (8 * j)) & 0xff; px[8 + j] = (w2 >> (8 * j)) & 0xff; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)px[3 * j + c] * scale[c] + shift[c];
+        st4(out + ((size_t)b * 3 + c) * HW + p, v);
+    }
+}
+extern "C" int ssl4gie_normalize_u8(const unsigned char* img, float* out, const float* mean,
+                                    const float* std, int B, int H, int W, void* stream) {
+    REQUIRE(img && out && mean && std && B > 0 && H > 0 && W > 0 && ((long long)H * W) % 4 == 0);
+    for (int c = 0; c < 3; ++c) REQUIRE(std[c] > 0.f);
+    const int HW = H * W;
+    const long long total4 = (long long)B * (HW / 4);
+    f32x4 scale = {1.f / (255.f * std[0]), 1.f / (255.f * std[1]), 1.f / (255.f * std[2]), 0.f};
+    f32x4 shift = {-mean[0] / std[0], -mean[1] / std[1], -mean[2] / std[2], 0.f};
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, img, out, scale, shift, HW, total4);
+    LAUNCH_CHECK();
+    return 0;
+}

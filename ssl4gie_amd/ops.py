@@ -794,3 +794,19 @@ def map_layernorm_bwd(x, dy, w, mean, rstd, dw=None, db=None, accumulate=False):
                                            ptr(db), int(accumulate), ptr(ws), code(x.dtype), B, M,
                                            stream()), "map_layernorm_bwd")
     return dx
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def normalize_u8(img_u8, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """uint8 HWC batch [B, H, W, 3] on the device -> fp32 NCHW, (x / 255 - mean) / std
+    (ToTensor + Normalize of the reference's dataloaders, without the PIL / CPU round trip)"""
+    _dev(img_u8)
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[3] == 3 and img_u8.is_contiguous()
+    B, H, W, _ = img_u8.shape
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=img_u8.device)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    _lib.check(_lib.load().ssl4gie_normalize_u8(ptr(img_u8), ptr(out), m, s, B, H, W, stream()), "normalize_u8")
+    return out

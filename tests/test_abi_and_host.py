@@ -132,3 +132,35 @@ def test_lds_swizzles_are_conflict_free():
                    for c0 in range(0, nch, 4) for r0 in (0, 16, 208))
         assert all(sim.tr_b16_cycles(sim.attn_tr_read_addrs(rb, swz, k0, d0, s)) == 2
                    for k0 in (0, 32, 192) for d0 in range(0, nch * 8, 16) for s in (False, True))
+
+
+def test_checkpoint_wrappers_round_trip():
+    """MoCo / Barlow Twins / DDP wrappers -> backbone state_dicts (host logic only)"""
+    from functools import partial
+    import torch
+    from ssl4gie_amd import checkpoints as ck
+    from ssl4gie_amd.Models import models
+    from ssl4gie_amd.Models.barlow_twins import BarlowTwins
+    from ssl4gie_amd.Models.moco_v3 import vits
+    from ssl4gie_amd.Models.moco_v3.moco import builder
+    from ssl4gie_amd.Models.resnet import resnet50
+    torch.manual_seed(0)
+    moco = builder.MoCo_ResNet(partial(resnet50, zero_init_residual=True), 256, 4096, 1.0)
+    saved = {"epoch": 3, "state_dict": {"module." + k: v for k, v in moco.state_dict().items()}}
+    bb = ck.moco_to_backbone(saved)
+    assert not any(k.startswith(("fc.", "head.")) for k in bb) and "conv1.weight" in bb
+    target = models.ResNet_from_Any(None, False, 0, False, None)
+    assert set(bb) == set(target.state_dict())            # strict-loadable, as the reference expects
+    target.load_state_dict(bb, strict=True)
+    assert torch.equal(target.layer3[2].conv2.weight, moco.base_encoder.layer3[2].conv2.weight)
+
+    vit = vits.VisionTransformerMoCo(embed_dim=192, depth=2, num_heads=3, num_classes=8)
+    del vit.head
+    bt = BarlowTwins(vit, 192, "64-64-64")
+    bsd = ck.barlow_twins_to_backbone({"model": {"module." + k: v for k, v in bt.state_dict().items()}})
+    assert set(bsd) == set(vit.state_dict())
+
+    ddp = {"model_state_dict": {"module." + k: v for k, v in target.state_dict().items()}}
+    assert set(ck.ddp_unwrap(ddp)) == set(target.state_dict())
+    loaded, missing, unexpected = ck.load_matching(target, {**bb, "extra.weight": torch.zeros(1)})
+    assert len(loaded) == len(bb) and missing == [] and unexpected == ["extra.weight"]

@@ -452,3 +452,13 @@ def test_block_stack_fwd_bwd(dt, N, D, H):
     for name, p in blocks.named_parameters():
         assert p.grad is not None, name
         assert rel_err(p.grad, sdo[name].grad) < tol_g, name
+
+
+def test_normalize_u8_matches_totensor_normalize():
+    from ssl4gie_amd import ops
+    img = torch.randint(0, 256, (3, 30, 28, 3), generator=G(11), dtype=torch.uint8)
+    out = ops.normalize_u8(img.to(DEV)).cpu()
+    mean = torch.tensor(ops.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(ops.IMAGENET_STD).view(1, 3, 1, 1)
+    ref = (img.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+    assert out.shape == ref.shape and rel_err(out, ref) < 1e-6
