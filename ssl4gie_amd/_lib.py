@@ -116,6 +116,7 @@ PROTOTYPES = {
     "ssl4gie_map_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i64, vp]),
     "ssl4gie_map_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i64, vp]),
     "ssl4gie_set_wgrad_stream": (i32, [i32]),
+    "ssl4gie_set_compute_cus": (i32, [i32]),
     "ssl4gie_prof_begin": (i32, [i32]),
     "ssl4gie_prof_collect": (i32, [vp, vp, vp]),
     "ssl4gie_prof_end": (i32, []),

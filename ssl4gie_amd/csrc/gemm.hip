@@ -743,6 +743,22 @@ static int tn_splits(const ssl4gie_gemm_desc* d) {
     return s;
 }
 
+// ---- CUs available to the GEMM grids
+static int g_compute_cus = -1;  // -1: SSL4GIE_COMPUTE_CUS or 256
+int ssl4gie_internal_compute_cus() {
+    if (g_compute_cus < 0) {
+        const char* e = getenv("SSL4GIE_COMPUTE_CUS");
+        const int v = e ? atoi(e) : 256;
+        g_compute_cus = v < 8 ? 8 : (v > 256 ? 256 : v);
+    }
+    return g_compute_cus;
+}
+extern "C" int ssl4gie_set_compute_cus(int n) {
+    REQUIRE(n >= 8 && n <= 256);
+    g_compute_cus = n;
+    return 0;
+}
+
 // ---- implicit 3x3 patch-matrix operand (ssl4gie_gemm_desc::conv)
 bool ssl4gie_internal_conv_geom_ok(const ssl4gie_conv3x3_geom* g) {
     if (!g || g->B < 1 || g->H < 1 || g->W < 1 || g->C < 8 || g->C % 8 != 0) return false;
@@ -836,7 +852,8 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
         REQUIRE(!d->conv);  // the gathered operand only exists in the 256x256 kernels
         const int tm = (d->M + BT_M - 1) / BT_M, tn = (d->N + BT_N - 1) / BT_N;
         const int ntiles = tm * tn;
-        dim3 grid(ntiles < NT_MAX_WGS ? ntiles : NT_MAX_WGS), block(256);
+        const int max_wgs = 2 * ssl4gie_internal_compute_cus();  // 2 workgroups per CU
+        dim3 grid(ntiles < max_wgs ? ntiles : max_wgs), block(256);
         ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
 #define NT_LAUNCH(TC_, MODE_)                                                                  \
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<TC_, MODE_>), grid, block, BT_LDS_BYTES, st,       \

@@ -35,6 +35,11 @@ static inline long long conv_rows(const ssl4gie_conv3x3_geom* g) {
 bool ssl4gie_internal_conv_geom_ok(const ssl4gie_conv3x3_geom* g);
 int ssl4gie_internal_conv_k(const ssl4gie_conv3x3_geom* g, ConvK* k);  // fills k (zero page incl.)
 
+// CUs the persistent / one-workgroup-per-CU GEMM grids are sized for (ssl4gie_set_compute_cus):
+// 256 on a GPU of its own; data-parallel runs leave a few CUs to the RCCL kernels, which cannot
+// share a CU with a workgroup that holds all 160 KiB of LDS.
+int ssl4gie_internal_compute_cus();
+
 // 256x256x64 ping-pong NT kernel (gemm_nt256.hip): C[M,N] = A[M,K] B[N,K]^T with the fused
 // epilogues.  `nt256_ok` says whether the descriptor (already known to satisfy the NT fast-path
 // layout rules) is worth / able to run on it; `nt256_launch` enqueues it.

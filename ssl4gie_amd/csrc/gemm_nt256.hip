@@ -421,7 +421,8 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
 int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + P_BN - 1) / P_BN;
     const int ntiles = tm * tn;
-    dim3 grid(ntiles < 256 ? ntiles : 256), block(512);
+    const int cus = ssl4gie_internal_compute_cus();
+    dim3 grid(ntiles < cus ? ntiles : cus), block(512);
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate};
     static int skip_epi = -1;  // SSL4GIE_NT256_NOEPI=1: ablation (K-loop only; outputs are garbage)
     if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] == '1') ? 1 : 0; }

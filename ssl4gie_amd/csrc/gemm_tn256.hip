@@ -311,7 +311,7 @@ bool ssl4gie_internal_tn256_ok(const ssl4gie_gemm_desc* d) {
 int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d) {
     const int tiles = ((d->M + P_BM - 1) / P_BM) * ((d->N + P_BN - 1) / P_BN);
     const int nkt = d->K / P_BK;
-    int s = (256 + tiles / 2) / tiles;  // one workgroup per CU
+    int s = (ssl4gie_internal_compute_cus() + tiles / 2) / tiles;  // one workgroup per CU
     if (s > nkt / 8) s = nkt / 8;       // at least 8 K-tiles per split
     if (s < 1) s = 1;
     if (s > 64) s = 64;

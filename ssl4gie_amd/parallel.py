@@ -49,6 +49,14 @@ class DataParallel:
         self._hi = self._arena.grad.numel()  # everything in [self._hi, numel) already reduced
         self._avg_op = self._pick_avg_op()
         self.n_collectives = 0
+        if self._is_cuda and self.world > 1:
+            # the 256x256 GEMM workgroups own a CU's whole LDS, so RCCL's kernels need CUs of their
+            # own while a bucket is in flight: size the persistent GEMM grids for 256 - R CUs
+            # (init_from_env caps RCCL at R channels).  SSL4GIE_COMM_CUS=0 disables the reservation.
+            from . import _lib
+            r = comm_cus()
+            if r > 0:
+                _lib.check(_lib.load().ssl4gie_set_compute_cus(256 - r), "set_compute_cus")
         if broadcast_parameters and self.world > 1:
             dist.broadcast(self._arena.data, src=0, group=process_group)
         model._grad_hook = self._on_module_grads if overlap else None
@@ -124,6 +132,12 @@ class DataParallel:
         return t / self.world
 
 
+def comm_cus() -> int:
+    """CUs left to the communication kernels in data-parallel runs (SSL4GIE_COMM_CUS, default 16)"""
+    import os
+    return max(0, min(128, int(os.environ.get("SSL4GIE_COMM_CUS", "16"))))
+
+
 def init_from_env(backend: Optional[str] = None):
     """Initialise torch.distributed from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world)."""
@@ -140,6 +154,8 @@ def init_from_env(backend: Optional[str] = None):
                 ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
+            if comm_cus() > 0:  # one RCCL channel = one workgroup = one CU (see DataParallel)
+                os.environ.setdefault("NCCL_MAX_NCHANNELS", str(comm_cus()))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
