@@ -217,6 +217,70 @@ def bench_moco(a):
         dist.destroy_process_group()
 
 
+def bench_vit(a):
+    """Plain ViT-B fwd + bwd + AdamW at bs 256 (linear-classifier finetune of a MAE trunk,
+    `get_MAE_backbone(None, True, 6, False, None, False)`; train_classification.py): the un-masked
+    N = 197 trunk that the north_star's "ViT-B fwd+bwd at bs=256/GPU" target is phrased on."""
+    import torch.distributed as dist
+    from ssl4gie_amd import _lib, parallel
+    from ssl4gie_amd.Models import models
+    _lib.load()
+    rank, local, world = parallel.init_from_env()
+    assert world == a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = a.batch
+    torch.manual_seed(0)
+    model = models.ViT_from_MAE(None, True, 6, False, None, False, None, 768, 12, 12, "cls")
+    model.to(dev).set_precision(a.precision)
+    ddp = parallel.DataParallel(model) if world > 1 else None
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
+    g = torch.Generator("cpu").manual_seed(rank)
+    imgs = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    labels = torch.randint(0, 6, (B,), generator=g).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy((ddp or model)(imgs), labels)
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        ips = B * world * a.steps / dt
+        print(json.dumps({
+            "metric": "images/sec (fwd+bwd+AdamW) ViT-B 224x224 linear-head finetune, un-masked trunk",
+            "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "ViT_from_MAE(head=True, num_classes=6) + cross entropy + AdamW(1e-4), "
+                                   "synthetic images resident in HBM",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "model_mfma_frac": round(ips / world * 105.38 / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(float(loss.detach()), 5)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_det(a):
     """detection ViT-B backbone (windowed + global attention, N = 4096) + ViTDet
     FPN at 1024 x 1024, fwd + bwd + AdamW with a synthetic quadratic loss on the five pyramid maps
@@ -373,7 +437,7 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco", "bt", "det"],
+    ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco", "bt", "det", "vit"],
                     help="mae = BASELINE.json configs[1] (the headline metric); depth = configs[3] "
                          "(ViT-B + DPT depth finetune step, bs 128/GPU) as an extra measurement")
     a = ap.parse_args()
@@ -383,6 +447,8 @@ def main():
         return bench_bt(a)
     if a.workload == "det":
         return bench_det(a)
+    if a.workload == "vit":
+        return bench_vit(a)
     if a.workload == "moco":
         return bench_moco(a)
 

@@ -82,12 +82,43 @@ DEVI float group_sum(float v) {
 }
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// three [n, HD] slices (Q, K, V of one head: same row stride, bases D apart) staged in one go: all
+// global loads of a thread are issued before the first LDS write, so the prologue costs one HBM
+// round trip instead of one per 16-byte chunk (the per-image loop above waits for each load before
+// it stores)
+template <int HD, int NPAD, int NTH>
+DEVI void stage_qkv(char* img0, char* img1, char* img2, const bf16_t* src0, const bf16_t* src1,
+                    const bf16_t* src2, long long rs, int n, int tid) {
+    constexpr int CPR = HD / 8, TOTAL = NPAD * CPR, IT = (TOTAL + NTH - 1) / NTH;
+    u32x4 v[3][IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTH, row = idx / CPR, c = idx % CPR;
+        const bool ok = idx < TOTAL && row < n;
+        const size_t off = (size_t)row * rs + c * 8;
+        v[0][i] = ok ? *(const u32x4*)(src0 + off) : u32x4{0, 0, 0, 0};
+        v[1][i] = ok ? *(const u32x4*)(src1 + off) : u32x4{0, 0, 0, 0};
+        v[2][i] = ok ? *(const u32x4*)(src2 + off) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTH, row = idx / CPR, c = idx % CPR;
+        if (idx < TOTAL) {
+            *(u32x4*)(img0 + img_off<HD>(row, c)) = v[0][i];
+            *(u32x4*)(img1 + img_off<HD>(row, c)) = v[1][i];
+            *(u32x4*)(img2 + img_off<HD>(row, c)) = v[2][i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ forward
-template <int HD, int NKT>
-__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv,
-                                                            bf16_t* __restrict__ out,
-                                                            float* __restrict__ lse, int N, int H,
-                                                            float scale) {
+// WAVES: 4, or 8 when the three operand images leave room for only one workgroup per CU (hd 64,
+// N > 128: 86 KiB) — 8 waves share that one set of images, i.e. 2 waves per SIMD instead of 1, so
+// one wave's LDS reads and softmax VALU work overlap the other's MFMAs.
+template <int HD, int NKT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 14 ? 3 : 2))) void attn_fwd_bf16_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H,
+    float scale) {
     constexpr int NPAD = NKT * 16, RB = HD * 2, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kimg = smem;
@@ -101,13 +132,12 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn_fwd_bf16_kernel(
     const int D = H * HD;
     const long long rs = 3LL * D;
     const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
-    stage_rows<HD>(Kimg, qb + D, rs, N, NPAD, tid);
-    stage_rows<HD>(Vimg, qb + 2 * D, rs, N, NPAD, tid);
-    stage_rows<HD>(Qimg, qb, rs, N, NPAD, tid);  // every operand is LDS-fed: no global-load latency
+    // every operand is LDS-fed: no global-load latency
+    stage_qkv<HD, NPAD, 64 * WAVES>(Kimg, Vimg, Qimg, qb + D, qb + 2 * D, qb, rs, N, tid);
     __syncthreads();                              // inside the per-tile dependency chains
     const float c = scale * 1.44269504088896340736f;
     const int nqt = (N + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += WAVES) {
         const int q = qt * 16 + (lane & 15);
         bf16x8 qf[KS];
 #pragma unroll
@@ -198,26 +228,33 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
 
     constexpr int NTH = 64 * ATTN_BWD_WAVES;
     // ---------------- prologue: stage K, V, Q, dO; delta and lse rows
-    stage_rows<HD>(Kimg, qb + D, rs, N, NPAD, tid, NTH);
-    stage_rows<HD>(Vimg, qb + 2 * D, rs, N, NPAD, tid, NTH);
-    stage_rows<HD>(Qimg, qb, rs, N, NPAD, tid, NTH);
-    for (int idx = tid; idx < NPAD * CPR; idx += NTH) {  // wave-uniform trip count (NPAD*CPR % 64 == 0)
-        const int row = idx / CPR, ch = idx % CPR;
-        u32x4 v = {0, 0, 0, 0};
-        float dot = 0.f;
-        if (row < N) {
-            v = *(const u32x4*)(dob + (size_t)row * D + ch * 8);
-            const u32x4 o = *(const u32x4*)(ob + (size_t)row * D + ch * 8);
+    stage_qkv<HD, NPAD, NTH>(Kimg, Vimg, Qimg, qb + D, qb + 2 * D, qb, rs, N, tid);
+    {  // dO image + delta rows; loads first, then arithmetic and LDS writes (one HBM round trip)
+        constexpr int TOTAL = NPAD * CPR, IT = (TOTAL + NTH - 1) / NTH;  // TOTAL % 64 == 0: wave-uniform guards
+        u32x4 vv[IT], oo[IT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dot += __uint_as_float(v[j] << 16) * __uint_as_float(o[j] << 16);
-                dot += __uint_as_float(v[j] & 0xffff0000u) * __uint_as_float(o[j] & 0xffff0000u);
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
+            const bool ok = idx < TOTAL && row < N;
+            vv[i] = ok ? *(const u32x4*)(dob + (size_t)row * D + ch * 8) : u32x4{0, 0, 0, 0};
+            oo[i] = ok ? *(const u32x4*)(ob + (size_t)row * D + ch * 8) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
+            if (idx < TOTAL) {
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dot += __uint_as_float(vv[i][j] << 16) * __uint_as_float(oo[i][j] << 16);
+                    dot += __uint_as_float(vv[i][j] & 0xffff0000u) * __uint_as_float(oo[i][j] & 0xffff0000u);
+                }
+                *(u32x4*)(Oimg + img_off<HD>(row, ch)) = vv[i];
+#pragma unroll
+                for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);  // the row's CPR lanes
+                if (ch == 0) del_s[row] = dot;
             }
         }
-        *(u32x4*)(Oimg + img_off<HD>(row, ch)) = v;
-#pragma unroll
-        for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);  // the row's CPR lanes
-        if (ch == 0) del_s[row] = dot;
     }
     for (int i = tid; i < NPAD; i += NTH) lse_s[i] = i < N ? lrow[i] * LOG2E : 0.f;
     __syncthreads();
@@ -707,11 +744,12 @@ template <int HD, int NKT>
 static int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale,
                       hipStream_t st) {
     const size_t lds = (size_t)3 * NKT * 16 * HD * 2;
-    auto k = attn_fwd_bf16_kernel<HD, NKT>;
+    constexpr int WAVES = (3 * NKT * 16 * HD * 2 > 80 * 1024) ? 8 : 4;
+    auto k = attn_fwd_bf16_kernel<HD, NKT, WAVES>;
     if (lds > 65536)
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * HD, st);
-    hipLaunchKernelGGL(k, dim3(B * H), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse,
+    hipLaunchKernelGGL(k, dim3(B * H), dim3(64 * WAVES), lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse,
                        N, H, scale);
     LAUNCH_CHECK();
     return 0;

@@ -6,7 +6,8 @@ import torch
 from ssl4gie_amd import ops
 
 torch.manual_seed(0)
-CASES = [("mae.enc", 256, 50, 12, 64), ("mae.dec", 256, 197, 16, 32), ("vitb.full", 128, 197, 12, 64)]
+CASES = [("mae.enc", 256, 50, 12, 64), ("mae.dec", 256, 197, 16, 32), ("vitb.full", 256, 197, 12, 64),
+         ("det.window", 64, 256, 12, 64), ("det.global", 4, 4096, 12, 64)]
 
 
 def timeit(fn, iters=20):
