@@ -24,6 +24,7 @@
 #include "prof.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 // ------------------------------------------------------------------ LDS image helpers
@@ -371,69 +372,84 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
 }
 
 
-// ------------------------------------------------------------------ long sequences (N % 128 == 0)
-// Streaming ("flash") variants for hd = 64 and sequences that do not fit LDS (the detection
-// backbone's global-attention blocks at 1024^2: N = 4096, reference models.py:281-285,310-336).
-// A workgroup of 8 waves owns 128 queries (forward, dQ) or 128 keys (dK/dV) — their MFMA
-// fragments stay in registers — and streams the other side through LDS in blocks of 128 rows:
-// two images (K,V resp. Q,dO) x two buffers = 64 KiB, next block prefetched into registers while
-// the current one is consumed, one __syncthreads per block.  Forward keeps the running row
-// maximum / sum per query lane (online softmax, exp2 domain) and rescales the O^T accumulators;
-// backward recomputes P from the saved log-sum-exp, with delta_q = sum_d dO O from a small
-// pre-pass kernel.  No N x N tensor reaches HBM, no atomics, fixed summation order.
+// ------------------------------------------------------------------ streaming kernels (N > 128)
+// Streaming ("flash") variants for sequences that do not fit the whole-head kernels above (N > 256):
+// the detection backbone's global blocks (N = 4096; reference models.py:281-285,310-336) and other
+// fixed_size grids.  A workgroup of 8 waves owns 128 queries
+// (forward, dQ) or 128 keys (dK/dV) — their MFMA fragments stay in registers — and streams the
+// other side through LDS in blocks of 128 rows: two images (K,V resp. Q,dO) x two buffers, the next
+// block prefetched into registers while the current one is consumed, one __syncthreads per block.
+// With 32 KiB (hd 32) / 64 KiB (hd 64) of LDS two or more workgroups share a CU, so one
+// workgroup's prologue (an HBM round trip) hides behind another's MFMAs.  Forward keeps the
+// running row maximum / sum per query lane (online softmax, exp2 domain) and rescales the O^T
+// accumulators; backward recomputes P from the saved log-sum-exp, with delta_q = sum_d dO O from a
+// small pre-pass kernel.  MASK: N is not a multiple of 128 (rows past N are staged as zeros, padded
+// keys get probability 0, padded queries are never stored).  No N x N tensor reaches HBM, no
+// atomics, fixed summation order.
 #define LONG_WAVES 8
 #define LONG_BLK 128
-struct LongRegs {
-    u32x4 a[2], b[2];
+template <int HD> struct LongRegs {
+    static constexpr int NL = HD / 32;  // 16-byte chunks per thread and image
+    u32x4 a[NL], b[NL];
 };
-// rows row0 .. row0+127 of two [*, 64] bf16 operands (row strides rsa / rsb elements)
-DEVI void long_load(LongRegs& r, const bf16_t* A, long long rsa, const bf16_t* Bp, long long rsb,
-                    int row0, int tid) {
+// rows row0 .. row0+127 of two [*, HD] bf16 operands (row strides rsa / rsb elements)
+template <int HD, bool MASK>
+DEVI void long_load(LongRegs<HD>& r, const bf16_t* A, long long rsa, const bf16_t* Bp, long long rsb,
+                    int row0, int N, int tid) {
+    constexpr int CPR = HD / 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * 64 * LONG_WAVES, row = idx >> 3, c = idx & 7;
-        r.a[i] = *(const u32x4*)(A + (size_t)(row0 + row) * rsa + c * 8);
-        r.b[i] = *(const u32x4*)(Bp + (size_t)(row0 + row) * rsb + c * 8);
+    for (int i = 0; i < LongRegs<HD>::NL; ++i) {
+        const int idx = tid + i * 64 * LONG_WAVES, row = row0 + idx / CPR, c = idx % CPR;
+        if (!MASK || row < N) {
+            r.a[i] = *(const u32x4*)(A + (size_t)row * rsa + c * 8);
+            r.b[i] = *(const u32x4*)(Bp + (size_t)row * rsb + c * 8);
+        } else {
+            r.a[i] = u32x4{0, 0, 0, 0};
+            r.b[i] = u32x4{0, 0, 0, 0};
+        }
     }
 }
-DEVI void long_store(const LongRegs& r, char* imgA, char* imgB, int tid) {
+template <int HD>
+DEVI void long_store(const LongRegs<HD>& r, char* imgA, char* imgB, int tid) {
+    constexpr int CPR = HD / 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * 64 * LONG_WAVES, row = idx >> 3, c = idx & 7;
-        *(u32x4*)(imgA + img_off<64>(row, c)) = r.a[i];
-        *(u32x4*)(imgB + img_off<64>(row, c)) = r.b[i];
+    for (int i = 0; i < LongRegs<HD>::NL; ++i) {
+        const int idx = tid + i * 64 * LONG_WAVES, row = idx / CPR, c = idx % CPR;
+        *(u32x4*)(imgA + img_off<HD>(row, c)) = r.a[i];
+        *(u32x4*)(imgB + img_off<HD>(row, c)) = r.b[i];
     }
 }
 
+template <int HD, bool MASK>
 __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_fwd_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H,
     float scale) {
-    constexpr int HD = 64, KS = 2, DT = 4, NKT = LONG_BLK / 16, IMG = LONG_BLK * HD * 2;
+    constexpr int KS = HD / 32, DT = HD / 16, NKT = LONG_BLK / 16, IMG = LONG_BLK * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int b = blockIdx.y / H, h = blockIdx.y % H;
     const int D = H * HD;
     const long long rs = 3LL * D;
     const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
-    const int q0 = blockIdx.x * LONG_BLK + wave * 16;
-    const int q = q0 + (lane & 15);
+    const int q = blockIdx.x * LONG_BLK + wave * 16 + (lane & 15);
+    const int qc = (MASK && q >= N) ? N - 1 : q;  // padded query lanes compute on a valid row, never store
     bf16x8 qf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(qb, rs, q, ks, lane);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(qb, rs, qc, ks, lane);
     const float c = scale * 1.44269504088896340736f;
     float m = -INFINITY, lsum = 0.f;
     f32x4 o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0, 0, 0, 0};
-    const int nkb = N / LONG_BLK;
-    LongRegs r;
-    long_load(r, qb + D, rs, qb + 2 * D, rs, 0, tid);
-    long_store(r, smem, smem + IMG, tid);
+    const int nkb = (N + LONG_BLK - 1) / LONG_BLK;
+    LongRegs<HD> r;
+    long_load<HD, MASK>(r, qb + D, rs, qb + 2 * D, rs, 0, N, tid);
+    long_store<HD>(r, smem, smem + IMG, tid);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         const char* Kimg = smem + (kb & 1) * 2 * IMG;
         const char* Vimg = Kimg + IMG;
-        if (kb + 1 < nkb) long_load(r, qb + D, rs, qb + 2 * D, rs, (kb + 1) * LONG_BLK, tid);
+        if (kb + 1 < nkb) long_load<HD, MASK>(r, qb + D, rs, qb + 2 * D, rs, (kb + 1) * LONG_BLK, N, tid);
         f32x4 s[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -441,6 +457,13 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_fwd_kernel(
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 s[kt] = MFMA16(row_frag<HD>(Kimg, kt * 16, ks, lane), qf[ks], s[kt]);
+        }
+        if (MASK && kb == nkb - 1) {  // wave-uniform: padded keys only in the last block
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    if (kb * LONG_BLK + kt * 16 + 4 * g + rr >= N) s[kt][rr] = -INFINITY;
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -472,30 +495,34 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_fwd_kernel(
         }
         if (kb + 1 < nkb) {
             char* nK = smem + ((kb + 1) & 1) * 2 * IMG;
-            long_store(r, nK, nK + IMG, tid);
+            long_store<HD>(r, nK, nK + IMG, tid);
         }
         __syncthreads();
     }
     const float l = group_sum(lsum);
     const float inv = 1.0f / l;
-    bf16_t* orow = out + ((size_t)b * N + q) * D + h * HD + 4 * g;
+    if (!MASK || q < N) {
+        bf16_t* orow = out + ((size_t)b * N + q) * D + h * HD + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) st4(orow + dt * 16, o[dt] * inv);
-    if (g == 0) lse[((size_t)b * H + h) * N + q] = m * scale + __logf(l);
+        for (int dt = 0; dt < DT; ++dt) st4(orow + dt * 16, o[dt] * inv);
+        if (g == 0) lse[((size_t)b * H + h) * N + q] = m * scale + __logf(l);
+    }
 }
 
-// delta[b, h, q] = sum_d dO[b, q, h, d] O[b, q, h, d]   (8 lanes per (row, head), 16 B each)
+// delta[b, h, q] = sum_d dO[b, q, h, d] O[b, q, h, d]   (HD / 8 lanes per (row, head), 16 B each)
+template <int HD>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out,
                                                          const bf16_t* __restrict__ dout,
                                                          float* __restrict__ delta, long long rows,
                                                          int N, int H) {
+    constexpr int CPR = HD / 8;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (row, head, chunk)
-    const long long rh = idx >> 3;
-    const int ch = (int)(idx & 7);
+    const long long rh = idx / CPR;
+    const int ch = (int)(idx % CPR);
     if (rh >= rows * H) return;
     const long long row = rh / H;
     const int h = (int)(rh % H);
-    const size_t off = ((size_t)row * H + h) * 64 + ch * 8;
+    const size_t off = ((size_t)row * H + h) * HD + ch * 8;
     const u32x4 v = *(const u32x4*)(dout + off), o = *(const u32x4*)(out + off);
     float dot = 0.f;
 #pragma unroll
@@ -503,9 +530,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
         dot += __uint_as_float(v[j] << 16) * __uint_as_float(o[j] << 16);
         dot += __uint_as_float(v[j] & 0xffff0000u) * __uint_as_float(o[j] & 0xffff0000u);
     }
-    dot += __shfl_xor(dot, 4, 64);
-    dot += __shfl_xor(dot, 2, 64);
-    dot += __shfl_xor(dot, 1, 64);
+#pragma unroll
+    for (int o2 = CPR / 2; o2 > 0; o2 >>= 1) dot += __shfl_xor(dot, o2, 64);
     if (ch == 0) {
         const long long bb = row / N, n = row % N;
         delta[((size_t)bb * H + h) * N + n] = dot;
@@ -513,10 +539,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 // dQ: the workgroup owns 128 queries and streams K, V
+template <int HD, bool MASK>
 __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dq_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H, float scale) {
-    constexpr int HD = 64, KS = 2, DT = 4, IMG = LONG_BLK * HD * 2;
+    constexpr int KS = HD / 32, DT = HD / 16, IMG = LONG_BLK * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int b = blockIdx.y / H, h = blockIdx.y % H;
@@ -525,28 +552,30 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dq_kernel(
     const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
     const bf16_t* dob = dout + (size_t)b * N * D + h * HD;
     const int q = blockIdx.x * LONG_BLK + wave * 16 + (lane & 15);
+    const int qc = (MASK && q >= N) ? N - 1 : q;
     const float LOG2E = 1.44269504088896340736f;
     const float c = scale * LOG2E;
     bf16x8 qf[KS], dof[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = row_frag_global(qb, rs, q, ks, lane);
-        dof[ks] = row_frag_global(dob, D, q, ks, lane);
+        qf[ks] = row_frag_global(qb, rs, qc, ks, lane);
+        dof[ks] = row_frag_global(dob, D, qc, ks, lane);
     }
-    const float l2 = lse[((size_t)b * H + h) * N + q] * LOG2E;
-    const float dl = delta[((size_t)b * H + h) * N + q];
+    const float l2 = lse[((size_t)b * H + h) * N + qc] * LOG2E;
+    const float dl = delta[((size_t)b * H + h) * N + qc];
     f32x4 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
-    const int nkb = N / LONG_BLK;
-    LongRegs r;
-    long_load(r, qb + D, rs, qb + 2 * D, rs, 0, tid);
-    long_store(r, smem, smem + IMG, tid);
+    const int nkb = (N + LONG_BLK - 1) / LONG_BLK;
+    LongRegs<HD> r;
+    long_load<HD, MASK>(r, qb + D, rs, qb + 2 * D, rs, 0, N, tid);
+    long_store<HD>(r, smem, smem + IMG, tid);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         const char* Kimg = smem + (kb & 1) * 2 * IMG;
         const char* Vimg = Kimg + IMG;
-        if (kb + 1 < nkb) long_load(r, qb + D, rs, qb + 2 * D, rs, (kb + 1) * LONG_BLK, tid);
+        if (kb + 1 < nkb) long_load<HD, MASK>(r, qb + D, rs, qb + 2 * D, rs, (kb + 1) * LONG_BLK, N, tid);
+        const bool tail = MASK && kb == nkb - 1;  // wave-uniform
 #pragma unroll 1
         for (int kp = 0; kp < LONG_BLK / 32; ++kp) {
             f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
@@ -557,10 +586,15 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dq_kernel(
                 p0 = MFMA16(row_frag<HD>(Vimg, kp * 32, ks, lane), dof[ks], p0);
                 p1 = MFMA16(row_frag<HD>(Vimg, kp * 32 + 16, ks, lane), dof[ks], p1);
             }
+            const int ka = kb * LONG_BLK + kp * 32 + 4 * g;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const float pa = __builtin_amdgcn_exp2f(s0[rr] * c - l2);
-                const float pb = __builtin_amdgcn_exp2f(s1[rr] * c - l2);
+                float pa = __builtin_amdgcn_exp2f(s0[rr] * c - l2);
+                float pb = __builtin_amdgcn_exp2f(s1[rr] * c - l2);
+                if (tail) {
+                    pa = (ka + rr < N) ? pa : 0.f;
+                    pb = (ka + 16 + rr < N) ? pb : 0.f;
+                }
                 s0[rr] = pa * (p0[rr] - dl);  // dS^T
                 s1[rr] = pb * (p1[rr] - dl);
             }
@@ -571,20 +605,23 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dq_kernel(
         }
         if (kb + 1 < nkb) {
             char* nK = smem + ((kb + 1) & 1) * 2 * IMG;
-            long_store(r, nK, nK + IMG, tid);
+            long_store<HD>(r, nK, nK + IMG, tid);
         }
         __syncthreads();
     }
-    bf16_t* dr = dqkv + (size_t)b * N * rs + h * HD + (size_t)q * rs + 4 * g;
+    if (!MASK || q < N) {
+        bf16_t* dr = dqkv + (size_t)b * N * rs + h * HD + (size_t)q * rs + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) st4(dr + dt * 16, dq[dt] * scale);
+        for (int dt = 0; dt < DT; ++dt) st4(dr + dt * 16, dq[dt] * scale);
+    }
 }
 
 // dK, dV: the workgroup owns 128 keys and streams Q, dO (+ the lse / delta rows of the block)
+template <int HD, bool MASK>
 __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H, float scale) {
-    constexpr int HD = 64, KS = 2, DT = 4, IMG = LONG_BLK * HD * 2;
+    constexpr int KS = HD / 32, DT = HD / 16, IMG = LONG_BLK * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][Q | dO], then [buf][lse | delta]
     float* stat = (float*)(smem + 4 * IMG);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
@@ -596,13 +633,14 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dkv_kernel(
     const float* lrow = lse + ((size_t)b * H + h) * N;
     const float* drow = delta + ((size_t)b * H + h) * N;
     const int key = blockIdx.x * LONG_BLK + wave * 16 + (lane & 15);
+    const int kc = (MASK && key >= N) ? N - 1 : key;
     const float LOG2E = 1.44269504088896340736f;
     const float c = scale * LOG2E;
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = row_frag_global(qb + D, rs, key, ks, lane);
-        vf[ks] = row_frag_global(qb + 2 * D, rs, key, ks, lane);
+        kf[ks] = row_frag_global(qb + D, rs, kc, ks, lane);
+        vf[ks] = row_frag_global(qb + 2 * D, rs, kc, ks, lane);
     }
     f32x4 dk[DT], dv[DT];
 #pragma unroll
@@ -610,16 +648,17 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dkv_kernel(
         dk[dt] = f32x4{0, 0, 0, 0};
         dv[dt] = f32x4{0, 0, 0, 0};
     }
-    const int nqb = N / LONG_BLK;
-    LongRegs r;
+    const int nqb = (N + LONG_BLK - 1) / LONG_BLK;
+    LongRegs<HD> r;
     float st_next = 0.f;  // threads 0..127: lse * log2e, 128..255: delta of the next block
     auto stat_load = [&](int blk) {
-        if (tid < LONG_BLK) st_next = lrow[blk * LONG_BLK + tid] * LOG2E;
-        else if (tid < 2 * LONG_BLK) st_next = drow[blk * LONG_BLK + tid - LONG_BLK];
+        const int i = blk * LONG_BLK + (tid & (LONG_BLK - 1));
+        st_next = 0.f;
+        if (tid < 2 * LONG_BLK && (!MASK || i < N)) st_next = tid < LONG_BLK ? lrow[i] * LOG2E : drow[i];
     };
-    long_load(r, qb, rs, dob, D, 0, tid);
+    long_load<HD, MASK>(r, qb, rs, dob, D, 0, N, tid);
     stat_load(0);
-    long_store(r, smem, smem + IMG, tid);
+    long_store<HD>(r, smem, smem + IMG, tid);
     if (tid < 2 * LONG_BLK) stat[tid] = st_next;
     __syncthreads();
     for (int qbk = 0; qbk < nqb; ++qbk) {
@@ -628,9 +667,10 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dkv_kernel(
         const float* lse_s = stat + (qbk & 1) * 2 * LONG_BLK;
         const float* del_s = lse_s + LONG_BLK;
         if (qbk + 1 < nqb) {
-            long_load(r, qb, rs, dob, D, (qbk + 1) * LONG_BLK, tid);
+            long_load<HD, MASK>(r, qb, rs, dob, D, (qbk + 1) * LONG_BLK, N, tid);
             stat_load(qbk + 1);
         }
+        const bool tail = MASK && qbk == nqb - 1;  // wave-uniform: padded queries only in the last block
 #pragma unroll 1
         for (int qp = 0; qp < LONG_BLK / 32; ++qp) {
             f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
@@ -649,6 +689,10 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dkv_kernel(
             for (int rr = 0; rr < 4; ++rr) {
                 pa[rr] = __builtin_amdgcn_exp2f(s0[rr] * c - la[rr]);
                 pb[rr] = __builtin_amdgcn_exp2f(s1[rr] * c - lb[rr]);
+                if (tail) {
+                    pa[rr] = (qbk * LONG_BLK + qa + rr < N) ? pa[rr] : 0.f;
+                    pb[rr] = (qbk * LONG_BLK + qa + 16 + rr < N) ? pb[rr] : 0.f;
+                }
                 dsa[rr] = pa[rr] * (p0[rr] - da[rr]);
                 dsb[rr] = pb[rr] * (p1[rr] - db[rr]);
             }
@@ -661,16 +705,18 @@ __global__ __launch_bounds__(64 * LONG_WAVES, 2) void attn_long_bwd_dkv_kernel(
         }
         if (qbk + 1 < nqb) {
             char* nQ = smem + ((qbk + 1) & 1) * 2 * IMG;
-            long_store(r, nQ, nQ + IMG, tid);
+            long_store<HD>(r, nQ, nQ + IMG, tid);
             if (tid < 2 * LONG_BLK) stat[((qbk + 1) & 1) * 2 * LONG_BLK + tid] = st_next;
         }
         __syncthreads();
     }
-    bf16_t* dr = dqkv + (size_t)b * N * rs + h * HD + (size_t)key * rs + 4 * g;
+    if (!MASK || key < N) {
+        bf16_t* dr = dqkv + (size_t)b * N * rs + h * HD + (size_t)key * rs + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        st4(dr + D + dt * 16, dk[dt] * scale);
-        st4(dr + 2 * D + dt * 16, dv[dt]);
+        for (int dt = 0; dt < DT; ++dt) {
+            st4(dr + D + dt * 16, dk[dt] * scale);
+            st4(dr + 2 * D + dt * 16, dv[dt]);
+        }
     }
 }
 
@@ -732,7 +778,23 @@ static ssl4gie_gemm_desc bdesc(int M, int N, int K, int B, int H) {
     return d;
 }
 
-static bool attn_long(int N, int hd) { return N > 256 && N % LONG_BLK == 0 && hd == 64; }
+// SSL4GIE_ATTN_STREAM_MIN: smallest N that takes the streaming kernels.  Default 257: measured
+// (profiles/r01q_attn_stream_vs_whole.log), the whole-head-in-LDS kernels win up to N = 256 —
+// at N = 197 the 128-row blocks pad keys to 256 and queries to 256, K/V are staged twice per head
+// and the backward recomputes the scores in two kernels.  Lower values are for A/B measurements;
+// the streaming kernels handle any N (MASK variant) for hd 32 / 64.
+static int attn_stream_min() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SSL4GIE_ATTN_STREAM_MIN");
+        v = e ? atoi(e) : 257;
+        if (v < 1) v = 1;
+    }
+    return v;
+}
+static bool attn_long(int N, int hd) {
+    return (hd == 64 || hd == 32) && (N > 256 || N >= attn_stream_min());
+}
 
 extern "C" size_t ssl4gie_attn_workspace_bytes(int dtype, int B, int N, int H, int hd) {
     if (dtype == SSL4GIE_BF16)  // long sequences: delta[b, h, q] of the backward pass
@@ -777,16 +839,25 @@ extern "C" int ssl4gie_attn_fwd(const void* qkv, void* out, float* lse, int dtyp
     if (dtype == SSL4GIE_BF16) {
         REQUIRE(hd == 32 || hd == 64);
         if (attn_long(N, hd)) {
-            const int lds = 4 * LONG_BLK * 64 * 2;
-            static bool attr = false;
-            if (!attr) {
-                HIP_RET(hipFuncSetAttribute((const void*)attn_long_fwd_kernel,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                attr = true;
-            }
+            const int lds = 4 * LONG_BLK * hd * 2;
+            const bool mask = N % LONG_BLK != 0;
+            const dim3 grid((N + LONG_BLK - 1) / LONG_BLK, B * H), block(64 * LONG_WAVES);
             ProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * hd, st);
-            hipLaunchKernelGGL(attn_long_fwd_kernel, dim3(N / LONG_BLK, B * H), dim3(64 * LONG_WAVES),
-                               lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+#define LFWD(HD_, MASK_)                                                                           \
+    do {                                                                                           \
+        auto kfn = attn_long_fwd_kernel<HD_, MASK_>;                                               \
+        static bool attr = false;                                                                  \
+        if (!attr) {                                                                               \
+            HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 65536));      \
+            attr = true;                                                                           \
+        }                                                                                          \
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, \
+                           scale);                                                                 \
+    } while (0)
+            if (hd == 64) { if (mask) LFWD(64, true); else LFWD(64, false); }
+            else { if (mask) LFWD(32, true); else LFWD(32, false); }
+#undef LFWD
             LAUNCH_CHECK();
             return 0;
         }
@@ -834,26 +905,39 @@ extern "C" int ssl4gie_attn_bwd(const void* qkv, const void* out, const void* do
             REQUIRE(workspace);
             float* delta = (float*)workspace;
             const long long rows = (long long)B * N;
-            const long long items = rows * H * 8;
-            hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
-                               (const bf16_t*)out, (const bf16_t*)dout, delta, rows, N, H);
+            const long long items = rows * H * (hd / 8);
+            const dim3 dgrid((unsigned)((items + 255) / 256));
+            if (hd == 64)
+                hipLaunchKernelGGL(attn_delta_kernel<64>, dgrid, dim3(256), 0, st, (const bf16_t*)out,
+                                   (const bf16_t*)dout, delta, rows, N, H);
+            else
+                hipLaunchKernelGGL(attn_delta_kernel<32>, dgrid, dim3(256), 0, st, (const bf16_t*)out,
+                                   (const bf16_t*)dout, delta, rows, N, H);
             LAUNCH_CHECK();
-            const int lds_q = 4 * LONG_BLK * 64 * 2, lds_kv = lds_q + 4 * LONG_BLK * (int)sizeof(float);
-            static bool attr = false;
-            if (!attr) {
-                HIP_RET(hipFuncSetAttribute((const void*)attn_long_bwd_dq_kernel,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_q));
-                HIP_RET(hipFuncSetAttribute((const void*)attn_long_bwd_dkv_kernel,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv));
-                attr = true;
-            }
+            const int lds_q = 4 * LONG_BLK * hd * 2, lds_kv = lds_q + 4 * LONG_BLK * (int)sizeof(float);
+            const bool mask = N % LONG_BLK != 0;
             ProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * hd, st);
-            dim3 grid(N / LONG_BLK, B * H), block(64 * LONG_WAVES);
-            hipLaunchKernelGGL(attn_long_bwd_dq_kernel, grid, block, lds_q, st, (const bf16_t*)qkv,
-                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
-            LAUNCH_CHECK();
-            hipLaunchKernelGGL(attn_long_bwd_dkv_kernel, grid, block, lds_kv, st, (const bf16_t*)qkv,
-                               (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+            const dim3 grid((N + LONG_BLK - 1) / LONG_BLK, B * H), block(64 * LONG_WAVES);
+#define LBWD(HD_, MASK_)                                                                           \
+    do {                                                                                           \
+        auto kq = attn_long_bwd_dq_kernel<HD_, MASK_>;                                             \
+        auto kkv = attn_long_bwd_dkv_kernel<HD_, MASK_>;                                           \
+        static bool attr = false;                                                                  \
+        if (!attr) {                                                                               \
+            HIP_RET(hipFuncSetAttribute((const void*)kq,                                           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 65536));      \
+            HIP_RET(hipFuncSetAttribute((const void*)kkv,                                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 2048)); \
+            attr = true;                                                                           \
+        }                                                                                          \
+        hipLaunchKernelGGL(kq, grid, block, lds_q, st, (const bf16_t*)qkv, (const bf16_t*)dout,    \
+                           lse, delta, (bf16_t*)dqkv, N, H, scale);                                \
+        hipLaunchKernelGGL(kkv, grid, block, lds_kv, st, (const bf16_t*)qkv, (const bf16_t*)dout,  \
+                           lse, delta, (bf16_t*)dqkv, N, H, scale);                                \
+    } while (0)
+            if (hd == 64) { if (mask) LBWD(64, true); else LBWD(64, false); }
+            else { if (mask) LBWD(32, true); else LBWD(32, false); }
+#undef LBWD
             LAUNCH_CHECK();
             return 0;
         }

@@ -225,7 +225,7 @@ def test_attention_f32_path(N, H, hd):
     assert rel_err(dqkv, t.grad) < 2e-5
 
 
-@pytest.mark.parametrize("N", [50, 197, 17, 64, 224, 256, 1])
+@pytest.mark.parametrize("N", [50, 197, 17, 64, 65, 128, 129, 224, 256, 300, 1])
 @pytest.mark.parametrize("hd", [64, 32])
 def test_attention_bf16_fused(N, hd):
     from ssl4gie_amd import ops
