@@ -117,6 +117,13 @@ typedef struct ssl4gie_gemm_desc {
 size_t ssl4gie_gemm_workspace_bytes(const ssl4gie_gemm_desc* d);
 int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t workspace_bytes,
                  void* stream);
+/* Two weight-gradient (TN) products with the same contraction length K in one launch: they share
+ * the one-workgroup-per-CU grid, so each needs half the split-K slabs (and half the reduction
+ * traffic) it would need alone.  Descriptors as for ssl4gie_gemm; pairs that do not qualify run as
+ * two ssl4gie_gemm calls.  Used for (dW_fc2, dW_fc1) and (dW_proj, dW_qkv) of a transformer block. */
+size_t ssl4gie_gemm_tn_pair_workspace_bytes(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b);
+int ssl4gie_gemm_tn_pair(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- attention
  * replaces timm Attention.forward == Models/models.py:195-209 minus windowing:

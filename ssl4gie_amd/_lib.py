@@ -115,6 +115,8 @@ PROTOTYPES = {
     "ssl4gie_map_layernorm_workspace_bytes": (sz, [i32]),
     "ssl4gie_map_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i64, vp]),
     "ssl4gie_map_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i64, vp]),
+    "ssl4gie_gemm_tn_pair_workspace_bytes": (sz, [vp, vp]),
+    "ssl4gie_gemm_tn_pair": (i32, [vp, vp, vp, sz, vp]),
     "ssl4gie_set_wgrad_stream": (i32, [i32]),
     "ssl4gie_set_compute_cus": (i32, [i32]),
     "ssl4gie_prof_begin": (i32, [i32]),

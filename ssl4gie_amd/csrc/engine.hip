@@ -150,12 +150,15 @@ BwdLayout bwd_layout(const ssl4gie_block_dims* d) {
     L.dqkv = o; o += align_up(T * 3 * D * es);
     L.ln_ws = o; o += align_up(ssl4gie_layernorm_bwd_workspace_bytes((int)T, (int)D));
     size_t g = 0;
-    const int dims[4][2] = {{(int)(3 * D), (int)D}, {(int)D, (int)D}, {(int)F, (int)D}, {(int)D, (int)F}};
-    for (int i = 0; i < 4; ++i) {
+    // the weight gradients run as two pairs: (fc2, fc1) and (proj, qkv)
+    const int dims[4][2] = {{(int)D, (int)F}, {(int)F, (int)D}, {(int)D, (int)D}, {(int)(3 * D), (int)D}};
+    for (int i = 0; i < 4; i += 2) {
         // pointers only matter for alignment checks: use 16-B aligned dummies
-        ssl4gie_gemm_desc w = wgrad_desc(dims[i][0], dims[i][1], (int)T, (const void*)256,
-                                         (const void*)256, (float*)256, (float*)256, d->dtype, 0);
-        const size_t b = ssl4gie_gemm_workspace_bytes(&w);
+        ssl4gie_gemm_desc w0 = wgrad_desc(dims[i][0], dims[i][1], (int)T, (const void*)256,
+                                          (const void*)256, (float*)256, (float*)256, d->dtype, 0);
+        ssl4gie_gemm_desc w1 = wgrad_desc(dims[i + 1][0], dims[i + 1][1], (int)T, (const void*)256,
+                                          (const void*)256, (float*)256, (float*)256, d->dtype, 0);
+        const size_t b = ssl4gie_gemm_tn_pair_workspace_bytes(&w0, &w1);
         if (b > g) g = b;
     }
     L.gemm_ws_bytes = g;
@@ -257,7 +260,7 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     float* ln_ws = (float*)(ws + L.ln_ws);
     void* gws = ws + L.gemm_ws;
     const void* dy = (dt == SSL4GIE_F32) ? (const void*)dx_out : dx_out_lp;
-    ssl4gie_gemm_desc e, wg;
+    ssl4gie_gemm_desc e, wg, wg2;
     // weight gradients go to the side stream when there is one (see SideStream)
     hipStream_t main_st = (hipStream_t)stream;
     SideStream* ss = side_stream();
@@ -272,16 +275,15 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     };
 
     // ---- fc2
-    RC(fork());
-    wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, g->bfc2, dt, accumulate);
-    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, wst));
     memset(&e, 0, sizeof(e));
     e.C = du; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_MUL_AUX; e.aux = a->u;
     RC(linear_bwd_data(dy, w->wfc2, w->wfc2_t, T, D, F, dt, e, stream));
-    // ---- fc1
+    // ---- dW_fc2 and dW_fc1 as one paired launch (both inputs exist once du does)
     RC(fork());
-    wg = wgrad_desc(F, D, T, du, a->h2, g->wfc1, g->bfc1, dt, accumulate);
-    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, wst));
+    wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, g->bfc2, dt, accumulate);
+    wg2 = wgrad_desc(F, D, T, du, a->h2, g->wfc1, g->bfc1, dt, accumulate);
+    RC(ssl4gie_gemm_tn_pair(&wg, &wg2, gws, L.gemm_ws_bytes, wst));
+    // ---- fc1
     memset(&e, 0, sizeof(e));
     e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(du, w->wfc1, w->wfc1_t, T, F, D, dt, e, stream));
@@ -290,19 +292,18 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
                              dt == SSL4GIE_F32 ? nullptr : dxmid_lp, dt, g->ln2_g, g->ln2_b,
                              accumulate, ln_ws, T, D, stream));
     // ---- proj
-    RC(fork());
-    wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
-    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, wst));
     memset(&e, 0, sizeof(e));
     e.C = dattn; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(dxmid_lp, w->wproj, w->wproj_t, T, D, D, dt, e, stream));
     // ---- attention
     RC(ssl4gie_attn_bwd(a->qkv, a->attn, dattn, a->lse, dqkv, dt, d->B, d->N, d->H, D / d->H,
                         ws + L.attn_ws, stream));
-    // ---- qkv
+    // ---- dW_proj and dW_qkv as one paired launch
     RC(fork());
-    wg = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
-    RC(ssl4gie_gemm(&wg, gws, L.gemm_ws_bytes, wst));
+    wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
+    wg2 = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
+    RC(ssl4gie_gemm_tn_pair(&wg, &wg2, gws, L.gemm_ws_bytes, wst));
+    // ---- qkv
     memset(&e, 0, sizeof(e));
     e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(dqkv, w->wqkv, w->wqkv_t, T, 3 * D, D, dt, e, stream));

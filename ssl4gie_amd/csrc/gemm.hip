@@ -940,3 +940,88 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     }
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Two weight-gradient (TN) products with the same contraction length in ONE launch.  A split-K TN
+// product alone spreads over ~one workgroup per CU, each writing a full 256 x 256 fp32 slab (64 MiB
+// per product whatever its shape); two products sharing the grid need half the splits each, hence
+// half the slab traffic and reduction work.  Falls back to two ssl4gie_gemm calls when the pair does
+// not qualify (shape rules of the 256x256 TN kernel, equal K, no implicit-conv operand).
+static bool tn_pair_ok(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b) {
+    static int enabled = -1;  // SSL4GIE_TN_PAIR=0: always two launches (A/B measurements)
+    if (enabled < 0) {
+        const char* e = getenv("SSL4GIE_TN_PAIR");
+        enabled = (e && e[0] == '0') ? 0 : 1;
+    }
+    return enabled && a && b && !nt_ok(a) && !nt_ok(b) && tn_ok(a) && tn_ok(b) && !a->conv && !b->conv &&
+           ssl4gie_internal_tn256_ok(a) && ssl4gie_internal_tn256_ok(b) && a->K == b->K &&
+           a->accumulate == b->accumulate && a->alpha == 1.f && b->alpha == 1.f &&
+           a->N % 4 == 0 && b->N % 4 == 0;
+}
+struct PairPlan {
+    int splits;
+    size_t slab_a, slab_b, cs_a, cs_b, off_b, off_csa, off_csb, total;
+};
+static PairPlan pair_plan(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b) {
+    PairPlan p;
+    p.splits = ssl4gie_internal_tn256_pair_splits(a, b);
+    const bool sp = p.splits > 1;
+    p.slab_a = sp ? al256((size_t)p.splits * a->M * a->N * sizeof(float)) : 0;
+    p.slab_b = sp ? al256((size_t)p.splits * b->M * b->N * sizeof(float)) : 0;
+    p.cs_a = (sp && a->colsum_a) ? al256((size_t)p.splits * a->M * sizeof(float)) : 0;
+    p.cs_b = (sp && b->colsum_a) ? al256((size_t)p.splits * b->M * sizeof(float)) : 0;
+    p.off_b = p.slab_a;
+    p.off_csa = p.off_b + p.slab_b;
+    p.off_csb = p.off_csa + p.cs_a;
+    p.total = p.off_csb + p.cs_b;
+    return p;
+}
+extern "C" size_t ssl4gie_gemm_tn_pair_workspace_bytes(const ssl4gie_gemm_desc* a,
+                                                       const ssl4gie_gemm_desc* b) {
+    if (!a || !b) return 0;
+    if (tn_pair_ok(a, b)) return pair_plan(a, b).total;
+    const size_t wa = ssl4gie_gemm_workspace_bytes(a), wb = ssl4gie_gemm_workspace_bytes(b);
+    return wa > wb ? wa : wb;
+}
+extern "C" int ssl4gie_gemm_tn_pair(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    REQUIRE(a && b);
+    if (!tn_pair_ok(a, b)) {
+        const int rc = ssl4gie_gemm(a, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        return ssl4gie_gemm(b, workspace, workspace_bytes, stream);
+    }
+    REQUIRE(a->A && a->B && a->C && b->A && b->B && b->C);
+    REQUIRE(!a->colsum_a || a->sAk >= a->M);
+    REQUIRE(!b->colsum_a || b->sAk >= b->M);
+    hipStream_t st = (hipStream_t)stream;
+    const PairPlan p = pair_plan(a, b);
+    REQUIRE(p.total == 0 || (workspace && workspace_bytes >= p.total));
+    char* ws = (char*)workspace;
+    float* slabs_a = (float*)ws;
+    float* slabs_b = (float*)(ws + p.off_b);
+    float* cs_a = p.cs_a ? (float*)(ws + p.off_csa) : nullptr;
+    float* cs_b = p.cs_b ? (float*)(ws + p.off_csb) : nullptr;
+    {
+        ProfScope prof(PROF_GEMM_TN, 2.0 * a->K * ((double)a->M * a->N + (double)b->M * b->N), st);
+        const int rc = ssl4gie_internal_tn256_launch_pair(a, b, p.splits, slabs_a, cs_a, slabs_b, cs_b, st);
+        if (rc) return rc;
+    }
+    if (p.splits > 1) {
+        const ssl4gie_gemm_desc* ds[2] = {a, b};
+        float* sl[2] = {slabs_a, slabs_b};
+        float* cs[2] = {cs_a, cs_b};
+        for (int i = 0; i < 2; ++i) {
+            const ssl4gie_gemm_desc* d = ds[i];
+            const size_t total4 = (size_t)d->M * d->N / 4;
+            const unsigned c_blocks = (unsigned)((total4 + 255) / 256);
+            const unsigned b_blocks = d->colsum_a ? (unsigned)((d->M + 255) / 256) : 0;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(c_blocks + b_blocks), dim3(256), 0, st,
+                               (const float*)sl[i], (float*)d->C, d->ldc, d->M, d->N, p.splits, d->alpha,
+                               d->accumulate, (const float*)cs[i], d->colsum_a, c_blocks);
+            LAUNCH_CHECK();
+        }
+    }
+    return 0;
+}

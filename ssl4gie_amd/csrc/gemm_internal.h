@@ -52,3 +52,17 @@ int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d);
 // `slabs` (splits > 1) and `colsum_part` ([splits][M], splits > 1 and d->colsum_a) are workspace
 int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, float* slabs, float* colsum_part,
                                   hipStream_t st);
+// Second problem of a paired launch (two TN products with the same contraction length K share one
+// grid: half the split-K slabs each would need alone).  ntiles == 0: no second problem.
+struct TnSecond {
+    const void* At; long long ldat;
+    const void* Bt; long long ldbt;
+    float* C; long long ldc;
+    float* slabs;
+    int M, N, tiles_n, ntiles;
+    float* colsum; float* colsum_part;
+};
+int ssl4gie_internal_tn256_pair_splits(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b);
+int ssl4gie_internal_tn256_launch_pair(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b,
+                                       int splits, float* slabs_a, float* cs_a, float* slabs_b,
+                                       float* cs_b, hipStream_t st);

@@ -50,13 +50,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     const bf16_t* __restrict__ At, long long ldat, const bf16_t* __restrict__ Bt, long long ldbt,
     float* __restrict__ C, long long ldc, float* __restrict__ slabs, int M, int N, int K,
     int tiles_n, int ntiles, int splits, float alpha, int accumulate, float* __restrict__ colsum,
-    float* __restrict__ colsum_part, ConvK cg) {
+    float* __restrict__ colsum_part, ConvK cg, TnSecond sec) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = bid / ntiles, tile = bid % ntiles;
+    const int all_tiles = ntiles + sec.ntiles;
+    const int split = bid / all_tiles;
+    int tile = bid % all_tiles;
+    if (tile >= ntiles) {  // paired launch: this workgroup belongs to the second product (uniform)
+        tile -= ntiles;
+        At = (const bf16_t*)sec.At; ldat = sec.ldat;
+        Bt = (const bf16_t*)sec.Bt; ldbt = sec.ldbt;
+        C = sec.C; ldc = sec.ldc; slabs = sec.slabs;
+        M = sec.M; N = sec.N; tiles_n = sec.tiles_n;
+        colsum = sec.colsum; colsum_part = sec.colsum_part;
+    }
     const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * P_BN;
     const int nkt = K / P_BK;
     const int kt0 = (int)((long long)nkt * split / splits);
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     bf16x8 a[4][2], b0[2][2], b1[2][2];
     f32x4 accb[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    const bool do_cs = COLSUM && (n0 == 0);
+    const bool do_cs = COLSUM && (n0 == 0) && colsum != nullptr;
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
@@ -318,11 +328,45 @@ int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d) {
     return s;
 }
 
+int ssl4gie_internal_tn256_pair_splits(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b) {
+    const int tiles = ((a->M + P_BM - 1) / P_BM) * ((a->N + P_BN - 1) / P_BN) +
+                      ((b->M + P_BM - 1) / P_BM) * ((b->N + P_BN - 1) / P_BN);
+    const int nkt = a->K / P_BK;
+    int s = (ssl4gie_internal_compute_cus() + tiles / 2) / tiles;
+    if (s > nkt / 8) s = nkt / 8;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+static int tn256_launch_impl(const ssl4gie_gemm_desc* d, const ssl4gie_gemm_desc* d2, int splits,
+                             float* slabs, float* colsum_part, float* slabs2, float* colsum_part2,
+                             hipStream_t st);
+
 int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, float* slabs, float* colsum_part,
                                   hipStream_t st) {
+    return tn256_launch_impl(d, nullptr, ssl4gie_internal_tn256_splits(d), slabs, colsum_part, nullptr,
+                             nullptr, st);
+}
+int ssl4gie_internal_tn256_launch_pair(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b,
+                                       int splits, float* slabs_a, float* cs_a, float* slabs_b,
+                                       float* cs_b, hipStream_t st) {
+    return tn256_launch_impl(a, b, splits, slabs_a, cs_a, slabs_b, cs_b, st);
+}
+
+static int tn256_launch_impl(const ssl4gie_gemm_desc* d, const ssl4gie_gemm_desc* d2, int splits,
+                             float* slabs, float* colsum_part, float* slabs2, float* colsum_part2,
+                             hipStream_t st) {
     const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + P_BN - 1) / P_BN;
-    const int splits = ssl4gie_internal_tn256_splits(d);
-    dim3 grid(tm * tn * splits), block(512);
+    TnSecond sec{};
+    if (d2) {
+        const int tm2 = (d2->M + P_BM - 1) / P_BM, tn2 = (d2->N + P_BN - 1) / P_BN;
+        sec.At = d2->A; sec.ldat = d2->sAk; sec.Bt = d2->B; sec.ldbt = d2->sBk;
+        sec.C = (float*)d2->C; sec.ldc = d2->ldc; sec.slabs = slabs2;
+        sec.M = d2->M; sec.N = d2->N; sec.tiles_n = tn2; sec.ntiles = tm2 * tn2;
+        sec.colsum = d2->colsum_a; sec.colsum_part = colsum_part2;
+    }
+    dim3 grid((tm * tn + sec.ntiles) * splits), block(512);
     ConvK ck{};
     if (d->conv) {
         const int rc = ssl4gie_internal_conv_k(d->conv, &ck);
@@ -340,10 +384,10 @@ int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, float* slabs, floa
         hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAk,         \
                            (const bf16_t*)d->B, d->sBk, (float*)d->C, d->ldc, slabs, d->M, d->N,   \
                            d->K, tn, tm * tn, splits, d->alpha, d->accumulate, d->colsum_a,        \
-                           colsum_part, ck);                                                       \
+                           colsum_part, ck, sec);                                                  \
     } while (0)
     const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
-    if (d->colsum_a) {
+    if (d->colsum_a || (d2 && d2->colsum_a)) {
         if (cv == 0) Q_LAUNCH(true, 0);
         else if (cv == 1) Q_LAUNCH(true, 1);
         else Q_LAUNCH(true, 2);
