@@ -169,8 +169,13 @@ def bench_moco(a):
     ddp = parallel.DataParallel(model) if world > 1 else None
     # lr: the reference ramps 0 -> 0.6 bs/256 over 10 warm-up epochs (main_moco.py:420-428); a
     # throughput run on uncorrelated noise views uses an early-warm-up value
-    opt = LARS([p for p in model.parameters() if p.requires_grad], lr=0.03 * B * world / 256,
-               weight_decay=1e-6, momentum=0.9)
+    if a.optim == "arena":
+        from ssl4gie_amd.optim import ArenaLARS
+        opt = ArenaLARS(model, [p for p in model.parameters() if p.requires_grad],
+                        lr=0.03 * B * world / 256, weight_decay=1e-6, momentum=0.9)
+    else:
+        opt = LARS([p for p in model.parameters() if p.requires_grad], lr=0.03 * B * world / 256,
+                   weight_decay=1e-6, momentum=0.9)
     g = torch.Generator("cpu").manual_seed(rank)
     x1 = torch.randn(B, 3, 224, 224, generator=g).to(dev)
     x2 = torch.randn(B, 3, 224, 224, generator=g).to(dev)
@@ -437,6 +442,9 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--optim", default="torch", choices=["torch", "arena"],
+                    help="torch: torch.optim fused / foreach steps (what the north_star prescribes); arena: "
+                         "the same updates as kernels over the parameter arena (ssl4gie_amd.optim)")
     ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco", "bt", "det", "vit"],
                     help="mae = BASELINE.json configs[1] (the headline metric); depth = configs[3] "
                          "(ViT-B + DPT depth finetune step, bs 128/GPU) as an extra measurement")
@@ -465,10 +473,14 @@ def main():
     torch.manual_seed(0)
     model = models_mae.mae_vit_base_patch16(norm_pix_loss=True).to(dev).set_precision(a.precision)
     ddp = parallel.DataParallel(model) if world > 1 else None
-    try:
-        opt = torch.optim.AdamW(param_groups(model), lr=1.5e-4, betas=(0.9, 0.95), fused=True)
-    except Exception:
-        opt = torch.optim.AdamW(param_groups(model), lr=1.5e-4, betas=(0.9, 0.95))
+    if a.optim == "arena":  # the same update as one kernel over the parameter arena
+        from ssl4gie_amd.optim import ArenaAdamW
+        opt = ArenaAdamW(model, param_groups(model), lr=1.5e-4, betas=(0.9, 0.95))
+    else:
+        try:
+            opt = torch.optim.AdamW(param_groups(model), lr=1.5e-4, betas=(0.9, 0.95), fused=True)
+        except Exception:
+            opt = torch.optim.AdamW(param_groups(model), lr=1.5e-4, betas=(0.9, 0.95))
 
     # seed + rank (main_pretrain.py:116); SSL4GIE_BENCH_SAME_DATA=1 feeds every rank the same batch,
     # which makes the N-rank run numerically comparable to N=1 (tools/gpu_rehearse_dp.sh)

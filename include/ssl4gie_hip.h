@@ -343,6 +343,22 @@ int ssl4gie_maxpool3x3s2_bwd(const void* dy, const unsigned char* arg, void* dx,
 int ssl4gie_avgpool_fwd(const void* x, float* y, int dtype, int B, int HW, int C, void* stream);
 int ssl4gie_avgpool_bwd(const float* dy, void* dx, int dtype, int B, int HW, int C, void* stream);
 
+/* ---------------------------------------------------------------- optimizer steps over the arena
+ * One parameter arena = S segments (one per parameter, 64-element aligned; padding stays zero).
+ * Device tables: seg_start [S+1] int64 element offsets, seg_lr [S] (< 0: skip the segment: frozen or
+ * without a gradient this step), seg_wd [S], seg_mat [S] (LARS: 1 for p.ndim > 1).
+ * adamw_arena: torch.optim.AdamW's update (main_pretrain.py:179-180, train_depth.py:280), `step` =
+ *   1-based step count for the bias corrections; m / v are the flat moment buffers.
+ * lars_arena: Models/moco_v3/moco/optimizer.py:18-43: matrices dp = (g + wd p) trust |p|/|dp|
+ *   (1 where a norm is 0), vectors dp = g; mu = momentum mu + dp; p -= lr mu. */
+int ssl4gie_adamw_arena(float* p, const float* g, float* m, float* v, const long long* seg_start,
+                        const float* seg_lr, const float* seg_wd, int S, float beta1, float beta2,
+                        float eps, int step, long long n, void* stream);
+size_t ssl4gie_lars_workspace_bytes(int S);
+int ssl4gie_lars_arena(float* p, const float* g, float* mu, const long long* seg_start,
+                       const float* seg_lr, const float* seg_wd, const float* seg_mat, int S,
+                       float momentum, float trust, float* workspace, long long n, void* stream);
+
 /* ---------------------------------------------------------------- input pipeline
  * transforms.ToTensor() + transforms.Normalize(mean, std) (Depth_estimation/Data/dataloaders.py:
  * 55-63) on the device: uint8 HWC [B, H, W, 3] -> fp32 NCHW [B, 3, H, W] = (x / 255 - mean) / std.

@@ -108,6 +108,9 @@ PROTOTYPES = {
     "ssl4gie_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_adamw_arena": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, i64, vp]),
+    "ssl4gie_lars_workspace_bytes": (sz, [i32]),
+    "ssl4gie_lars_arena": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, i64, vp]),
     "ssl4gie_normalize_u8": (i32, [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, i32, i32, vp]),
     "ssl4gie_maxpool2x2_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_maxpool2x2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -20,7 +20,7 @@ import os
 import torch
 
 from . import ops
-from .engine import GradSink, LPCache
+from .engine import GradSink, LPCache, weights_epoch
 
 
 # SSL4GIE_IMPLICIT_CONV=0 forces the materialised patch matrix (A/B measurements, parity tests)
@@ -38,7 +38,7 @@ def _fills_chip(x, stride, n_out):
 def _derived(lp: LPCache, p: torch.Tensor, tag: str, dtype, fn):
     """operand-type tensor derived from parameter `p` by `fn`, cached until p changes"""
     key = (id(p), tag)
-    ver = (p._version, p.data_ptr(), dtype)
+    ver = (p._version, p.data_ptr(), dtype, weights_epoch())
     ent = lp._c.get(key)
     if ent is None or ent[0] != ver:
         with torch.no_grad():

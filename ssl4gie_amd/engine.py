@@ -84,6 +84,19 @@ class ParamArena:
 # ------------------------------------------------------------------------------------------------
 # operand-type weight copies
 # ------------------------------------------------------------------------------------------------
+# Parameters updated by raw-pointer kernels (ssl4gie_amd.optim) do not bump torch's version counters:
+# those optimizers advance this epoch instead, and every operand cache keys on it.
+_WEIGHTS_EPOCH = [0]
+
+
+def weights_epoch() -> int:
+    return _WEIGHTS_EPOCH[0]
+
+
+def bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
+
 class LPCache:
     """bf16 copies W[out,in] and W^T[in,out] of fp32 master weights, refreshed when the parameter's
     version counter or storage changes (optimizer.step / load_state_dict bump it)."""
@@ -97,7 +110,7 @@ class LPCache:
         if dtype == torch.float32:
             return w2d, None
         key = id(p)
-        ver = (p._version, p.data_ptr(), dtype)
+        ver = (p._version, p.data_ptr(), dtype, weights_epoch())
         ent = self._c.get(key)
         if ent is None or ent[0] != ver or ent[3]() is not p:
             w = ops.cast(w2d, dtype)

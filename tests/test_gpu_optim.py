@@ -1,0 +1,127 @@
+"""GPU parity of the arena optimizer kernels against torch.optim.AdamW and the
+host-side LARS mirror of the reference (`ssl4gie_amd.Models.moco_v3.moco.optimizer.LARS`, itself
+pinned by the G8 fixture of the reference's own class)."""
+import copy
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ssl4gie_amd import _lib
+    _lib.load()
+
+
+def _toy():
+    from ssl4gie_amd.engine import EngineModule
+
+    class Toy(EngineModule):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(40, 72)
+            self.b = torch.nn.Linear(72, 24)
+            self.norm = torch.nn.LayerNorm(24)
+            self.frozen = torch.nn.Parameter(torch.randn(3, 5), requires_grad=False)
+            self.unused = torch.nn.Parameter(torch.randn(7))  # never receives a gradient
+            self.conv = torch.nn.Conv2d(8, 16, 3)
+    torch.manual_seed(0)
+    return Toy().to(DEV)
+
+
+def _fake_grads(m, seed):
+    g = torch.Generator("cpu").manual_seed(seed)
+    for name, p in m.named_parameters():
+        if p.requires_grad and name != "unused":
+            p.grad = torch.randn(p.shape, generator=g).to(DEV)
+        else:
+            p.grad = None
+
+
+def _groups(m):
+    decay = [p for n, p in m.named_parameters() if p.requires_grad and p.ndim > 1]
+    no_decay = [p for n, p in m.named_parameters() if p.requires_grad and p.ndim <= 1]
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.05}]
+
+
+def test_arena_adamw_matches_torch_adamw():
+    from ssl4gie_amd.optim import ArenaAdamW
+    m = _toy()
+    ref = copy.deepcopy(m)
+    m.arena()
+    opt = ArenaAdamW(m, _groups(m), lr=1e-2, betas=(0.9, 0.95))
+    topt = torch.optim.AdamW(_groups(ref), lr=1e-2, betas=(0.9, 0.95))
+    frozen0, unused0 = m.frozen.detach().clone(), m.unused.detach().clone()
+    for step in range(4):
+        _fake_grads(m, 10 + step)
+        for (n1, p1), (n2, p2) in zip(m.named_parameters(), ref.named_parameters()):
+            p2.grad = None if p1.grad is None else p1.grad.clone()
+        # grads must live in the arena for the kernel: copy them into the arena views
+        a = m.arena()
+        for p in m.parameters():
+            if p.grad is not None:
+                v = a.grad_view(p)
+                v.copy_(p.grad)
+                p.grad = v
+        if step == 2:  # a learning-rate schedule edits param_groups in place
+            for g in opt.param_groups + topt.param_groups:
+                g["lr"] = 5e-3
+        opt.step()
+        topt.step()
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), ref.named_parameters()):
+        assert rel_err(p1, p2) < 1e-5, n1
+    assert torch.equal(m.frozen, frozen0) and torch.equal(m.unused, unused0)
+
+
+def test_arena_lars_matches_reference_lars():
+    from ssl4gie_amd.Models.moco_v3.moco.optimizer import LARS
+    from ssl4gie_amd.optim import ArenaLARS
+    m = _toy()
+    ref = copy.deepcopy(m)
+    m.arena()
+    ps = [p for p in m.parameters() if p.requires_grad]
+    opt = ArenaLARS(m, ps, lr=0.3, weight_decay=1e-2, momentum=0.9)
+    topt = LARS([p for p in ref.parameters() if p.requires_grad], lr=0.3, weight_decay=1e-2, momentum=0.9)
+    for step in range(3):
+        _fake_grads(m, 20 + step)
+        for (n1, p1), (n2, p2) in zip(m.named_parameters(), ref.named_parameters()):
+            p2.grad = None if p1.grad is None else p1.grad.clone()
+        a = m.arena()
+        for p in m.parameters():
+            if p.grad is not None:
+                v = a.grad_view(p)
+                v.copy_(p.grad)
+                p.grad = v
+        opt.step()
+        topt.step()
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), ref.named_parameters()):
+        assert rel_err(p1, p2) < 1e-5, n1
+
+
+def test_arena_adamw_trains_mae_and_refreshes_operand_caches():
+    """end to end: the fused step must invalidate the bf16 weight copies (weights_epoch)"""
+    from ssl4gie_amd.Models.mae import models_mae
+    from ssl4gie_amd.optim import ArenaAdamW
+    torch.manual_seed(0)
+    m = models_mae.MaskedAutoencoderViT(embed_dim=192, depth=2, num_heads=3, decoder_embed_dim=128,
+                                        decoder_depth=1, decoder_num_heads=4, norm_pix_loss=True).to(DEV)
+    m.set_precision("bf16")
+    imgs = torch.randn(16, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(DEV)
+    noise = torch.rand(16, 196, generator=torch.Generator().manual_seed(2)).to(DEV)
+    opt = ArenaAdamW(m, [p for p in m.parameters() if p.requires_grad], lr=2e-3, betas=(0.9, 0.95),
+                     weight_decay=0.05)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss, _, _ = m(imgs, mask_ratio=0.75, noise=noise)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.9 * losses[0], losses
