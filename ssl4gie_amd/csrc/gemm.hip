@@ -834,7 +834,8 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     REQUIRE(d->batch1 >= 1 && d->batch2 >= 1);
     REQUIRE(d->dtype_ab == SSL4GIE_F32 || d->dtype_ab == SSL4GIE_BF16);
     REQUIRE(d->dtype_c == SSL4GIE_F32 || d->dtype_c == SSL4GIE_BF16);
-    REQUIRE(d->epilogue >= SSL4GIE_EPI_NONE && d->epilogue <= SSL4GIE_EPI_MUL_AUX);
+    REQUIRE(d->epilogue >= SSL4GIE_EPI_NONE && d->epilogue <= SSL4GIE_EPI_RELU_MASK_AUX);
+    REQUIRE(d->epilogue != SSL4GIE_EPI_RELU_MASK_AUX || (d->conv && d->aux));  // implicit conv only
     REQUIRE(d->epilogue != SSL4GIE_EPI_BIAS || d->bias);
     REQUIRE((d->epilogue != SSL4GIE_EPI_BIAS_GELU && d->epilogue != SSL4GIE_EPI_BIAS_GELU_GRAD) || d->out2);
     REQUIRE(d->epilogue != SSL4GIE_EPI_BIAS_RESIDUAL || d->residual);

@@ -126,7 +126,7 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
 // bf16 outputs multiplied by a bf16 auxiliary tile (the saved GELU derivative): same transposition,
 // fp32 through the staging area, the aux rows requested 6 row blocks ahead (48 VGPRs, the registers of the
 // dead operand fragments) in the coalesced row layout.
-// AUXF: 1 multiply by aux, 2 multiply by gelu'(aux).
+// AUXF: 1 multiply by aux, 2 multiply by gelu'(aux), 3 zero where aux <= 0 (ReLU mask).
 template <bool FULL, int AUXF>
 DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
                            const bf16_t* __restrict__ aux, bf16_t* __restrict__ C,
@@ -134,7 +134,7 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
     const int r16 = lane & 15, g4 = lane >> 4;
     const int R0 = lane >> 4, Cc = lane & 15;
     const int gn = cbase + 4 * Cc;
-    constexpr int PF = AUXF == 2 ? 4 : 6;  // ring of 6 of the 8 row blocks: 48 VGPRs
+    constexpr int PF = AUXF == 2 ? 4 : 6;  // ring of 6 (4) of the 8 row blocks: 48 VGPRs
     u32x2 ax[PF][4];
     auto fetch = [&](int mt, u32x2 (&dst)[4]) {
 #pragma unroll
@@ -166,7 +166,12 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) u[j] = dgelu_fast(u[j]);
             }
-            w *= u;
+            if constexpr (AUXF == 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = u[j] > 0.f ? w[j] : 0.f;
+            } else {
+                w *= u;
+            }
             if (FULL || (gm < M && gn < N)) st4(C + (size_t)gm * ldc + gn, w);
         }
         if (mt + PF < 8) fetch(mt + PF, ax[mt % PF]);

@@ -64,9 +64,10 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
             if (bias && (FULL || n < N)) bias4[nt] = ld4(bias + n);
         }
     }
-    if constexpr (sizeof(TC) == 2 && (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX)) {
-        p_store_bf16_aux<FULL, MODE == SSL4GIE_EPI_DGELU ? 2 : 1>(acc, stg, alpha, aux, (bf16_t*)C,
-                                                                  ldc, rbase, cbase, M, N, lane);
+    if constexpr (sizeof(TC) == 2 && (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
+                                      MODE == SSL4GIE_EPI_RELU_MASK_AUX)) {
+        constexpr int AUXF = MODE == SSL4GIE_EPI_DGELU ? 2 : (MODE == SSL4GIE_EPI_RELU_MASK_AUX ? 3 : 1);
+        p_store_bf16_aux<FULL, AUXF>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane);
     } else if constexpr (sizeof(TC) == 2) {
         // bf16: stage 16 rows x 64 columns (2 KiB), chunk c of row r at position c ^ (r & 7)
         const int R0 = lane >> 3, Cc = lane & 7;
@@ -404,12 +405,13 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
         return ssl4gie_internal_conv_geom_ok(d->conv) && d->conv->C % P_BK == 0 &&
                d->K == 9 * d->conv->C && (long long)d->M == conv_rows(d->conv) &&
                d->dtype_c == SSL4GIE_BF16 && !d->accumulate &&
-               (ep == SSL4GIE_EPI_BIAS || ep == SSL4GIE_EPI_NONE);
+               (ep == SSL4GIE_EPI_BIAS || ep == SSL4GIE_EPI_NONE ||
+                (ep == SSL4GIE_EPI_RELU_MASK_AUX && d->aux && !d->conv->relu));
     if (d->dtype_c == SSL4GIE_BF16) {
         if (ep == SSL4GIE_EPI_BIAS_RESIDUAL || d->accumulate) return false;
     } else {
         if (ep == SSL4GIE_EPI_BIAS_GELU || ep == SSL4GIE_EPI_DGELU ||
-            ep == SSL4GIE_EPI_BIAS_GELU_GRAD || ep == SSL4GIE_EPI_MUL_AUX)
+            ep == SSL4GIE_EPI_BIAS_GELU_GRAD || ep == SSL4GIE_EPI_MUL_AUX || ep == SSL4GIE_EPI_RELU_MASK_AUX)
             return false;
     }
     if (mode == 1) return true;
@@ -448,7 +450,8 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     } while (0)
     if (d->conv) {
         const bool relu = d->conv->relu != 0, bias = d->epilogue == SSL4GIE_EPI_BIAS;
-        if (bias && relu) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_BIAS, 2);
+        if (d->epilogue == SSL4GIE_EPI_RELU_MASK_AUX) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_RELU_MASK_AUX, 1);
+        else if (bias && relu) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_BIAS, 2);
         else if (bias) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_BIAS, 1);
         else if (relu) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_NONE, 2);
         else P_LAUNCH_C(bf16_t, SSL4GIE_EPI_NONE, 1);

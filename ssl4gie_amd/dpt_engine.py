@@ -139,7 +139,9 @@ class Conv3x3Fn(torch.autograd.Function):
                 dy4 = dy.view(B, H, W, Cout)
                 if _IMPLICIT and ld2 == 9 * Cout and _fills_chip(dy4, 1, Cin) and \
                         ops.conv3x3_implicit_ok(dy4, 1, Cin):
-                    dxr = ops.conv3x3_fwd(dy4, wd, None, 1, False)
+                    # the ReLU in front of this convolution masks its data gradient in the epilogue
+                    dxr = ops.conv3x3_fwd(dy4, wd, None, 1, False, relu_mask=x if relu_in else None)
+                    return dxr, rets[0], rets[1], None, None, None, None
                 else:
                     dcols = ops.im2col3x3(dy4, 1, False, ld2)
                     dxr = ops.linear_fwd(dcols, wd, None, out_dtype=dt).view(B, H, W, Cin)

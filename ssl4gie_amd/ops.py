@@ -442,10 +442,12 @@ def _geom(x, stride, relu):
     return g
 
 
-def conv3x3_fwd(x, w2, bias=None, stride=1, relu=False):
+def conv3x3_fwd(x, w2, bias=None, stride=1, relu=False, relu_mask=None):
     """y[(b,oy,ox), co] = sum_k P[(b,oy,ox), k] w2[co, k] (+ bias), P = implicit patch matrix of the
-    bf16 map x [B,H,W,C] (never materialised; ssl4gie_gemm_desc.conv), w2 [Cout, 9C]."""
-    _dev(x, w2, bias)
+    bf16 map x [B,H,W,C] (never materialised; ssl4gie_gemm_desc.conv), w2 [Cout, 9C].
+    `relu_mask` [B,Ho,Wo,Cout]: y = relu_mask > 0 ? y : 0 in the epilogue (the data gradient of a
+    convolution whose input went through a ReLU; no bias, no relu)."""
+    _dev(x, w2, bias, relu_mask)
     B, H, W, Cin = _nhwc(x)
     Cout, K = w2.shape
     assert K == 9 * Cin and w2.dtype == x.dtype and w2.is_contiguous()
@@ -463,6 +465,10 @@ def conv3x3_fwd(x, w2, bias=None, stride=1, relu=False):
         _f32(bias)
         assert bias.numel() == Cout
         d.epilogue, d.bias = _lib.EPI_BIAS, ptr(bias)
+    if relu_mask is not None:
+        assert bias is None and not relu and relu_mask.dtype == x.dtype and relu_mask.is_contiguous() \
+            and relu_mask.numel() == M * Cout
+        d.epilogue, d.aux = _lib.EPI_RELU_MASK_AUX, ptr(relu_mask)
     gemm_raw(d, x.device)
     return y.view(B, Ho, Wo, Cout)
 

@@ -99,6 +99,21 @@ def test_conv3x3_implicit_weight_gradient(B, H, W, Cin, Cout, stride, relu):
     assert torch.equal(dw3, dw2)
 
 
+def test_conv3x3_relu_mask_epilogue():
+    """data gradient of conv(relu(x)): the mask x > 0 applied in the GEMM epilogue"""
+    from ssl4gie_amd import ops
+    x, w, _ = _case(3, 20, 24, 64, 128, 40)           # x: the convolution's input (mask source)
+    dy = torch.randn(3, 20, 24, 128, generator=G(43)).to(BF)
+    wflip = w.flip(2, 3).permute(1, 2, 3, 0).reshape(64, 9 * 128).contiguous()  # [Cin, 9 Cout]
+    xd, dyd, wd = x.to(DEV), dy.to(DEV), wflip.to(DEV)
+    dx = ops.conv3x3_fwd(dyd, wd, None, 1, False, relu_mask=xd).float().cpu()
+    plain = ops.conv3x3_fwd(dyd, wd, None, 1, False).float().cpu()
+    assert torch.equal(dx, torch.where(x.float() > 0, plain, torch.zeros(())))
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    F.conv2d(F.relu(xr), w.float(), None, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    assert rel_err(dx, xr.grad.permute(0, 2, 3, 1)) < 4e-3
+
+
 def test_conv3x3_fn_matches_materialised_path(monkeypatch):
     """Conv3x3Fn forward + backward: implicit path vs SSL4GIE_IMPLICIT_CONV=0 on one layer"""
     from ssl4gie_amd import dpt_engine
