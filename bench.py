@@ -80,6 +80,32 @@ def cpu_baseline(steps=8, warmup=2, b=8):
                       f"CPU oracle (oracle/mae_ref.py), {warmup} warm-up steps"}
 
 
+def timed_steps(step, a, world, dev):
+    """the driver's timing contract: W untimed warm-up steps, then exactly K steps bracketed by a
+    barrier + torch.cuda.synchronize() on both sides; returns (last loss, MAX over ranks of the
+    elapsed seconds)"""
+    import torch.distributed as dist
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return loss, float(tt.item())
+
+
 def bench_depth(a):
     """configs[3]: ViT_from_MAE(dense="depth") + SSI loss + AdamW(1e-4) (train_depth.py:22-78,230,280)
     on synthetic img [B,3,224,224] N(0,1) and depth targets U(0,1) with 10 % zeros."""
@@ -113,23 +139,7 @@ def bench_depth(a):
         opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    loss, dt = timed_steps(step, a, world, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
         print(json.dumps({
@@ -189,23 +199,7 @@ def bench_moco(a):
         opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    loss, dt = timed_steps(step, a, world, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
         print(json.dumps({
@@ -253,23 +247,7 @@ def bench_vit(a):
         opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    loss, dt = timed_steps(step, a, world, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
         print(json.dumps({
@@ -317,23 +295,7 @@ def bench_det(a):
         opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    loss, dt = timed_steps(step, a, world, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
         # GEMM-shaped MACs per image: 12 blocks x 4096 tokens x 12 D^2, windowed attention
@@ -396,23 +358,7 @@ def bench_bt(a):
         opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    loss, dt = timed_steps(step, a, world, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
         # 212.44 GFLOP per image (two views, trunk + projector, fwd+bwd) + the three
@@ -497,23 +443,7 @@ def main():
         opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    loss, dt = timed_steps(step, a, world, dev)
     final_loss = float(loss.detach())
 
     # ---- roofline pass (instrumented; outside the timed region)
