@@ -242,8 +242,8 @@ int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* 
  * on = 0 folds them back onto `stream` (also: environment SSL4GIE_WGRAD_STREAM=0); bench.py does
  * that while it measures per-kernel durations. */
 int ssl4gie_set_wgrad_stream(int on);
-/* Number of CUs the persistent / one-workgroup-per-CU GEMM grids are sized for (8..256, default 256;
- * environment SSL4GIE_COMPUTE_CUS).  The 256x256 kernels hold all 160 KiB of a CU's LDS, so an RCCL
+/* Number of CUs the persistent / one-workgroup-per-CU GEMM grids are sized for (8..256, default 240:
+ * the weight-gradient side stream shares the chip; environment SSL4GIE_COMPUTE_CUS).  The 256x256 kernels hold all 160 KiB of a CU's LDS, so an RCCL
  * kernel running beside them needs CUs of its own: ssl4gie_amd.parallel reserves a few in
  * data-parallel runs (and caps RCCL's channel count to match) so that no GEMM workgroup has to
  * wait for a second wave behind a busy CU. */

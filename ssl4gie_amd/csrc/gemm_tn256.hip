@@ -332,7 +332,18 @@ int ssl4gie_internal_tn256_pair_splits(const ssl4gie_gemm_desc* a, const ssl4gie
     const int tiles = ((a->M + P_BM - 1) / P_BM) * ((a->N + P_BN - 1) / P_BN) +
                       ((b->M + P_BM - 1) / P_BM) * ((b->N + P_BN - 1) / P_BN);
     const int nkt = a->K / P_BK;
-    int s = (ssl4gie_internal_compute_cus() + tiles / 2) / tiles;
+    // SSL4GIE_TN_FILL (percent, default 75): share of the CUs a paired launch aims to fill — on the
+    // weight-gradient side stream fewer, longer workgroups mean less slab traffic (measured:
+    // profiles/r01w_ab_grid_sizing.log)
+    static int fill = -1;
+    if (fill < 0) {
+        const char* e = getenv("SSL4GIE_TN_FILL");
+        fill = e ? atoi(e) : 75;
+        if (fill < 10) fill = 10;
+        if (fill > 200) fill = 200;
+    }
+    const int target = ssl4gie_internal_compute_cus() * fill / 100;
+    int s = (target + tiles / 2) / tiles;
     if (s > nkt / 8) s = nkt / 8;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
