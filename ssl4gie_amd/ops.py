@@ -202,6 +202,33 @@ def linear_bwd_weight(dy2d, x2d, out=None, accumulate=False, bias_out=None):
     return out
 
 
+def linear_bwd_weight_pair(dy_a, x_a, dy_b, x_b, bias_a=None, bias_b=None):
+    """two weight-gradient products with the same token count in ONE launch (ssl4gie_gemm_tn_pair):
+    (dW_a [n_a, k_a], dW_b [n_b, k_b]) = (dy_a^T x_a, dy_b^T x_b); optional fused bias gradients"""
+    _dev(dy_a, x_a, dy_b, x_b, bias_a, bias_b)
+    T = dy_a.shape[0]
+    assert dy_b.shape[0] == T and x_a.shape[0] == T and x_b.shape[0] == T
+    outs, descs = [], []
+    for dy, x, b in ((dy_a, x_a, bias_a), (dy_b, x_b, bias_b)):
+        n_out, k_in = dy.shape[1], x.shape[1]
+        out = torch.empty(n_out, k_in, dtype=torch.float32, device=x.device)
+        d = _desc(n_out, k_in, T, code(dy.dtype), F32)
+        d.A, d.sAm, d.sAk = ptr(dy), 1, n_out
+        d.B, d.sBk, d.sBn = ptr(x), k_in, 1
+        d.C, d.ldc = ptr(out), k_in
+        if b is not None:
+            assert b.dtype == torch.float32 and b.numel() == n_out
+            d.colsum_a = ptr(b)
+        outs.append(out)
+        descs.append(d)
+    L = _lib.load()
+    nbytes = L.ssl4gie_gemm_tn_pair_workspace_bytes(C.byref(descs[0]), C.byref(descs[1]))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy_a.device) if nbytes else None
+    _lib.check(L.ssl4gie_gemm_tn_pair(C.byref(descs[0]), C.byref(descs[1]), ptr(ws), nbytes, stream()),
+               "gemm_tn_pair")
+    return outs[0], outs[1]
+
+
 # ------------------------------------------------------------------ attention
 def attn_fwd(qkv, B, N, H, hd):
     _dev(qkv)

@@ -462,3 +462,41 @@ def test_normalize_u8_matches_totensor_normalize():
     std = torch.tensor(ops.IMAGENET_STD).view(1, 3, 1, 1)
     ref = (img.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
     assert out.shape == ref.shape and rel_err(out, ref) < 1e-6
+
+
+@pytest.mark.parametrize("T,na,ka,nb,kb", [(12800, 768, 3072, 3072, 768), (4096, 512, 512, 1536, 512),
+                                            (1024, 264, 136, 72, 520), (256, 64, 64, 64, 64)])
+def test_weight_gradient_pair_matches_two_products(T, na, ka, nb, kb):
+    """ssl4gie_gemm_tn_pair: two TN products in one split-K launch == the two products alone"""
+    from ssl4gie_amd import ops
+    dya = torch.randn(T, na, generator=G(30)).to(BF).to(DEV)
+    xa = torch.randn(T, ka, generator=G(31)).to(BF).to(DEV)
+    dyb = torch.randn(T, nb, generator=G(32)).to(BF).to(DEV)
+    xb = torch.randn(T, kb, generator=G(33)).to(BF).to(DEV)
+    ba = torch.empty(na, device=DEV)
+    bb = torch.empty(nb, device=DEV)
+    wa, wb = ops.linear_bwd_weight_pair(dya, xa, dyb, xb, ba, bb)
+    assert rel_err(wa, dya.double().t() @ xa.double()) < 1e-5
+    assert rel_err(wb, dyb.double().t() @ xb.double()) < 1e-5
+    assert rel_err(ba, dya.double().sum(0)) < 1e-5 and rel_err(bb, dyb.double().sum(0)) < 1e-5
+    wa2, wb2 = ops.linear_bwd_weight_pair(dya, xa, dyb, xb)  # without the fused bias gradients
+    assert rel_err(wa2, wa) < 1e-6 and rel_err(wb2, wb) < 1e-6
+
+
+def test_compute_cus_setting_changes_grids_not_results():
+    from ssl4gie_amd import _lib, ops
+    L = _lib.load()
+    x = torch.randn(12800, 768, generator=G(40)).to(BF).to(DEV)
+    w = torch.randn(2304, 768, generator=G(41)).to(BF).to(DEV)
+    dy = torch.randn(12800, 2304, generator=G(42)).to(BF).to(DEV)
+    try:
+        outs = []
+        for cus in (256, 200, 64):
+            assert L.ssl4gie_set_compute_cus(cus) == 0
+            outs.append((ops.linear_fwd(x, w).float(), ops.linear_bwd_weight(dy, x)))
+        assert L.ssl4gie_set_compute_cus(4) == 1000 and L.ssl4gie_set_compute_cus(300) == 1000
+    finally:
+        L.ssl4gie_set_compute_cus(240)
+    for y, dw in outs[1:]:
+        assert torch.equal(y, outs[0][0])          # NT: tile assignment changes, arithmetic does not
+        assert rel_err(dw, outs[0][1]) < 2e-5      # TN: split-K boundaries move (fp32 summation order)
