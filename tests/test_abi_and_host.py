@@ -164,3 +164,24 @@ def test_checkpoint_wrappers_round_trip():
     assert set(ck.ddp_unwrap(ddp)) == set(target.state_dict())
     loaded, missing, unexpected = ck.load_matching(target, {**bb, "extra.weight": torch.zeros(1)})
     assert len(loaded) == len(bb) and missing == [] and unexpected == ["extra.weight"]
+
+
+def test_window_permutation_matches_reference_construction_cpu():
+    """perm / inv_perm of WindowedAttention (models.py:179-191) for N = 4096, window 16:
+    integer work, exact — the engine's index construction against the oracle's statement-for-statement
+    restatement, plus the structural properties the detection trunk relies on"""
+    import torch
+    from oracle import det_ref
+    from ssl4gie_amd.Models.models import WINDOWED_BLOCKS, window_permutation
+    for s in (64, 48, 32, 16):
+        perm, inv, windows = det_ref.window_perm(s * s, 16)
+        p2, i2 = window_permutation(s, 16)
+        assert torch.equal(perm, p2) and torch.equal(inv, i2) and windows == (s // 16) ** 2
+        assert torch.equal(perm[inv], torch.arange(s * s)) and torch.equal(inv[perm], torch.arange(s * s))
+        # window w = (wi, wj) occupies the contiguous run [256 w, 256 (w + 1)) in row-major order
+        for w in (0, windows - 1):
+            wi, wj = divmod(w, s // 16)
+            blk = perm[256 * w:256 * (w + 1)].reshape(16, 16)
+            want = (torch.arange(16)[:, None] + 16 * wi) * s + torch.arange(16)[None, :] + 16 * wj
+            assert torch.equal(blk, want)
+    assert WINDOWED_BLOCKS == det_ref.WINDOWED == (0, 1, 3, 4, 6, 7, 9, 10)
