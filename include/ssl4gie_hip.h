@@ -5,10 +5,15 @@
  * `Models/mae/models_mae.py`, `Models/models.py`.  Every entry point below names the reference
  * call site(s) whose arithmetic it replaces.  Conventions:
  *   - plain C types only; device pointers + explicit sizes/strides + a HIP stream (`void*`);
- *   - nothing is allocated, freed or synchronised inside; workspaces are caller-allocated and
- *     sized by the matching `*_workspace_bytes()` query;
+ *   - no per-call allocation, nothing freed, no host synchronisation; workspaces are
+ *     caller-allocated and sized by the matching `*_workspace_bytes()` query.  Three objects are
+ *     created once per device on first use and live as long as the library: the 256-byte zero page
+ *     of the implicit convolution, the weight-gradient side stream + its events
+ *     (ssl4gie_set_wgrad_stream), and — opt-in — the launch profiler (ssl4gie_prof_*);
  *   - returns 0 on success, SSL4GIE_EARG (1000) for an invalid argument, otherwise a hipError_t;
- *   - re-entrant (no mutable globals), callable from any host thread;
+ *   - callable from any host thread; the only mutable process-wide settings are the execution
+ *     options ssl4gie_set_wgrad_stream / ssl4gie_set_compute_cus and the profiler;
+ *   - ssl4gie_abi_version() = 2 (1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`);
  *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
  *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
  */

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ssl4gie_hip.h but not exported"
     assert set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
-    assert _lib.load().ssl4gie_abi_version() == 1
+    assert _lib.load().ssl4gie_abi_version() == 2
 
 
 def test_workspace_queries_need_no_gpu():
