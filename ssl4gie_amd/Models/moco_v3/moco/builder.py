@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ....engine import EngineModule, LinearFn
+from ....engine import EngineModule, LinearFn, bump_weights_epoch
 from ....resnet_engine import BatchNormFn
 from .... import ops
 
@@ -76,6 +76,9 @@ class MoCo(EngineModule):
         m0, m1 = a.span(pm)
         assert b1 - b0 == m1 - m0, "base / momentum encoders must have identical layouts"
         ops.ema_update(a.data[m0:m1], a.data[b0:b1], m)
+        # the kernel writes through raw pointers: torch's version counters do not move, so the
+        # operand caches (bf16 weight copies) are invalidated through the engine's epoch instead
+        bump_weights_epoch()
 
     def contrastive_loss(self, q, k):
         import torch.distributed as dist

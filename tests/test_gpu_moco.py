@@ -112,3 +112,26 @@ def test_moco_resnet_step_vs_oracle():
         else:
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
     assert int(m.base_encoder.bn1.num_batches_tracked) == 2 and int(m.momentum_encoder.bn1.num_batches_tracked) == 2
+
+
+def test_momentum_encoder_uses_updated_weights_after_ema():
+    """the EMA kernel writes parameters through raw pointers: the bf16 operand copies of the momentum
+    encoder must be refreshed (weights epoch), or it would keep computing keys with its first weights"""
+    m = _moco().to(DEV).set_precision("bf16")
+    g = torch.Generator().manual_seed(7)
+    x1 = torch.randn(4, 3, 64, 64, generator=g).to(DEV)
+    x2 = torch.randn(4, 3, 64, 64, generator=g).to(DEV)
+    m(x1, x2, 0.99)                       # first forward: operand copies of both encoders are cached
+    with torch.no_grad():
+        for p in m.base_encoder.parameters():
+            p.mul_(1.5)                   # a (drastic) optimizer step on the base encoder
+        m.eval()                          # BatchNorm in eval mode: outputs depend on weights only
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.running_mean.zero_()
+                mod.running_var.fill_(1.0)
+        m._prepare()
+        m._update_momentum_encoder(0.0)   # momentum <- base exactly
+        kb = m.encode(m.base_encoder, x1)
+        km = m.encode(m.momentum_encoder, x1)
+    assert rel_err(km, kb) < 1e-6
