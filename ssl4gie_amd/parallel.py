@@ -59,6 +59,11 @@ class DataParallel:
                 _lib.check(_lib.load().ssl4gie_set_compute_cus(256 - r), "set_compute_cus")
         if broadcast_parameters and self.world > 1:
             dist.broadcast(self._arena.data, src=0, group=process_group)
+            try:  # the flat buffer was written, not the parameter views: refresh operand caches
+                from .engine import bump_weights_epoch
+                bump_weights_epoch()
+            except ImportError:  # toy models of the CPU tests do not load the engine
+                pass
         model._grad_hook = self._on_module_grads if overlap else None
 
     # the model is used exactly like the wrapped module
