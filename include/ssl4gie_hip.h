@@ -121,6 +121,11 @@ typedef struct ssl4gie_gemm_desc {
     /* optional: the K-major operand (A of an NT product, B of a TN product) is the implicit 3x3
      * patch matrix of this map instead of a matrix in memory (see ssl4gie_conv3x3_geom) */
     const ssl4gie_conv3x3_geom* conv;
+    /* optional fp32 [ceil(M / 128)][2][N]: per 128-row block, the column sums ([0]) and sums of
+     * squares ([1]) of the STORED outputs — the batch statistics of the BatchNorm that follows a
+     * convolution, produced by the GEMM's epilogue (see ssl4gie_bn_fwd_partials).  NT products with
+     * bf16 C, EPI_NONE, no accumulate, N % 8 == 0 only; anything else is SSL4GIE_EARG. */
+    float* colstats;
 } ssl4gie_gemm_desc;
 size_t ssl4gie_gemm_workspace_bytes(const ssl4gie_gemm_desc* d);
 int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t workspace_bytes,
@@ -344,6 +349,16 @@ int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x, const flo
 int ssl4gie_ema_update(float* dst, const float* src, float m, long long n, void* stream);
 /* MaxPool2d(3, stride 2, pad 1) with the argmax window position saved (first maximum in row-major
  * scan order); backward in gather form.  Global average pool -> fp32 [B, C] and its gradient. */
+/* The same forward / SyncBatchNorm statistics with the batch statistics taken from per-128-row
+ * partial sums `partial` [parts][2][C] written by the producing GEMM (ssl4gie_gemm_desc::colstats)
+ * instead of a pass over x.  workspace: ssl4gie_bn_workspace_bytes(rows, C). */
+int ssl4gie_bn_fwd_partials(const void* x, const float* partial, int parts, const float* gamma,
+                            const float* beta, const void* res, void* y, float* mean, float* rstd,
+                            float* running_mean, float* running_var, float momentum, float eps,
+                            int relu, float* workspace, int dtype, long long rows, int C,
+                            void* stream);
+int ssl4gie_bn_stats_partials(const float* partial, int parts, float* mean, float* var,
+                              float* workspace, long long rows, int C, void* stream);
 int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* arg, int dtype, int B, int H,
                              int W, int C, void* stream);
 int ssl4gie_maxpool3x3s2_bwd(const void* dy, const unsigned char* arg, void* dx, int dtype, int B,

@@ -106,19 +106,27 @@ class DPT_decoder(EngineModule):
         return Conv3x3Fn.apply(x, conv.weight, conv.bias, conv.stride[0], relu_in, self.sink(),
                                self.lp_cache)
 
-    def _bn(self, x, bn, relu=False, res=None):
+    def _c3_stats(self, x, conv: nn.Conv2d, relu_in=False):
+        """bias-free convolution in front of a BatchNorm: (map, partial batch statistics or None)"""
+        return Conv3x3Fn.apply(x, conv.weight, conv.bias, conv.stride[0], relu_in, self.sink(),
+                               self.lp_cache, True)
+
+    def _bn(self, x, bn, relu=False, res=None, stats=None):
         """BatchNorm2d over the rows of a channels-last map (+ residual) (+ ReLU)"""
         shp = x.shape
         C = shp[-1]
         r2 = res.contiguous().view(-1, C) if res is not None else None
-        y = BatchNormFn.apply(x.contiguous().view(-1, C), bn.weight, bn.bias, r2, bn, relu, self.sink())
+        y = BatchNormFn.apply(x.contiguous().view(-1, C), bn.weight, bn.bias, r2, bn, relu, self.sink(),
+                              stats)
         return y.view(shp)
 
     def _rcu(self, x, rcu: _RCU):
         """out = [bn2](conv2(relu([bn1](conv1(relu(x)))))) + x  (reference :212-233)"""
         if rcu.bn:
-            out = self._bn(self._c3(x, rcu.conv1, relu_in=True), rcu.bn1, relu=True)
-            return self._bn(self._c3(out, rcu.conv2), rcu.bn2, res=x)  # the skip add rides on bn2
+            out, st = self._c3_stats(x, rcu.conv1, relu_in=True)
+            out = self._bn(out, rcu.bn1, relu=True, stats=st)
+            out, st = self._c3_stats(out, rcu.conv2)
+            return self._bn(out, rcu.bn2, res=x, stats=st)  # the skip add rides on bn2
         out = self._c3(x, rcu.conv1, relu_in=True)
         out = self._c3(out, rcu.conv2, relu_in=True)
         return AddFn.apply(out, x)
@@ -159,7 +167,8 @@ class DPT_decoder(EngineModule):
         p1 = self._fusion(self.refinenet1, p2, l1)
         oc = self.output_conv
         if self.dense == "seg":
-            h = self._bn(self._c3(p1, oc[0]), oc[1], relu=True)
+            h, st = self._c3_stats(p1, oc[0])
+            h = self._bn(h, oc[1], relu=True, stats=st)
             h = nn.functional.dropout(h, oc[3].p, self.training)
             return SegHeadFn.apply(h, oc[4].weight, oc[4].bias, self.sink(), self.lp_cache)
         h = self._c3(p1, oc[0])

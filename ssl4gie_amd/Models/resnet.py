@@ -14,7 +14,12 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+import os
+
 from ..dpt_engine import Conv3x3Fn
+
+# SSL4GIE_BN_STATS_FUSED=0: BatchNorm statistics by their own pass over the map (A/B measurements)
+_BN_STATS = os.environ.get("SSL4GIE_BN_STATS_FUSED", "1") != "0"
 from ..engine import EngineModule, LinearFn
 from ..resnet_engine import AvgPoolFn, BatchNormFn, MaxPoolFn, StemConvFn, Subsample2Fn
 
@@ -75,27 +80,34 @@ class ResNet50(EngineModule):
         return nn.Sequential(*layers)
 
     # ------------------------------------------------------------------ engine forward
-    def _bn(self, x, bn, relu, res=None):
-        return BatchNormFn.apply(x, bn.weight, bn.bias, res, bn, relu, self.sink())
+    def _bn(self, x, bn, relu, res=None, stats=None):
+        return BatchNormFn.apply(x, bn.weight, bn.bias, res, bn, relu, self.sink(), stats)
 
     def _c1(self, x, conv):
+        """1x1 convolution -> (map, BatchNorm partial statistics of the map or None)"""
         if conv.stride[0] == 2:
             x = Subsample2Fn.apply(x)
         B, H, W, C = x.shape
-        y = LinearFn.apply(x.reshape(-1, C), conv.weight, None, self.dtype_, self.dtype_, self.sink(),
-                           self.lp_cache)
-        return y.view(B, H, W, -1)
+        r = LinearFn.apply(x.reshape(-1, C), conv.weight, None, self.dtype_, self.dtype_, self.sink(),
+                           self.lp_cache, _BN_STATS)
+        y, st = r if _BN_STATS else (r, None)
+        return y.view(B, H, W, -1), st
 
     def _block(self, x, blk: Bottleneck):
-        out = self._bn(self._c1(x, blk.conv1), blk.bn1, True)
-        out = Conv3x3Fn.apply(out, blk.conv2.weight, None, blk.conv2.stride[0], False, self.sink(),
-                              self.lp_cache)
-        out = self._bn(out, blk.bn2, True)
-        out = self._c1(out, blk.conv3)
+        # every convolution hands the batch statistics of its output to the BatchNorm that follows
+        # (column sums from the GEMM epilogue): no separate statistics pass over the maps
+        out, st = self._c1(x, blk.conv1)
+        out = self._bn(out, blk.bn1, True, stats=st)
+        r = Conv3x3Fn.apply(out, blk.conv2.weight, None, blk.conv2.stride[0], False, self.sink(),
+                            self.lp_cache, _BN_STATS)
+        out, st = r if _BN_STATS else (r, None)
+        out = self._bn(out, blk.bn2, True, stats=st)
+        out, st = self._c1(out, blk.conv3)
         identity = x
         if blk.downsample is not None:
-            identity = self._bn(self._c1(x, blk.downsample[0]), blk.downsample[1], False)
-        return self._bn(out, blk.bn3, True, res=identity)  # relu(bn3(out) + identity)
+            idn, sti = self._c1(x, blk.downsample[0])
+            identity = self._bn(idn, blk.downsample[1], False, stats=sti)
+        return self._bn(out, blk.bn3, True, res=identity, stats=st)  # relu(bn3(out) + identity)
 
     def forward_maps(self, imgs, all_stages=False):
         self._prepare()

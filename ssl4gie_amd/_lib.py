@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("dtype_ab", i32), ("dtype_c", i32), ("alpha", f32), ("epilogue", i32),
         ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("out2", vp),
         ("accumulate", i32), ("colsum_a", vp), ("conv", C.POINTER(Conv3x3Geom)),
+        ("colstats", vp),
     ]
 
 
@@ -108,6 +109,9 @@ PROTOTYPES = {
     "ssl4gie_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_bn_fwd_partials": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, i64,
+                                      i32, vp]),
+    "ssl4gie_bn_stats_partials": (i32, [vp, i32, vp, vp, vp, i64, i32, vp]),
     "ssl4gie_adamw_arena": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, i64, vp]),
     "ssl4gie_lars_workspace_bytes": (sz, [i32]),
     "ssl4gie_lars_arena": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, i64, vp]),

@@ -851,9 +851,10 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate};
 
     REQUIRE(!d->conv || (d->dtype_ab == SSL4GIE_BF16 && d->batch1 * d->batch2 == 1));
+    REQUIRE(!d->colstats || (d->dtype_ab == SSL4GIE_BF16 && d->batch1 * d->batch2 == 1));
     if (nt_ok(d)) {
         if (ssl4gie_internal_nt256_ok(d)) return ssl4gie_internal_nt256_launch(d, st);
-        REQUIRE(!d->conv);  // the gathered operand only exists in the 256x256 kernels
+        REQUIRE(!d->conv && !d->colstats);  // these only exist in the 256x256 kernels
         const int tm = (d->M + BT_M - 1) / BT_M, tn = (d->N + BT_N - 1) / BT_N;
         const int ntiles = tm * tn;
         const int max_wgs = 2 * ssl4gie_internal_compute_cus();  // 2 workgroups per CU
@@ -884,6 +885,7 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
         const TnPlan p = tn_plan(d);
         const int splits = p.splits;
         REQUIRE(!d->conv || p.big);
+        REQUIRE(!d->colstats);
         REQUIRE(p.total == 0 || (workspace && workspace_bytes >= p.total));
         float* slabs = (float*)workspace;
         float* cs_ws = p.cs_bytes ? (float*)((char*)workspace + p.cs_off) : nullptr;
@@ -917,7 +919,7 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
         return 0;
     }
     // generic
-    REQUIRE(!d->conv);
+    REQUIRE(!d->conv && !d->colstats);
     GemmArgs g;
     g.M = d->M; g.N = d->N; g.K = d->K; g.batch2 = d->batch2;
     g.A = d->A; g.sAm = d->sAm; g.sAk = d->sAk; g.sAb1 = d->sAb1; g.sAb2 = d->sAb2;

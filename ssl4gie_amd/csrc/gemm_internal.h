@@ -12,6 +12,7 @@ struct EpiArgs {
     const void* aux;
     void* out2;
     int accumulate;
+    float* colstats;  // optional (256x256 NT kernel, bf16 C, EPI_NONE): see ssl4gie_gemm_desc::colstats
 };
 
 // Implicit 3x3 / pad-1 patch-matrix operand (ssl4gie_gemm_desc::conv): device-side geometry with

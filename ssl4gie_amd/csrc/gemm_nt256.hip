@@ -47,12 +47,15 @@
 
 // ---- epilogue of one wave's 128 x 64 sub-tile ---------------------------------------------------
 // acc[mt][nt]: rows rbase + 16 mt + (l & 15), columns cbase + 16 nt + 4 (l >> 4) + 0..3
-template <typename TC, int MODE, bool FULL>
+// STATS (bf16 C, plain epilogue): per-column sums and sums of squares of the STORED (bf16-rounded)
+// values over the wave's 128 rows -> colstats[(rbase / 128)][{0,1}][N]: the BatchNorm statistics of
+// the layer that follows ride on the producing GEMM instead of costing a pass over the activation.
+template <typename TC, int MODE, bool FULL, bool STATS>
 DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                      const float* __restrict__ bias, const float* __restrict__ residual,
                      const long long ldr, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out2,
                      const int accumulate, TC* __restrict__ C, long long ldc, int rbase, int cbase,
-                     int M, int N, int lane) {
+                     int M, int N, int lane, float* __restrict__ colstats) {
     const int r16 = lane & 15, g4 = lane >> 4;
     f32x4 bias4[4];
 #pragma unroll
@@ -79,13 +82,28 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
             const int c = nt * 2 + (g4 >> 1);
             *(u32x2*)(stg + base + r16 * 128 + ((c ^ (r16 & 7)) << 4) + ((g4 & 1) << 3)) = pk;
         };
+        float cs[8], cq[8];  // STATS: this lane's 8 columns, summed over the rows it flushes
+        if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
+        }
         auto flush = [&](int base, bf16_t* __restrict__ dst, int mt) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int R = R0 + 8 * hh;
                 const u32x4 w = *(const u32x4*)(stg + base + R * 128 + ((Cc ^ (R & 7)) << 4));
                 const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
-                if (FULL || (gm < M && gn < N)) *(u32x4*)(dst + (size_t)gm * ldc + gn) = w;
+                if (FULL || (gm < M && gn < N)) {
+                    *(u32x4*)(dst + (size_t)gm * ldc + gn) = w;
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+                            cs[2 * j] += lo; cq[2 * j] += lo * lo;
+                            cs[2 * j + 1] += hi; cq[2 * j + 1] += hi * hi;
+                        }
+                    }
+                }
             }
         };
 #pragma unroll
@@ -119,6 +137,25 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
             if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD || MODE == SSL4GIE_EPI_BIAS_GELU)
                 flush(2048, out2, mt);
         }
+        if constexpr (STATS) {
+            // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row groups
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    cs[j] += __shfl_xor(cs[j], o, 64);
+                    cq[j] += __shfl_xor(cq[j], o, 64);
+                }
+            const int gn = cbase + 8 * Cc;
+            // a 128-row block that starts past M has no row in colstats (ceil(M / 128) blocks)
+            if (lane < 8 && (FULL || (gn < N && rbase < M))) {
+                float* p = colstats + (size_t)(rbase >> 7) * 2 * N + gn;
+                st4(p, f32x4{cs[0], cs[1], cs[2], cs[3]});
+                st4(p + 4, f32x4{cs[4], cs[5], cs[6], cs[7]});
+                st4(p + N, f32x4{cq[0], cq[1], cq[2], cq[3]});
+                st4(p + N + 4, f32x4{cq[4], cq[5], cq[6], cq[7]});
+            }
+        }
     } else {
         p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL>(
             acc, stg, alpha, bias4, residual, ldr, MODE == SSL4GIE_EPI_NONE && accumulate, (float*)C,
@@ -128,7 +165,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
 
 // CONV: 0 = A is a matrix; 1 = A is the implicit 3x3 patch matrix of the map at `A` (geometry cg,
 // header of ssl4gie_conv3x3_geom); 2 = the same with ReLU applied to the A fragments.
-template <typename TC, int MODE, int CONV>
+template <typename TC, int MODE, int CONV, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
     TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e,
@@ -151,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const bf16_t* e_aux = (const bf16_t*)e.aux;
     bf16_t* e_out2 = (bf16_t*)e.out2;
     const int e_accumulate = e.accumulate;
+    float* e_colstats = e.colstats;
 
     // ------------------------------------------------------------------ LDS-DMA stream state
     // this lane's source byte offsets: v<item>_<piece> for the 4 half-tiles x 2 pieces (named
@@ -361,13 +399,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             if (dbg_skip_epilogue) {
                 asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[7][3][3]));
             } else if (m0 + P_BM <= M && n0 + P_BN <= N)
-                p_epilogue<TC, MODE, true>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
-                                           e_out2, e_accumulate, C, ldc, m0 + wr * 128,
-                                           n0 + wc * 64, M, N, lane);
+                p_epilogue<TC, MODE, true, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                                                  e_out2, e_accumulate, C, ldc, m0 + wr * 128,
+                                                  n0 + wc * 64, M, N, lane, e_colstats);
             else
-                p_epilogue<TC, MODE, false>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
-                                            e_out2, e_accumulate, C, ldc, m0 + wr * 128,
-                                            n0 + wc * 64, M, N, lane);
+                p_epilogue<TC, MODE, false, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                                                   e_out2, e_accumulate, C, ldc, m0 + wr * 128,
+                                                   n0 + wc * 64, M, N, lane, e_colstats);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -401,6 +439,9 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
         return false;
     if (d->K % P_BK != 0 || d->N % 8 != 0 || d->ldc % 8 != 0) return false;
     const int ep = d->epilogue;
+    if (d->colstats && !(d->dtype_c == SSL4GIE_BF16 && ep == SSL4GIE_EPI_NONE && !d->accumulate &&
+                         d->N % 8 == 0))
+        return false;
     if (d->conv)  // gathered A: bf16 outputs with bias / plain only, whole K-tiles inside a tap
         return ssl4gie_internal_conv_geom_ok(d->conv) && d->conv->C % P_BK == 0 &&
                d->K == 9 * d->conv->C && (long long)d->M == conv_rows(d->conv) &&
@@ -414,7 +455,7 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
             ep == SSL4GIE_EPI_BIAS_GELU_GRAD || ep == SSL4GIE_EPI_MUL_AUX || ep == SSL4GIE_EPI_RELU_MASK_AUX)
             return false;
     }
-    if (mode == 1) return true;
+    if (mode == 1 || d->colstats) return true;  // the statistics only exist in this kernel
     // heuristic: enough 256x256 tiles to fill most of the chip
     const long long tiles = (long long)((d->M + P_BM - 1) / P_BM) * ((d->N + P_BN - 1) / P_BN);
     return tiles >= 128;
@@ -425,7 +466,8 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     const int ntiles = tm * tn;
     const int cus = ssl4gie_internal_compute_cus();
     dim3 grid(ntiles < cus ? ntiles : cus), block(512);
-    EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate};
+    EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate,
+              d->colstats};
     static int skip_epi = -1;  // SSL4GIE_NT256_NOEPI=1: ablation (K-loop only; outputs are garbage)
     if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] == '1') ? 1 : 0; }
     ConvK ck{};
@@ -435,9 +477,10 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     }
     ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
 #define P_LAUNCH(TC_, MODE_) P_LAUNCH_C(TC_, MODE_, 0)
-#define P_LAUNCH_C(TC_, MODE_, CONV_)                                                              \
+#define P_LAUNCH_C(TC_, MODE_, CONV_) P_LAUNCH_S(TC_, MODE_, CONV_, false)
+#define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_)                                                      \
     do {                                                                                           \
-        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_>;                                      \
+        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_>;                              \
         static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
         if (!attr_set) {                                                                           \
             HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
@@ -448,7 +491,12 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
                            (const bf16_t*)d->B, d->sBn, (TC_*)d->C, d->ldc, d->M, d->N, d->K, tn,  \
                            ntiles, e, skip_epi, ck);                                                \
     } while (0)
-    if (d->conv) {
+    if (d->colstats) {  // bf16, plain epilogue (checked by nt256_ok)
+        const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
+        if (cv == 0) P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 0, true);
+        else if (cv == 1) P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 1, true);
+        else P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 2, true);
+    } else if (d->conv) {
         const bool relu = d->conv->relu != 0, bias = d->epilogue == SSL4GIE_EPI_BIAS;
         if (d->epilogue == SSL4GIE_EPI_RELU_MASK_AUX) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_RELU_MASK_AUX, 1);
         else if (bias && relu) P_LAUNCH_C(bf16_t, SSL4GIE_EPI_BIAS, 2);
@@ -475,6 +523,7 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     }
 #undef P_LAUNCH
 #undef P_LAUNCH_C
+#undef P_LAUNCH_S
     LAUNCH_CHECK();
     return 0;
 }

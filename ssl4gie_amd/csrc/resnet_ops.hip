@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void bn_fwd_tail_kernel(
     const float d = s / count;
     float var = q / count - d * d;
     var = var > 0.f ? var : 0.f;
-    const float m = pivot[c] + d, r = rsqrtf(var + eps);
+    const float m = (pivot ? pivot[c] : 0.f) + d, r = rsqrtf(var + eps);
     mean[c] = m;
     rstd[c] = r;
     if (running_mean) {
@@ -646,7 +646,9 @@ extern "C" int ssl4gie_subsample2(const void* x, void* y, int dtype, int B, int 
     return 0;
 }
 extern "C" size_t ssl4gie_bn_workspace_bytes(long long rows, int C) {
-    return (((size_t)bn_parts(rows, C) + 1) * 2 + 1 + 3) * C * sizeof(float);  // partials, sums, pivot, coef
+    size_t parts = (size_t)bn_parts(rows, C);
+    if (parts < 64) parts = 64;  // the partials paths fold into 64 x 2C floats of this workspace
+    return ((parts + 1) * 2 + 1 + 3) * C * sizeof(float);  // coef, partials, sums, pivot
 }
 // forward: statistics over the rows of x [rows, C] (biased variance), optional running-stat update,
 // y = act(xhat gamma + beta (+ res)); mean / rstd [C] are kept for backward
@@ -797,7 +799,7 @@ __global__ void bn_local_stats_kernel(const float* __restrict__ sums, const floa
     if (c >= C) return;
     const float d = sums[c] / count;
     const float v = sums[C + c] / count - d * d;
-    mean[c] = pivot[c] + d;
+    mean[c] = (pivot ? pivot[c] : 0.f) + d;
     var[c] = v > 0.f ? v : 0.f;
 }
 extern "C" int ssl4gie_bn_stats(const void* x, float* mean, float* var, float* workspace, int dtype,
@@ -820,6 +822,82 @@ extern "C" int ssl4gie_bn_stats(const void* x, float* mean, float* var, float* w
     if (rc) return rc;
     hipLaunchKernelGGL(bn_local_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, pivot,
                        mean, var, (float)rows, C);
+    LAUNCH_CHECK();
+    return 0;
+}
+// ---- statistics that arrive as per-128-row partials from the producing GEMM's epilogue
+// (ssl4gie_gemm_desc::colstats: [parts][2][C], sums about 0): many partials (12 544 for the stem
+// map of a 512-image batch) are first folded to 64 by a wide grid, then finished by the tail kernel
+#define BN_FOLD 64
+__global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ pin, int parts,
+                                                               float* __restrict__ pout, int C) {
+    __shared__ float red[3][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, k = blockIdx.y;
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        for (int p = k + BN_FOLD * wave; p < parts; p += BN_FOLD * 4) {
+            s += pin[(size_t)p * 2 * C + c];
+            q += pin[(size_t)p * 2 * C + C + c];
+        }
+    }
+    if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
+        pout[(size_t)k * 2 * C + c] = s;
+        pout[(size_t)k * 2 * C + C + c] = q;
+    }
+}
+// -> (partials to hand to the tail kernels, their count); `scratch` holds BN_FOLD x 2C floats
+static int bn_fold(const float* partial, int parts, float* scratch, int C, hipStream_t st,
+                   const float** out, int* nout) {
+    if (parts <= 4 * BN_FOLD) { *out = partial; *nout = parts; return 0; }
+    hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + 63) / 64, BN_FOLD), dim3(256), 0, st, partial,
+                       parts, scratch, C);
+    LAUNCH_CHECK();
+    *out = scratch; *nout = BN_FOLD;
+    return 0;
+}
+// training-mode forward with the statistics taken from `partial` [parts][2][C] instead of a pass
+// over x; everything else as ssl4gie_bn_fwd.  workspace: ssl4gie_bn_workspace_bytes(rows, C).
+extern "C" int ssl4gie_bn_fwd_partials(const void* x, const float* partial, int parts, const float* gamma,
+                                       const float* beta, const void* res, void* y, float* mean,
+                                       float* rstd, float* running_mean, float* running_var,
+                                       float momentum, float eps, int relu, float* workspace, int dtype,
+                                       long long rows, int C, void* stream) {
+    REQUIRE(x && partial && parts > 0 && y && mean && rstd && workspace && rdt(dtype) && rows > 0 &&
+            C > 0 && C % 8 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = workspace;
+    float* scratch = workspace + 3 * (size_t)C;  // >= BN_FOLD x 2C floats by construction of the size
+    const float* pp; int np;
+    int rc = bn_fold(partial, parts, scratch, C, st, &pp, &np);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_fwd_tail_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pp, np,
+                       (const float*)nullptr, gamma, beta, mean, rstd, running_mean, running_var, coef,
+                       (float)rows, eps, momentum, C);
+    LAUNCH_CHECK();
+    const long long total = rows * C;
+    RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, coef, (const T*)res, (T*)y, relu,
+              C, total);
+    return 0;
+}
+// SyncBatchNorm's local (mean, biased var) from the same partials
+extern "C" int ssl4gie_bn_stats_partials(const float* partial, int parts, float* mean, float* var,
+                                         float* workspace, long long rows, int C, void* stream) {
+    REQUIRE(partial && parts > 0 && mean && var && workspace && rows > 0 && C > 0 && C % 8 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    float* scratch = workspace + 3 * (size_t)C;
+    float* sums = scratch + (size_t)BN_FOLD * 2 * C;
+    const float* pp; int np;
+    int rc = bn_fold(partial, parts, scratch, C, st, &pp, &np);
+    if (rc) return rc;
+    rc = ssl4gie_internal_reduce_partials(pp, sums, np, 2 * C, (size_t)2 * C, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_local_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums,
+                       (const float*)nullptr, mean, var, (float)rows, C);
     LAUNCH_CHECK();
     return 0;
 }

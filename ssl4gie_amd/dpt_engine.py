@@ -88,7 +88,8 @@ class Conv3x3Fn(torch.autograd.Function):
     act_postprocess42.1 :397-403)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, relu_in, sink: GradSink, lp: LPCache):
+    def forward(ctx, x, weight, bias, stride, relu_in, sink: GradSink, lp: LPCache, want_stats=False):
+        """want_stats: also return BatchNorm partial statistics of y (see engine.LinearFn) or None"""
         B, H, W, Cin = x.shape
         Cout = weight.shape[0]
         dt = x.dtype
@@ -99,16 +100,26 @@ class Conv3x3Fn(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (stride, relu_in, sink, lp, ld)
-        if _IMPLICIT and ld == 9 * Cin and _fills_chip(x, stride, Cout) and \
-                ops.conv3x3_implicit_ok(x, stride, Cout):
-            return ops.conv3x3_fwd(x, w2, b, stride, relu_in)  # patch matrix gathered in the GEMM
-        cols = ops.im2col3x3(x, stride, relu_in, ld)
-        y = ops.linear_fwd(cols, w2, b, out_dtype=dt)
+        implicit = _IMPLICIT and ld == 9 * Cin and ops.conv3x3_implicit_ok(x, stride, Cout)
         Ho, Wo = ops.conv_out_hw(H, W, stride)
-        return y.view(B, Ho, Wo, Cout)
+        stats = None
+        if want_stats and b is None and dt == torch.bfloat16 and Cout % 8 == 0 and ld % 64 == 0:
+            # the statistics only exist in the 256x256 kernel: taken whatever the tile count
+            if implicit:
+                y, stats = ops.conv3x3_fwd(x, w2, None, stride, relu_in, colstats=True)
+            else:
+                y, stats = ops.linear_fwd(ops.im2col3x3(x, stride, relu_in, ld), w2, None, out_dtype=dt,
+                                          colstats=True)
+                y = y.view(B, Ho, Wo, Cout)
+            ctx.mark_non_differentiable(stats)
+        elif implicit and _fills_chip(x, stride, Cout):
+            y = ops.conv3x3_fwd(x, w2, b, stride, relu_in)  # patch matrix gathered in the GEMM
+        else:
+            y = ops.linear_fwd(ops.im2col3x3(x, stride, relu_in, ld), w2, b, out_dtype=dt).view(B, Ho, Wo, Cout)
+        return (y, stats) if want_stats else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x, weight, bias = ctx.saved_tensors
         stride, relu_in, sink, lp, ld = ctx.cfg
         B, H, W, Cin = x.shape
@@ -141,7 +152,7 @@ class Conv3x3Fn(torch.autograd.Function):
                         ops.conv3x3_implicit_ok(dy4, 1, Cin):
                     # the ReLU in front of this convolution masks its data gradient in the epilogue
                     dxr = ops.conv3x3_fwd(dy4, wd, None, 1, False, relu_mask=x if relu_in else None)
-                    return dxr, rets[0], rets[1], None, None, None, None
+                    return dxr, rets[0], rets[1], None, None, None, None, None
                 else:
                     dcols = ops.im2col3x3(dy4, 1, False, ld2)
                     dxr = ops.linear_fwd(dcols, wd, None, out_dtype=dt).view(B, H, W, Cin)
@@ -153,7 +164,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 dcols = ops.linear_bwd_data(dy2, w2, w2t)  # [M_out, ld]
                 dxr = ops.col2im3x3(dcols, B, H, W, Cin, stride)
             dx = ops.relu_bwd(x, dxr) if relu_in else dxr
-        return dx, rets[0], rets[1], None, None, None, None
+        return dx, rets[0], rets[1], None, None, None, None, None
 
 
 class ConvTransposeFn(torch.autograd.Function):

@@ -364,18 +364,29 @@ class LinearFn(torch.autograd.Function):
     """y = x W^T + b on operand-type activations; y in `out_dtype`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, dtype, out_dtype, sink, lp):
+    def forward(ctx, x, weight, bias, dtype, out_dtype, sink, lp, want_stats=False):
+        """want_stats: also return the per-128-row column sums / sums of squares of y (fp32
+        [parts, 2, n_out], not differentiable) for the BatchNorm that follows — or None when the
+        GEMM cannot produce them (ops.colstats_ok)"""
         shp = x.shape
         x2 = x.contiguous().view(-1, shp[-1])
         assert x2.dtype == dtype
         w, wt = lp.get(weight, dtype)
-        y = ops.linear_fwd(x2, w, bias.detach() if bias is not None else None, out_dtype=out_dtype)
         ctx.save_for_backward(x2, weight, bias)
         ctx.wlp, ctx.wt, ctx.sink, ctx.dtype, ctx.shp = w, wt, sink, dtype, shp
+        if want_stats:
+            stats = None
+            if bias is None and out_dtype == dtype and ops.colstats_ok(x2.shape[0], w.shape[0], w.shape[1], dtype):
+                y, stats = ops.linear_fwd(x2, w, None, out_dtype=out_dtype, colstats=True)
+                ctx.mark_non_differentiable(stats)
+            else:
+                y = ops.linear_fwd(x2, w, bias.detach() if bias is not None else None, out_dtype=out_dtype)
+            return y.view(*shp[:-1], w.shape[0]), stats
+        y = ops.linear_fwd(x2, w, bias.detach() if bias is not None else None, out_dtype=out_dtype)
         return y.view(*shp[:-1], w.shape[0])
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x2, weight, bias = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
         if dy2.dtype != ctx.dtype:  # fp32 output (decoder_pred): operand copy for the GEMMs
@@ -388,7 +399,7 @@ class LinearFn(torch.autograd.Function):
             ops.linear_bwd_weight(dy2, x2, out=tw, accumulate=acc, bias_out=tb)
         elif tb is not None:
             ops.colsum(dy2, out=tb, accumulate=acc)
-        return dx, rets[0], rets[1], None, None, None, None
+        return dx, rets[0], rets[1], None, None, None, None, None
 
 
 class PatchEmbedFn(torch.autograd.Function):

@@ -121,8 +121,15 @@ def _desc(M, N, K, dt_ab, dt_c):
     return d
 
 
-def linear_fwd(x2d, w, bias=None, out_dtype=None, epilogue=None, residual=None):
-    """y[T, n_out] = x2d[T, k_in] @ w[n_out, k_in]^T (+bias | +bias+residual | gelu pair)."""
+def colstats_ok(T, n_out, k_in, dtype):
+    """whether the producing GEMM can emit BatchNorm partial statistics (256x256 NT kernel rules)"""
+    return dtype == torch.bfloat16 and k_in % 64 == 0 and n_out % 8 == 0 and T > 0
+
+
+def linear_fwd(x2d, w, bias=None, out_dtype=None, epilogue=None, residual=None, colstats=False):
+    """y[T, n_out] = x2d[T, k_in] @ w[n_out, k_in]^T (+bias | +bias+residual | gelu pair).
+    colstats=True (bf16, no bias): also returns the per-128-row column sums / sums of squares of y
+    ([ceil(T/128), 2, n_out] fp32) for the BatchNorm that follows."""
     _dev(x2d, w, bias, residual)
     T, k_in = x2d.shape
     n_out, k2 = w.shape
@@ -148,6 +155,12 @@ def linear_fwd(x2d, w, bias=None, out_dtype=None, epilogue=None, residual=None):
     if epilogue in (_lib.EPI_BIAS_GELU, _lib.EPI_BIAS_GELU_GRAD):
         out2 = torch.empty_like(y)  # (u, gelu(u)) resp. (gelu'(u), gelu(u))
         d.out2 = ptr(out2)
+    if colstats:
+        assert bias is None and epilogue == _lib.EPI_NONE and colstats_ok(T, n_out, k_in, x2d.dtype)
+        stats = torch.empty((T + 127) // 128, 2, n_out, dtype=torch.float32, device=x2d.device)
+        d.colstats = ptr(stats)
+        gemm_raw(d, x2d.device)
+        return y, stats
     gemm_raw(d, x2d.device)
     return (y, out2) if out2 is not None else y
 
@@ -469,7 +482,7 @@ def _geom(x, stride, relu):
     return g
 
 
-def conv3x3_fwd(x, w2, bias=None, stride=1, relu=False, relu_mask=None):
+def conv3x3_fwd(x, w2, bias=None, stride=1, relu=False, relu_mask=None, colstats=False):
     """y[(b,oy,ox), co] = sum_k P[(b,oy,ox), k] w2[co, k] (+ bias), P = implicit patch matrix of the
     bf16 map x [B,H,W,C] (never materialised; ssl4gie_gemm_desc.conv), w2 [Cout, 9C].
     `relu_mask` [B,Ho,Wo,Cout]: y = relu_mask > 0 ? y : 0 in the epilogue (the data gradient of a
@@ -496,6 +509,12 @@ def conv3x3_fwd(x, w2, bias=None, stride=1, relu=False, relu_mask=None):
         assert bias is None and not relu and relu_mask.dtype == x.dtype and relu_mask.is_contiguous() \
             and relu_mask.numel() == M * Cout
         d.epilogue, d.aux = _lib.EPI_RELU_MASK_AUX, ptr(relu_mask)
+    if colstats:  # BatchNorm partial statistics of y (see linear_fwd)
+        assert bias is None and relu_mask is None
+        stats = torch.empty((M + 127) // 128, 2, Cout, dtype=torch.float32, device=x.device)
+        d.colstats = ptr(stats)
+        gemm_raw(d, x.device)
+        return y.view(B, Ho, Wo, Cout), stats
     gemm_raw(d, x.device)
     return y.view(B, Ho, Wo, Cout)
 
@@ -658,8 +677,10 @@ def subsample2_bwd(dy, H, W):
 
 
 def bn_fwd(x2d, gamma, beta, res, running_mean, running_var, momentum, eps, relu, training,
-           mean=None, rstd=None):
-    _dev(x2d, gamma, beta, res, running_mean, running_var, mean, rstd)
+           mean=None, rstd=None, partials=None):
+    """`partials` [parts, 2, C]: training-mode statistics from the producing GEMM's epilogue
+    (linear_fwd / conv3x3_fwd with colstats=True) instead of a pass over x2d"""
+    _dev(x2d, gamma, beta, res, running_mean, running_var, mean, rstd, partials)
     rows, C = x2d.shape
     L = _lib.load()
     y = torch.empty_like(x2d)
@@ -667,6 +688,14 @@ def bn_fwd(x2d, gamma, beta, res, running_mean, running_var, momentum, eps, relu
         mean = torch.empty(C, dtype=torch.float32, device=x2d.device)
         rstd = torch.empty(C, dtype=torch.float32, device=x2d.device)
     ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    if training and partials is not None:
+        assert partials.dtype == torch.float32 and partials.shape[1:] == (2, C) and partials.is_contiguous()
+        _lib.check(L.ssl4gie_bn_fwd_partials(ptr(x2d), ptr(partials), partials.shape[0], ptr(gamma),
+                                             ptr(beta), ptr(res), ptr(y), ptr(mean), ptr(rstd),
+                                             ptr(running_mean), ptr(running_var), float(momentum),
+                                             float(eps), int(relu), ptr(ws), code(x2d.dtype), rows, C,
+                                             stream()), "bn_fwd_partials")
+        return y, mean, rstd
     _lib.check(L.ssl4gie_bn_fwd(ptr(x2d), ptr(gamma), ptr(beta), ptr(res), ptr(y), ptr(mean), ptr(rstd),
                                 ptr(running_mean), ptr(running_var), float(momentum), float(eps),
                                 int(relu), int(training), ptr(ws), code(x2d.dtype), rows, C, stream()),
@@ -724,14 +753,20 @@ def avgpool_bwd(dy, H, W, dtype):
 
 
 # ------------------------------------------------------------------ SyncBatchNorm pieces / MoCo EMA
-def bn_stats(x2d):
-    """local batch statistics (mean, biased variance) of the rows of x2d, fp32 [C] each"""
-    _dev(x2d)
+def bn_stats(x2d, partials=None):
+    """local batch statistics (mean, biased variance) of the rows of x2d, fp32 [C] each; from the
+    producing GEMM's `partials` [parts, 2, C] when given"""
+    _dev(x2d, partials)
     rows, C = x2d.shape
     L = _lib.load()
     mean = torch.empty(C, dtype=torch.float32, device=x2d.device)
     var = torch.empty(C, dtype=torch.float32, device=x2d.device)
     ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    if partials is not None:
+        assert partials.dtype == torch.float32 and partials.shape[1:] == (2, C) and partials.is_contiguous()
+        _lib.check(L.ssl4gie_bn_stats_partials(ptr(partials), partials.shape[0], ptr(mean), ptr(var),
+                                               ptr(ws), rows, C, stream()), "bn_stats_partials")
+        return mean, var
     _lib.check(L.ssl4gie_bn_stats(ptr(x2d), ptr(mean), ptr(var), ptr(ws), code(x2d.dtype), rows, C,
                                   stream()), "bn_stats")
     return mean, var

@@ -121,7 +121,9 @@ class BatchNormFn(torch.autograd.Function):
     kernel -> all_reduce of the 2C sums -> apply kernel (dgamma / dbeta stay local, DDP averages)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, bn, relu, sink: GradSink):
+    def forward(ctx, x, gamma, beta, res, bn, relu, sink: GradSink, stats=None):
+        """stats: per-128-row partial sums [parts, 2, C] of x from the GEMM that produced it
+        (LinearFn / Conv3x3Fn with want_stats) — saves the statistics pass over x"""
         shp = x.shape
         C = shp[-1]
         x2 = x.contiguous().view(-1, C)
@@ -134,9 +136,9 @@ class BatchNormFn(torch.autograd.Function):
         if training and not sync:
             mom = bn.momentum if bn.momentum is not None else 0.1
             y, mean, rstd = ops.bn_fwd(x2, g, b, r2, bn.running_mean, bn.running_var, mom, bn.eps, relu,
-                                       True)
+                                       True, partials=stats)
         elif training:
-            mean_l, var_l = ops.bn_stats(x2)
+            mean_l, var_l = ops.bn_stats(x2, partials=stats)
             mean, var, total = combine_batch_stats(mean_l, var_l, x2.shape[0], group)
             count = float(total)
             rstd = torch.rsqrt(var + bn.eps)
@@ -181,7 +183,7 @@ class BatchNormFn(torch.autograd.Function):
             gsums = sums.clone()
             dist.all_reduce(gsums, group=group)
             dx = ops.bn_bwd_apply(dy2, y, x2, gd, mean, rstd, gsums, 1.0 / count, relu)
-        return (dx.view(shp), rets[0], rets[1], dres.view(shp) if has_res else None, None, None, None)
+        return (dx.view(shp), rets[0], rets[1], dres.view(shp) if has_res else None, None, None, None, None)
 
 
 class MaxPoolFn(torch.autograd.Function):

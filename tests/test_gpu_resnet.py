@@ -223,3 +223,32 @@ def test_resnet_dense_decoder_vs_oracle():
         # fp32 engine vs fp64 oracle through a random-init ResNet50 at batch 4 (ill-conditioned, see
         # the trunk test above): several % of L2 noise; a structural error would be of order 1
         assert rel_err(pg[name].grad.cpu(), sd[name].grad.float()) < 0.15, name
+
+
+@pytest.mark.parametrize("T,K,N", [(1000, 64, 64), (12544, 256, 128), (300, 128, 264), (128, 64, 8)])
+def test_gemm_colstats_match_the_stored_outputs(T, K, N):
+    """ssl4gie_gemm_desc.colstats: per-128-row column sums / sums of squares of the bf16 outputs the
+    GEMM stored, and BatchNorm from them == BatchNorm with its own statistics pass"""
+    from ssl4gie_amd import ops
+    g = torch.Generator().manual_seed(50)
+    x = torch.randn(T, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    y, st = ops.linear_fwd(x, w, None, colstats=True)
+    y0 = ops.linear_fwd(x, w, None)
+    assert torch.equal(y, y0) and st.shape == ((T + 127) // 128, 2, N)
+    yf = y.float()
+    pad = (-T) % 128
+    yp = torch.cat([yf, yf.new_zeros(pad, N)]).view(-1, 128, N)
+    assert rel_err(st[:, 0], yp.sum(1)) < 1e-5
+    assert rel_err(st[:, 1], (yp * yp).sum(1)) < 1e-5
+    gam = (1 + 0.1 * torch.randn(N, generator=g)).to(DEV)
+    bet = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    rm0, rv0 = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    a, ma, ra = ops.bn_fwd(y, gam, bet, None, rm0, rv0, 0.1, 1e-5, True, True)
+    b, mb, rb = ops.bn_fwd(y, gam, bet, None, rm1, rv1, 0.1, 1e-5, True, True, partials=st)
+    assert rel_err(mb, ma) < 1e-4 and rel_err(rb, ra) < 1e-4
+    assert rel_err(b.float(), a.float()) < 5e-3 and rel_err(rm1, rm0) < 1e-4 and rel_err(rv1, rv0) < 1e-4
+    m2, v2 = ops.bn_stats(y, partials=st)   # the SyncBatchNorm half
+    m1, v1 = ops.bn_stats(y)
+    assert rel_err(m2, m1) < 1e-4 and rel_err(v2, v1) < 1e-4
