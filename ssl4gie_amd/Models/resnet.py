@@ -111,8 +111,9 @@ class ResNet50(EngineModule):
 
     def forward_maps(self, imgs, all_stages=False):
         self._prepare()
-        x = StemConvFn.apply(imgs, self.conv1.weight, self.dtype_, self.sink(), self.lp_cache)
-        x = self._bn(x, self.bn1, True)
+        r = StemConvFn.apply(imgs, self.conv1.weight, self.dtype_, self.sink(), self.lp_cache, _BN_STATS)
+        x, st = r if _BN_STATS else (r, None)
+        x = self._bn(x, self.bn1, True, stats=st)
         x = MaxPoolFn.apply(x)
         maps = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):

@@ -49,7 +49,8 @@ class StemConvFn(torch.autograd.Function):
     """conv1: Conv2d(3, 64, 7, stride 2, pad 3, bias=False) on the fp32 NCHW image."""
 
     @staticmethod
-    def forward(ctx, imgs, weight, dtype, sink: GradSink, lp: LPCache):
+    def forward(ctx, imgs, weight, dtype, sink: GradSink, lp: LPCache, want_stats=False):
+        """want_stats: also return the BatchNorm partial statistics of the map (or None)"""
         imgs = imgs.contiguous().float()
         B = imgs.shape[0]
         cols, Ho, Wo = STEM_COLS.get(imgs, dtype)
@@ -57,13 +58,19 @@ class StemConvFn(torch.autograd.Function):
         Cout = weight.shape[0]
         w2 = _derived(lp, weight, f"stem:{ld}", dtype,
                       lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 147), ld))
-        y = ops.linear_fwd(cols, w2, None, out_dtype=dtype)
         ctx.save_for_backward(imgs, weight)
         ctx.cfg = (dtype, sink)
-        return y.view(B, Ho, Wo, Cout)
+        stats = None
+        if want_stats and ops.colstats_ok(cols.shape[0], Cout, ld, dtype):
+            y, stats = ops.linear_fwd(cols, w2, None, out_dtype=dtype, colstats=True)
+            ctx.mark_non_differentiable(stats)
+        else:
+            y = ops.linear_fwd(cols, w2, None, out_dtype=dtype)
+        y = y.view(B, Ho, Wo, Cout)
+        return (y, stats) if want_stats else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         imgs, weight = ctx.saved_tensors
         dtype, sink = ctx.cfg
         Cout = weight.shape[0]
@@ -72,7 +79,7 @@ class StemConvFn(torch.autograd.Function):
             cols, _, _ = STEM_COLS.get(imgs, dtype)  # cached for the last two batches, else recomputed
             dw2 = ops.linear_bwd_weight(dy.contiguous().view(-1, Cout), cols)
             _write_grad(tw, dw2[:, :147].view(Cout, 7, 7, 3).permute(0, 3, 1, 2), acc)
-        return None, rets[0], None, None, None
+        return None, rets[0], None, None, None, None
 
 
 class Subsample2Fn(torch.autograd.Function):
