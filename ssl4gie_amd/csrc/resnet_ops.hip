@@ -645,10 +645,46 @@ extern "C" int ssl4gie_subsample2(const void* x, void* y, int dtype, int B, int 
     }
     return 0;
 }
+// ---- statistics that arrive as per-128-row partials from the producing GEMM's epilogue
+// (ssl4gie_gemm_desc::colstats: [parts][2][C], sums about 0): many partials (12 544 for the stem
+// map of a 512-image batch) are first folded to 64 by a wide grid, then finished by the tail kernel
+#define BN_FOLD 64
+__global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ pin, int parts,
+                                                               float* __restrict__ pout, int C) {
+    __shared__ float red[3][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, k = blockIdx.y;
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        for (int p = k + BN_FOLD * wave; p < parts; p += BN_FOLD * 4) {
+            s += pin[(size_t)p * 2 * C + c];
+            q += pin[(size_t)p * 2 * C + C + c];
+        }
+    }
+    if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
+        pout[(size_t)k * 2 * C + c] = s;
+        pout[(size_t)k * 2 * C + C + c] = q;
+    }
+}
+// -> (partials to hand to the tail kernels, their count); `scratch` holds BN_FOLD x 2C floats
+static int bn_fold(const float* partial, int parts, float* scratch, int C, hipStream_t st,
+                   const float** out, int* nout) {
+    if (parts <= 4 * BN_FOLD) { *out = partial; *nout = parts; return 0; }
+    hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + 63) / 64, BN_FOLD), dim3(256), 0, st, partial,
+                       parts, scratch, C);
+    LAUNCH_CHECK();
+    *out = scratch; *nout = BN_FOLD;
+    return 0;
+}
 extern "C" size_t ssl4gie_bn_workspace_bytes(long long rows, int C) {
     size_t parts = (size_t)bn_parts(rows, C);
     if (parts < 64) parts = 64;  // the partials paths fold into 64 x 2C floats of this workspace
-    return ((parts + 1) * 2 + 1 + 3) * C * sizeof(float);  // coef, partials, sums, pivot
+    // coef 3C, partials parts x 2C, sums 2C, pivot C, fold scratch 64 x 2C (backward tail)
+    return ((parts + 1) * 2 + 1 + 3 + 2 * BN_FOLD) * C * sizeof(float);
 }
 // forward: statistics over the rows of x [rows, C] (biased variance), optional running-stat update,
 // y = act(xhat gamma + beta (+ res)); mean / rstd [C] are kept for backward
@@ -710,8 +746,13 @@ extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, cons
                            (const float*)y, (const float*)x, mean, rstd, (float*)dres, partial, relu,
                            rows, C);
     LAUNCH_CHECK();
-    // dbeta = sum g, dgamma = sum g xhat, and the dx coefficients, in one launch
-    hipLaunchKernelGGL(bn_bwd_tail_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, parts, mean,
+    // dbeta = sum g, dgamma = sum g xhat, and the dx coefficients, in one launch (after a 64-way
+    // fold when the reduction left hundreds of partials: the tail's blocks are few and sequential)
+    const float* pp; int np;
+    float* fold_scratch = partial + ((size_t)parts * 2 + 3) * C;
+    int rc = bn_fold(partial, parts, fold_scratch, C, st, &pp, &np);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_tail_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pp, np, mean,
                        rstd, gamma, 1.0f / (float)rows, coef, dgamma, dbeta, accumulate, C);
     LAUNCH_CHECK();
     const long long total = rows * C;
@@ -823,41 +864,6 @@ extern "C" int ssl4gie_bn_stats(const void* x, float* mean, float* var, float* w
     hipLaunchKernelGGL(bn_local_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, pivot,
                        mean, var, (float)rows, C);
     LAUNCH_CHECK();
-    return 0;
-}
-// ---- statistics that arrive as per-128-row partials from the producing GEMM's epilogue
-// (ssl4gie_gemm_desc::colstats: [parts][2][C], sums about 0): many partials (12 544 for the stem
-// map of a 512-image batch) are first folded to 64 by a wide grid, then finished by the tail kernel
-#define BN_FOLD 64
-__global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ pin, int parts,
-                                                               float* __restrict__ pout, int C) {
-    __shared__ float red[3][2][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane, k = blockIdx.y;
-    float s = 0.f, q = 0.f;
-    if (c < C) {
-        for (int p = k + BN_FOLD * wave; p < parts; p += BN_FOLD * 4) {
-            s += pin[(size_t)p * 2 * C + c];
-            q += pin[(size_t)p * 2 * C + C + c];
-        }
-    }
-    if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
-    __syncthreads();
-    if (wave == 0 && c < C) {
-#pragma unroll
-        for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
-        pout[(size_t)k * 2 * C + c] = s;
-        pout[(size_t)k * 2 * C + C + c] = q;
-    }
-}
-// -> (partials to hand to the tail kernels, their count); `scratch` holds BN_FOLD x 2C floats
-static int bn_fold(const float* partial, int parts, float* scratch, int C, hipStream_t st,
-                   const float** out, int* nout) {
-    if (parts <= 4 * BN_FOLD) { *out = partial; *nout = parts; return 0; }
-    hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + 63) / 64, BN_FOLD), dim3(256), 0, st, partial,
-                       parts, scratch, C);
-    LAUNCH_CHECK();
-    *out = scratch; *nout = BN_FOLD;
     return 0;
 }
 // training-mode forward with the statistics taken from `partial` [parts][2][C] instead of a pass
