@@ -70,9 +70,12 @@ enum {
      * backward epilogue is one multiply (no transcendental work on the data-gradient GEMM) */
     SSL4GIE_EPI_BIAS_GELU_GRAD = 5, /* u = acc + bias[n]; C = gelu'(u); out2 = gelu(u) */
     SSL4GIE_EPI_MUL_AUX = 6,        /* C = acc * aux[m,n]                  */
-    SSL4GIE_EPI_RELU_MASK_AUX = 7   /* C = aux[m,n] > 0 ? acc : 0: gradient through the ReLU in front of a
+    SSL4GIE_EPI_RELU_MASK_AUX = 7,  /* C = aux[m,n] > 0 ? acc : 0: gradient through the ReLU in front of a
                                        convolution (aux = the convolution's input); implicit-conv NT
                                        products with bf16 output only */
+    SSL4GIE_EPI_ADD_AUX = 8         /* C = acc + aux[m,n]: a second gradient contribution of the same
+                                       tensor (residual branch) joined in the data-gradient GEMM;
+                                       256x256 NT kernel, bf16 output only */
 };
 /* Implicit patch-matrix operand of a 3x3 / pad-1 convolution over a channels-last bf16 map
  * x [B, H, W, C] (ssl4gie_gemm_desc::conv).  The patch matrix

@@ -18,9 +18,11 @@ import os
 
 from ..dpt_engine import Conv3x3Fn
 
+# SSL4GIE_GRAD_JOIN=0: autograd sums the two gradient contributions of a block input itself
+_GRAD_JOIN = os.environ.get("SSL4GIE_GRAD_JOIN", "1") != "0"
 # SSL4GIE_BN_STATS_FUSED=0: BatchNorm statistics by their own pass over the map (A/B measurements)
 _BN_STATS = os.environ.get("SSL4GIE_BN_STATS_FUSED", "1") != "0"
-from ..engine import EngineModule, LinearFn
+from ..engine import EngineModule, GradJoin, LinearFn
 from ..resnet_engine import AvgPoolFn, BatchNormFn, MaxPoolFn, StemConvFn, Subsample2Fn
 
 
@@ -80,23 +82,26 @@ class ResNet50(EngineModule):
         return nn.Sequential(*layers)
 
     # ------------------------------------------------------------------ engine forward
-    def _bn(self, x, bn, relu, res=None, stats=None):
-        return BatchNormFn.apply(x, bn.weight, bn.bias, res, bn, relu, self.sink(), stats)
+    def _bn(self, x, bn, relu, res=None, stats=None, join=None):
+        return BatchNormFn.apply(x, bn.weight, bn.bias, res, bn, relu, self.sink(), stats, join)
 
-    def _c1(self, x, conv):
+    def _c1(self, x, conv, join=None):
         """1x1 convolution -> (map, BatchNorm partial statistics of the map or None)"""
         if conv.stride[0] == 2:
             x = Subsample2Fn.apply(x)
+            join = None  # the pixel pick sits between x and the GEMM: its gradient is not x's
         B, H, W, C = x.shape
         r = LinearFn.apply(x.reshape(-1, C), conv.weight, None, self.dtype_, self.dtype_, self.sink(),
-                           self.lp_cache, _BN_STATS)
+                           self.lp_cache, _BN_STATS, join)
         y, st = r if _BN_STATS else (r, None)
         return y.view(B, H, W, -1), st
 
     def _block(self, x, blk: Bottleneck):
         # every convolution hands the batch statistics of its output to the BatchNorm that follows
         # (column sums from the GEMM epilogue): no separate statistics pass over the maps
-        out, st = self._c1(x, blk.conv1)
+        # x feeds conv1 and the identity (or downsample) branch: one GradJoin, conv1 is the adder
+        join = GradJoin.for_tensor(x) if _GRAD_JOIN else None
+        out, st = self._c1(x, blk.conv1, join)
         out = self._bn(out, blk.bn1, True, stats=st)
         r = Conv3x3Fn.apply(out, blk.conv2.weight, None, blk.conv2.stride[0], False, self.sink(),
                             self.lp_cache, _BN_STATS)
@@ -105,9 +110,10 @@ class ResNet50(EngineModule):
         out, st = self._c1(out, blk.conv3)
         identity = x
         if blk.downsample is not None:
-            idn, sti = self._c1(x, blk.downsample[0])
+            idn, sti = self._c1(x, blk.downsample[0], join)
             identity = self._bn(idn, blk.downsample[1], False, stats=sti)
-        return self._bn(out, blk.bn3, True, res=identity, stats=st)  # relu(bn3(out) + identity)
+            join = None  # bn3's residual input is the downsample branch, not x
+        return self._bn(out, blk.bn3, True, res=identity, stats=st, join=join)  # relu(bn3(out) + identity)
 
     def forward_maps(self, imgs, all_stages=False):
         self._prepare()

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libssl4gie_hip.so")
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX, \
-    EPI_RELU_MASK_AUX = range(8)
+    EPI_RELU_MASK_AUX, EPI_ADD_AUX = range(9)
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 

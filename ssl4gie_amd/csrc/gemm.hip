@@ -837,7 +837,9 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
     REQUIRE(d->batch1 >= 1 && d->batch2 >= 1);
     REQUIRE(d->dtype_ab == SSL4GIE_F32 || d->dtype_ab == SSL4GIE_BF16);
     REQUIRE(d->dtype_c == SSL4GIE_F32 || d->dtype_c == SSL4GIE_BF16);
-    REQUIRE(d->epilogue >= SSL4GIE_EPI_NONE && d->epilogue <= SSL4GIE_EPI_RELU_MASK_AUX);
+    REQUIRE(d->epilogue >= SSL4GIE_EPI_NONE && d->epilogue <= SSL4GIE_EPI_ADD_AUX);
+    REQUIRE(d->epilogue != SSL4GIE_EPI_ADD_AUX ||
+            (d->aux && !d->conv && nt_ok(d) && ssl4gie_internal_nt256_ok(d)));  // 256x256 NT kernel only
     REQUIRE(d->epilogue != SSL4GIE_EPI_RELU_MASK_AUX || (d->conv && d->aux));  // implicit conv only
     REQUIRE(d->epilogue != SSL4GIE_EPI_BIAS || d->bias);
     REQUIRE((d->epilogue != SSL4GIE_EPI_BIAS_GELU && d->epilogue != SSL4GIE_EPI_BIAS_GELU_GRAD) || d->out2);

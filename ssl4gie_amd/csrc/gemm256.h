@@ -126,7 +126,7 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
 // bf16 outputs multiplied by a bf16 auxiliary tile (the saved GELU derivative): same transposition,
 // fp32 through the staging area, the aux rows requested 6 row blocks ahead (48 VGPRs, the registers of the
 // dead operand fragments) in the coalesced row layout.
-// AUXF: 1 multiply by aux, 2 multiply by gelu'(aux), 3 zero where aux <= 0 (ReLU mask).
+// AUXF: 1 multiply by aux, 2 multiply by gelu'(aux), 3 zero where aux <= 0 (ReLU mask), 4 add aux.
 template <bool FULL, int AUXF>
 DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
                            const bf16_t* __restrict__ aux, bf16_t* __restrict__ C,
@@ -169,6 +169,8 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
             if constexpr (AUXF == 3) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = u[j] > 0.f ? w[j] : 0.f;
+            } else if constexpr (AUXF == 4) {
+                w += u;
             } else {
                 w *= u;
             }

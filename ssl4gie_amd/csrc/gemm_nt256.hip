@@ -68,8 +68,9 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
         }
     }
     if constexpr (sizeof(TC) == 2 && (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
-                                      MODE == SSL4GIE_EPI_RELU_MASK_AUX)) {
-        constexpr int AUXF = MODE == SSL4GIE_EPI_DGELU ? 2 : (MODE == SSL4GIE_EPI_RELU_MASK_AUX ? 3 : 1);
+                                      MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX)) {
+        constexpr int AUXF = MODE == SSL4GIE_EPI_DGELU ? 2
+                           : (MODE == SSL4GIE_EPI_RELU_MASK_AUX ? 3 : (MODE == SSL4GIE_EPI_ADD_AUX ? 4 : 1));
         p_store_bf16_aux<FULL, AUXF>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane);
     } else if constexpr (sizeof(TC) == 2) {
         // bf16: stage 16 rows x 64 columns (2 KiB), chunk c of row r at position c ^ (r & 7)
@@ -452,9 +453,11 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
         if (ep == SSL4GIE_EPI_BIAS_RESIDUAL || d->accumulate) return false;
     } else {
         if (ep == SSL4GIE_EPI_BIAS_GELU || ep == SSL4GIE_EPI_DGELU ||
-            ep == SSL4GIE_EPI_BIAS_GELU_GRAD || ep == SSL4GIE_EPI_MUL_AUX || ep == SSL4GIE_EPI_RELU_MASK_AUX)
+            ep == SSL4GIE_EPI_BIAS_GELU_GRAD || ep == SSL4GIE_EPI_MUL_AUX || ep == SSL4GIE_EPI_RELU_MASK_AUX ||
+            ep == SSL4GIE_EPI_ADD_AUX)
             return false;
     }
+    if (ep == SSL4GIE_EPI_ADD_AUX) return d->aux != nullptr;  // exists in this kernel only
     if (mode == 1 || d->colstats) return true;  // the statistics only exist in this kernel
     // heuristic: enough 256x256 tiles to fill most of the chip
     const long long tiles = (long long)((d->M + P_BM - 1) / P_BM) * ((d->N + P_BN - 1) / P_BN);
@@ -510,6 +513,7 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
             case SSL4GIE_EPI_DGELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_DGELU); break;
             case SSL4GIE_EPI_BIAS_GELU_GRAD: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU_GRAD); break;
             case SSL4GIE_EPI_MUL_AUX: P_LAUNCH(bf16_t, SSL4GIE_EPI_MUL_AUX); break;
+            case SSL4GIE_EPI_ADD_AUX: P_LAUNCH(bf16_t, SSL4GIE_EPI_ADD_AUX); break;
             case SSL4GIE_EPI_NONE: P_LAUNCH(bf16_t, SSL4GIE_EPI_NONE); break;
             default: return ARG_ERR;
         }

@@ -360,14 +360,48 @@ class LayerNormFn(torch.autograd.Function):
         return dx, rets[0], rets[1], None, None, None
 
 
+class GradJoin:
+    """Joins the gradient contributions of a tensor that feeds several engine nodes of one block
+    (ResNet bottleneck input: conv1 + identity / downsample branch) without autograd's separate add
+    kernel.  Nodes are handed the same GradJoin in forward, in creation order; backward runs them in
+    reverse, so the FIRST node created is the last to run: it is the `adder` and takes everything the
+    others deposited into its data-gradient GEMM's epilogue (ssl4gie EPI_ADD_AUX); the others return
+    None for that input.  A join is only created when the tensor requires grad, so the adder's
+    backward is guaranteed to run."""
+
+    __slots__ = ("adder_claimed", "pending")
+
+    def __init__(self):
+        self.adder_claimed = False
+        self.pending = None
+
+    @staticmethod
+    def for_tensor(x):
+        return GradJoin() if (torch.is_grad_enabled() and x.requires_grad) else None
+
+    def claim(self) -> str:
+        if not self.adder_claimed:
+            self.adder_claimed = True
+            return "adder"
+        return "depositor"
+
+    def deposit(self, g):
+        self.pending = g if self.pending is None else self.pending + g
+
+    def take(self):
+        g, self.pending = self.pending, None
+        return g
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b on operand-type activations; y in `out_dtype`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, dtype, out_dtype, sink, lp, want_stats=False):
+    def forward(ctx, x, weight, bias, dtype, out_dtype, sink, lp, want_stats=False, join=None):
         """want_stats: also return the per-128-row column sums / sums of squares of y (fp32
         [parts, 2, n_out], not differentiable) for the BatchNorm that follows — or None when the
-        GEMM cannot produce them (ops.colstats_ok)"""
+        GEMM cannot produce them (ops.colstats_ok).  join: GradJoin of the input tensor."""
+        ctx.join, ctx.join_role = join, (join.claim() if join is not None else None)
         shp = x.shape
         x2 = x.contiguous().view(-1, shp[-1])
         assert x2.dtype == dtype
@@ -394,12 +428,22 @@ class LinearFn(torch.autograd.Function):
         (tw, tb), acc, rets = ctx.sink.plan([weight, bias])
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear_bwd_data(dy2, ctx.wlp, ctx.wt).view(ctx.shp)
+            other = ctx.join.take() if ctx.join_role == "adder" else None
+            if other is not None and ops.add_aux_ok(dy2.shape[0], x2.shape[1], dy2.shape[1], ctx.dtype,
+                                                    ctx.wt is not None):
+                dx = ops.linear_bwd_data(dy2, ctx.wlp, ctx.wt, add_aux=other.contiguous()).view(ctx.shp)
+            else:
+                dx = ops.linear_bwd_data(dy2, ctx.wlp, ctx.wt).view(ctx.shp)
+                if other is not None:
+                    dx = dx + other.view(ctx.shp)
+            if ctx.join_role == "depositor":
+                ctx.join.deposit(dx)
+                dx = None
         if tw is not None:
             ops.linear_bwd_weight(dy2, x2, out=tw, accumulate=acc, bias_out=tb)
         elif tb is not None:
             ops.colsum(dy2, out=tb, accumulate=acc)
-        return dx, rets[0], rets[1], None, None, None, None, None
+        return dx, rets[0], rets[1], None, None, None, None, None, None
 
 
 class PatchEmbedFn(torch.autograd.Function):

@@ -165,10 +165,16 @@ def linear_fwd(x2d, w, bias=None, out_dtype=None, epilogue=None, residual=None, 
     return (y, out2) if out2 is not None else y
 
 
-def linear_bwd_data(dy2d, w, w_t=None, out_dtype=None, dgelu_aux=None, mul_aux=None):
+def add_aux_ok(T, k_in, n_out, dtype, has_wt):
+    """whether linear_bwd_data can join a second gradient contribution in its epilogue"""
+    return dtype == torch.bfloat16 and has_wt and n_out % 64 == 0 and k_in % 8 == 0 and T > 0
+
+
+def linear_bwd_data(dy2d, w, w_t=None, out_dtype=None, dgelu_aux=None, mul_aux=None, add_aux=None):
     """dx[T, k_in] = dy[T, n_out] @ w[n_out, k_in]; uses w_t[k_in, n_out] (NT fast path) if given.
-    `dgelu_aux` = u: dx *= gelu'(u);  `mul_aux` = m: dx *= m (m = gelu'(u) saved by the forward)."""
-    _dev(dy2d, w, w_t, dgelu_aux, mul_aux)
+    `dgelu_aux` = u: dx *= gelu'(u);  `mul_aux` = m: dx *= m (m = gelu'(u) saved by the forward);
+    `add_aux` = g: dx += g (another gradient contribution of the same tensor; see add_aux_ok)."""
+    _dev(dy2d, w, w_t, dgelu_aux, mul_aux, add_aux)
     T, n_out = dy2d.shape
     k_in = w.shape[1]
     assert w.shape[0] == n_out
@@ -189,6 +195,11 @@ def linear_bwd_data(dy2d, w, w_t=None, out_dtype=None, dgelu_aux=None, mul_aux=N
     if mul_aux is not None:
         assert dgelu_aux is None and mul_aux.shape == dx.shape and mul_aux.dtype == out_dtype
         d.epilogue, d.aux = _lib.EPI_MUL_AUX, ptr(mul_aux)
+    if add_aux is not None:
+        assert dgelu_aux is None and mul_aux is None and add_aux.dtype == out_dtype and \
+            add_aux.numel() == dx.numel() and add_aux.is_contiguous() and \
+            add_aux_ok(T, k_in, n_out, dy2d.dtype, w_t is not None)
+        d.epilogue, d.aux = _lib.EPI_ADD_AUX, ptr(add_aux)
     gemm_raw(d, dy2d.device)
     return dx
 

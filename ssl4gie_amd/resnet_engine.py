@@ -128,9 +128,11 @@ class BatchNormFn(torch.autograd.Function):
     kernel -> all_reduce of the 2C sums -> apply kernel (dgamma / dbeta stay local, DDP averages)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, bn, relu, sink: GradSink, stats=None):
+    def forward(ctx, x, gamma, beta, res, bn, relu, sink: GradSink, stats=None, join=None):
         """stats: per-128-row partial sums [parts, 2, C] of x from the GEMM that produced it
-        (LinearFn / Conv3x3Fn with want_stats) — saves the statistics pass over x"""
+        (LinearFn / Conv3x3Fn with want_stats) — saves the statistics pass over x.
+        join: engine.GradJoin of the residual input (its gradient is deposited, not returned)."""
+        ctx.join = join if (join is not None and res is not None and join.claim() == "depositor") else None
         shp = x.shape
         C = shp[-1]
         x2 = x.contiguous().view(-1, C)
@@ -190,7 +192,11 @@ class BatchNormFn(torch.autograd.Function):
             gsums = sums.clone()
             dist.all_reduce(gsums, group=group)
             dx = ops.bn_bwd_apply(dy2, y, x2, gd, mean, rstd, gsums, 1.0 / count, relu)
-        return (dx.view(shp), rets[0], rets[1], dres.view(shp) if has_res else None, None, None, None, None)
+        gres = dres.view(shp) if has_res else None
+        if gres is not None and ctx.join is not None:
+            ctx.join.deposit(gres)  # joined in the data-gradient GEMM of the block's first convolution
+            gres = None
+        return (dx.view(shp), rets[0], rets[1], gres, None, None, None, None, None)
 
 
 class MaxPoolFn(torch.autograd.Function):
