@@ -11,6 +11,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libssl4gie_hip.so")
 
+# the one copy of the ABI revision on the Python side: build(), the tests and load() compare the
+# library's ssl4gie_abi_version() with it (include/ssl4gie_hip.h documents the history)
+ABI_VERSION = 2
+
 F32, BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX, \
     EPI_RELU_MASK_AUX, EPI_ADD_AUX = range(9)
@@ -159,6 +163,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.ssl4gie_abi_version()
+    if got != ABI_VERSION:
+        raise HipExtensionMissing(
+            f"{LIB_PATH} has ABI revision {got}, this package binds revision {ABI_VERSION}: "
+            "rebuild it (`make -C ssl4gie_amd/csrc`)")
     _lib = lib
     return lib
 

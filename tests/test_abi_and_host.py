@@ -29,7 +29,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ssl4gie_hip.h but not exported"
     assert set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
-    assert _lib.load().ssl4gie_abi_version() == 2
+    assert _lib.load().ssl4gie_abi_version() == _lib.ABI_VERSION
+
+
+def test_graft_entry_build_runs_clean():
+    """the documented build command (README) must exit 0: make is a no-op when up to date"""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build()
 
 
 def test_workspace_queries_need_no_gpu():
