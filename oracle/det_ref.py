@@ -6,9 +6,12 @@ output projection), the block swap of `det=True` (:281-285: blocks 0,1,3,4,6,7,9
 `_pos_embed_interp` (:310-323: bilinear resize of the 14 x 14 table with align_corners=True, no cls
 token), `forward_features` (:325-338) and `ViTDet_FPN` (:213-259: MaxPool2d(2) / ConvTranspose2d
 (2, 2) / 1x1 / LayerNorm((C,H,W)) / GELU / 3x3 stacks, `pool` = max_pool2d(kernel 1, stride 2)).
-models.py cannot be imported here (timm / torchvision absent), and the reference holds no tests for
-this path: PARITY UNPINNED beyond torch op semantics — except the permutation, which is integer
-work restated index for index (checked for bijectivity and window structure in the tests).
+PINNED: tests/golden/g10_det.npz holds outputs and gradients of the reference's own
+`VisionTransformer_from_Any(det=True)` / `ViT_from_MAE(det=True)` / `ViTDet_FPN` (models.py imported
+in the authoring container on top of oracle/timm_restatement.py + oracle/torchvision_restatement.py
+— timm and torchvision themselves are pinned but absent — by tests/golden/make_golden.py:g10_det);
+tests/test_oracle_golden.py checks this restatement against it.  The permutation is integer work
+restated index for index (checked for bijectivity and window structure in the tests).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """

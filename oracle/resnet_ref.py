@@ -49,9 +49,11 @@ def resnet50_pooled(sd, imgs):
 
 # ------------------------------------------------------------------ dense decoder of the ResNet path
 # Reference: Models/models.py:14-60 (ResNet_Dec_Block / ResNet_Dec_Level), :88-107 (decoder_levels,
-# output_conv), :128-135 (decode).  models.py itself cannot be imported here (it imports timm and
-# torchvision at module level, both absent), so like the trunk this restatement is anchored by torch
-# op semantics only: PARITY UNPINNED.
+# output_conv), :128-135 (decode).  PINNED: tests/golden/g12_resnet_dec.npz holds outputs and
+# gradients of the reference's own `ResNet_from_Any(dense="depth").decode` (models.py imported in
+# the authoring container on top of oracle/timm_restatement.py + oracle/torchvision_restatement.py,
+# tests/golden/make_golden.py:g12_resnet_dec), and tests/test_oracle_golden.py checks this
+# restatement against it.  The trunk above stays unpinned at the torchvision boundary.
 def _bnb(sd, p, x, eps=1e-5):
     return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, eps)
 
@@ -87,13 +89,22 @@ def resnet50_stage_maps(sd, imgs):
     return maps
 
 
-def resnet50_dense(sd, imgs):
-    """ResNet_from_Any(dense=...)._forward_impl: stage maps -> 3 decoder levels -> output_conv"""
-    m = resnet50_stage_maps(sd, imgs)
-    out = dec_level(sd, "decoder_levels.0", m[-1], m[-2])
-    out = dec_level(sd, "decoder_levels.1", out, m[-3])
-    out = dec_level(sd, "decoder_levels.2", out, m[-4])
+def output_head(sd, out):
+    """models.py:96-104: up x2 -> 3x3 (256->128) -> up x2 -> 3x3 (128->32) -> ReLU -> 1x1 -> Sigmoid"""
     up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
     h = F.conv2d(up(out), sd["output_conv.1.weight"], sd["output_conv.1.bias"], padding=1)
     h = F.conv2d(up(h), sd["output_conv.3.weight"], sd["output_conv.3.bias"], padding=1)
     return torch.sigmoid(F.conv2d(F.relu(h), sd["output_conv.5.weight"], sd["output_conv.5.bias"]))
+
+
+def decode(sd, m):
+    """models.py:128-135 on the four stage maps m = [256@s, 512@s/2, 1024@s/4, 2048@s/8]"""
+    out = dec_level(sd, "decoder_levels.0", m[-1], m[-2])
+    out = dec_level(sd, "decoder_levels.1", out, m[-3])
+    out = dec_level(sd, "decoder_levels.2", out, m[-4])
+    return output_head(sd, out)
+
+
+def resnet50_dense(sd, imgs):
+    """ResNet_from_Any(dense=...)._forward_impl: stage maps -> 3 decoder levels -> output_conv"""
+    return decode(sd, resnet50_stage_maps(sd, imgs))

@@ -108,3 +108,31 @@ def synth_noise(b: int, l: int, seed: int = 0) -> np.ndarray:
         while len(np.unique(noise[r])) != l:
             noise[r] = torch.rand(l, generator=g).numpy()
     return noise
+
+
+def keyed_tensor(key: str, shape, seed: int) -> torch.Tensor:
+    """Generic rule for the finetune zoo (ViT trunks, ViTDet pyramid, ResNet50 + decoders, heads):
+    a pure function of (key, shape, seed) like `synth_tensor`, covering BatchNorm buffers, conv /
+    transposed-conv kernels and whole-map LayerNorm affines."""
+    shape = tuple(shape)
+    g = _gen(key, seed)
+    if key.endswith("num_batches_tracked"):
+        return torch.zeros(shape, dtype=torch.long)
+    if key.endswith("running_mean"):
+        return torch.zeros(shape)
+    if key.endswith("running_var"):
+        return torch.ones(shape)
+    if key.endswith("pos_embed") or key in ("cls_token", "mask_token"):
+        return 0.02 * torch.randn(shape, generator=g)
+    if key.endswith(".bias"):
+        return 0.05 * torch.randn(shape, generator=g)
+    if len(shape) in (1, 3):  # LayerNorm / BatchNorm scale (3-D: nn.LayerNorm((C, H, W)))
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    fan_in = int(np.prod(shape[1:]))
+    return torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+
+
+def keyed_state_dict(shapes: dict, seed: int, keep=()) -> dict:
+    """`shapes`: key -> shape (e.g. {k: v.shape for k, v in module.state_dict().items()}); keys in
+    `keep` are left out (fixed tables the module builds itself)."""
+    return {k: keyed_tensor(k, s, seed) for k, s in shapes.items() if k not in keep}

@@ -31,3 +31,24 @@ def rel_err(a, b):
     assert a.shape == b.shape, (a.shape, b.shape)
     den = b.abs().max().item()
     return (a - b).abs().max().item() / (den if den > 0 else 1.0)
+
+
+def keyed_weights(module, seed, keys=None, digest=None, keep=()):
+    """Load oracle.synth.keyed_tensor(key, shape, seed) into one of the build's modules (the same
+    tensors tests/golden/make_golden.py loaded into the reference's class; `keep` = fixed tables
+    the module builds itself) and prove it: same key set, same SHA-256 over the loaded state_dict.
+    Returns the state_dict as plain tensors (for the oracle)."""
+    import torch
+    from oracle import synth
+    own = module.state_dict()
+    if keys is not None:
+        assert sorted(own) == sorted(np.asarray(keys).tolist()), \
+            set(own) ^ set(np.asarray(keys).tolist())
+    sd = synth.keyed_state_dict({k: tuple(v.shape) for k, v in own.items()}, seed, keep=keep)
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    full = {k: v.detach().clone().cpu() for k, v in module.state_dict().items()}
+    if digest is not None:
+        assert synth.state_dict_digest(full) == str(digest), "weights differ from the generator's"
+    return full

@@ -21,6 +21,14 @@ Fixtures written:
   g6_dpt_depth.npz    reference DPT_decoder("depth") fwd + SSI loss + grads on seeded taps, B=2
   g7_ssi_loss.npz     reference ScaleAndShiftInvariantLoss(alpha=0.1) value + gradient
   g8_moco.npz         reference MoCo._build_mlp fwd/bwd, contrastive_loss (1-process gloo), LARS 3 steps
+  g3_sincos.npz       (+ moco_768: VisionTransformerMoCo.build_2d_sincos_position_embedding, vits.py:53-69)
+  g10_det.npz         reference Models/models.py detection backbone: VisionTransformer_from_Any(det=True)
+                      trunk at 512^2 (WindowedAttention :155-210, _pos_embed_interp :310-323) fwd + grads,
+                      ViT_from_MAE(det=True) trunk at 256^2, full backbone + ViTDet_FPN (:213-259) at 1024^2
+  g11_vit_api.npz     reference ViT_from_MAE / ViT_from_MoCoV3 / VisionTransformer_from_Any: heads (cls,
+                      spatial), dense taps (:427-456), ViT_from_MAE + DPT depth fwd + SSI loss + grad norms
+  g12_resnet_dec.npz  reference ResNet_from_Any(dense="depth"): decode() (:16-60,128-135) on seeded stage
+                      maps fwd + grads, and the whole model on top of oracle/torchvision_restatement.py
 """
 from __future__ import annotations
 
@@ -39,7 +47,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
-from oracle import mae_ref, synth, timm_restatement  # noqa: E402
+from oracle import mae_ref, synth, timm_restatement, torchvision_restatement  # noqa: E402
 
 
 def import_reference_mae():
@@ -212,6 +220,270 @@ def curve(ref_mae, cfg, b, steps, lr, fname):
                         weight_decay=np.array(0.05), betas=np.array([0.9, 0.95]),
                         digest=np.array(synth.state_dict_digest(sd)))
     print(fname, "first/last", losses[0], losses[-1])
+
+
+def import_reference_models():
+    """the reference's own Models/models.py (+ moco_v3/vits.py) on top of the timm / torchvision
+    restatements (both pinned in requirements.txt:7,10, neither vendored nor installed)"""
+    timm_restatement.install_as_timm()
+    torchvision_restatement.install_as_torchvision()
+    np.float = float
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import Models.models as ref_models  # noqa
+    return ref_models
+
+
+def load_keyed(m, seed, keep=()):
+    """overwrite every tensor of the reference module (except `keep`: fixed tables it built itself)
+    with oracle.synth.keyed_tensor(key, shape, seed); returns (shapes, digest)"""
+    own = m.state_dict()
+    sd = synth.keyed_state_dict({k: tuple(v.shape) for k, v in own.items()}, seed, keep=keep)
+    for k, v in sd.items():
+        assert v.dtype == own[k].dtype, (k, v.dtype, own[k].dtype)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert set(missing) <= set(keep) and not unexpected, (missing, unexpected)
+    return {k: tuple(v.shape) for k, v in own.items()}, synth.state_dict_digest(m.state_dict())
+
+
+def pack_grads(out, prefix, named_params, small=4096):
+    grads = {k: p.grad for k, p in named_params if p.grad is not None}
+    names = sorted(grads)
+    out[prefix + "grad_names"] = np.array(names)
+    out[prefix + "grad_norms"] = np.array([float(grads[k].double().norm()) for k in names], dtype=np.float64)
+    for k in names:
+        g = grads[k]
+        if g.numel() <= small:
+            out[f"{prefix}grad/{k}"] = g.numpy()
+        else:
+            out[f"{prefix}gslice/{k}"] = g.reshape(g.shape[0], -1)[:8, :64].numpy().copy()
+
+
+def g3b_moco_sincos():
+    import_reference_models()
+    import Models.moco_v3.vits as ref_vits
+    out = dict(np.load(os.path.join(HERE, "g3_sincos.npz")))
+    for d, grid in ((768, 14), (384, 14), (192, 4)):
+        obj = types.SimpleNamespace(patch_embed=types.SimpleNamespace(grid_size=(grid, grid)), embed_dim=d)
+        ref_vits.VisionTransformerMoCo.build_2d_sincos_position_embedding(obj)
+        t = obj.pos_embed.detach()
+        assert t.shape == (1, grid * grid + 1, d) and not obj.pos_embed.requires_grad
+        np.testing.assert_array_equal(mae_ref.sincos_2d_moco(d, grid).numpy(), t.numpy())
+        out[f"moco_{d}" + ("" if grid == 14 else f"_g{grid}")] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, "g3_sincos.npz"), **out)
+    print("g3b ok (oracle table bit-equal to the reference's)")
+
+
+def g10_det():
+    from oracle import det_ref
+    rm = import_reference_models()
+    out = {}
+    # ---- (a) VisionTransformer_from_Any(det=True) trunk, 512^2: N = 1024 tokens, 4 windows of 256
+    m = rm.VisionTransformer_from_Any(False, 0, False, None, True, 512, 768, 12, 12, "cls")
+    assert "cls_token" not in m.state_dict()
+    shapes, digest = load_keyed(m, seed=31)
+    out["keys"] = np.array(sorted(shapes))
+    out["digest"] = np.array(digest)
+    g = torch.Generator("cpu").manual_seed(32)
+    imgs = torch.randn(1, 3, 512, 512, generator=g)
+    wgt = torch.randn(1, 1024, 768, generator=g)
+    tok = m.forward_features(imgs)
+    (tok * wgt).sum().backward()
+    out["t512/tok_sub"] = tok.detach()[:, ::4].numpy()
+    out["t512/tok_norm"] = np.array(float(tok.detach().double().norm()))
+    pack_grads(out, "t512/", [(k, p) for k, p in m.named_parameters() if not k.startswith("fpn.")])
+    # the oracle restatement must agree with the reference before anything is written
+    sdo = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref_o = det_ref.det_trunk(sdo, imgs, 512)
+    np.testing.assert_allclose(ref_o.numpy(), tok.detach().numpy(), rtol=1e-3, atol=2e-4)
+    print(f"g10 trunk512: |tok|={float(out['t512/tok_norm']):.4f} (oracle agrees)")
+    # ---- (b) the whole backbone + ViTDet_FPN at its hard-coded 1024^2 geometry, B = 1
+    m.zero_grad(set_to_none=True)
+    m.fixed_size = 1024
+    m.patch_embed.img_size = (1024, 1024)
+    g = torch.Generator("cpu").manual_seed(33)
+    imgs = torch.randn(1, 3, 1024, 1024, generator=g)
+    maps = m(imgs)
+    assert list(maps.keys()) == ["0", "1", "2", "3", "pool"]
+    loss = 0
+    for i, (k, v) in enumerate(maps.items()):
+        w = torch.randn(v.shape, generator=torch.Generator("cpu").manual_seed(40 + i))
+        loss = loss + (v * w).sum() / v.numel() ** 0.5
+        out[f"f1024/shape/{k}"] = np.array(v.shape)
+        out[f"f1024/norm/{k}"] = np.array(float(v.detach().double().norm()))
+        out[f"f1024/corner/{k}"] = v.detach()[:, :8, :16, :16].numpy().copy()
+        out[f"f1024/center/{k}"] = v.detach()[:, 100:108, v.shape[2] // 2:v.shape[2] // 2 + 4,
+                                              v.shape[3] // 2:v.shape[3] // 2 + 4].numpy().copy()
+    loss.backward()
+    out["f1024/loss"] = np.array(float(loss))
+    pack_grads(out, "f1024/", list(m.named_parameters()))
+    with torch.no_grad():
+        tok_o = det_ref.det_trunk(sdo, imgs, 1024)
+        maps_o = det_ref.fpn(sdo, tok_o)
+    for k in maps:
+        np.testing.assert_allclose(maps_o[k].numpy(), maps[k].detach().numpy(), rtol=2e-3, atol=2e-3)
+    print(f"g10 full1024: loss={float(loss):.6f} (oracle agrees on all 5 maps)")
+    del m
+    # ---- (c) ViT_from_MAE(det=True) forward_encoder at 256^2 (one window; models.py:430-443)
+    m = rm.ViT_from_MAE(None, False, 0, False, None, True, 256, 768, 12, 12, "cls")
+    keep = ("pos_embed", "decoder_pos_embed")
+    shapes, digest = load_keyed(m, seed=34, keep=keep)
+    out["mae256/keys"] = np.array(sorted(shapes))
+    out["mae256/digest"] = np.array(digest)
+    imgs = torch.randn(2, 3, 256, 256, generator=torch.Generator("cpu").manual_seed(35))
+    with torch.no_grad():
+        tok = m.forward_encoder(imgs)
+    out["mae256/tok"] = tok[:, ::2, ::2].numpy().copy()
+    out["mae256/tok_norm"] = np.array(float(tok.double().norm()))
+    np.savez_compressed(os.path.join(HERE, "g10_det.npz"), **out)
+    print("g10 ok")
+
+
+def g11_vit_api():
+    from oracle import dpt_ref
+    rm = import_reference_models()
+    ref_loss = _load_by_path("ref_losses", os.path.join(REF, "Depth_estimation", "Metrics", "losses.py"))
+    out = {}
+    cfg = mae_ref.VIT_B
+    imgs = synth.synth_images(2, cfg, seed=41)
+    out["imgs_seed"] = np.array(41)
+    keep = ("pos_embed", "decoder_pos_embed")
+    # ---- ViT_from_MAE with a linear head: cls and spatial readouts (models.py:458-472)
+    m = rm.ViT_from_MAE(None, True, 6, False, None, False, None, 768, 12, 12, "cls")
+    assert "decoder_pos_embed" in m.state_dict() and "mask_token" not in m.state_dict()
+    shapes, digest = load_keyed(m, seed=42, keep=keep)
+    out["mae_head/keys"] = np.array(sorted(shapes)); out["mae_head/digest"] = np.array(digest)
+    y = m(imgs)
+    wy = torch.randn(y.shape, generator=torch.Generator("cpu").manual_seed(43))
+    (y * wy).sum().backward()
+    out["mae_head/cls"] = y.detach().numpy()
+    pack_grads(out, "mae_head/", list(m.named_parameters()))
+    m.out_token = "spatial"
+    with torch.no_grad():
+        out["mae_head/spatial"] = m(imgs).numpy()
+        tok = m.forward_encoder(imgs)
+    out["mae_head/tok_sub"] = tok[:, ::8].numpy().copy()
+    sdo = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        np.testing.assert_allclose(mae_ref.vit_trunk(sdo, cfg, imgs, False).numpy(), tok.numpy(), rtol=1e-3, atol=1e-4)
+    # ---- ViT_from_MAE(dense="depth"): taps after blocks 2/5/8/11 (no final norm), DPT decoder, SSI loss
+    m = rm.ViT_from_MAE(None, False, 1, False, "depth", False, None, 768, 12, 12, "cls")
+    shapes, digest = load_keyed(m, seed=44, keep=keep)
+    out["mae_depth/keys"] = np.array(sorted(shapes)); out["mae_depth/digest"] = np.array(digest)
+    taps = m.forward_encoder(imgs)
+    assert isinstance(taps, list) and len(taps) == 4
+    for i, t in enumerate(taps):
+        out[f"mae_depth/tap_sub/{i}"] = t.detach()[:, ::16, ::4].numpy().copy()
+        out[f"mae_depth/tap_norm/{i}"] = np.array(float(t.detach().double().norm()))
+    g = torch.Generator("cpu").manual_seed(45)
+    target = torch.rand(2, 1, 224, 224, generator=g)
+    target = torch.where(torch.rand(2, 1, 224, 224, generator=g) < 0.1, torch.zeros(()), target)
+    pred = m(imgs)
+    loss = ref_loss.ScaleAndShiftInvariantLoss(alpha=0.1)(pred, target)
+    loss.backward()
+    out["mae_depth/pred_sub"] = pred.detach()[:, :, ::2, ::2].numpy().copy()
+    out["mae_depth/pred_norm"] = np.array(float(pred.detach().double().norm()))
+    out["mae_depth/loss"] = np.array(float(loss))
+    pack_grads(out, "mae_depth/", list(m.named_parameters()))
+    out["mae_depth/no_grad_params"] = np.array(sorted(k for k, p in m.named_parameters()
+                                                      if p.requires_grad and p.grad is None))
+    sdo = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        taps_o = mae_ref.vit_trunk(sdo, cfg, imgs, True)
+        pred_o = dpt_ref.dpt_forward({k[len("decoder."):]: v for k, v in sdo.items() if k.startswith("decoder.")},
+                                     taps_o)
+    np.testing.assert_allclose(pred_o.numpy(), pred.detach().numpy(), rtol=1e-3, atol=1e-5)
+    print(f"g11 mae: depth loss={float(loss):.6f} (oracle trunk + DPT agree)")
+    # ---- ViT_from_MoCoV3 (cat cls THEN add the fixed MoCo table, timm _pos_embed; models.py:545-578)
+    m = rm.ViT_from_MoCoV3(None, True, 6, False, None, False, None, 768, "cls")
+    assert not m.pos_embed.requires_grad and m.patch_embed.proj.weight.requires_grad
+    shapes, digest = load_keyed(m, seed=46, keep=("pos_embed",))
+    out["moco_head/keys"] = np.array(sorted(shapes)); out["moco_head/digest"] = np.array(digest)
+    y = m(imgs)
+    (y * wy).sum().backward()
+    out["moco_head/cls"] = y.detach().numpy()
+    pack_grads(out, "moco_head/", list(m.named_parameters()))
+    m.out_token = "spatial"
+    with torch.no_grad():
+        out["moco_head/spatial"] = m(imgs).numpy()
+    # ---- VisionTransformer_from_Any (learned pos_embed incl. the cls row; models.py:325-356)
+    m = rm.VisionTransformer_from_Any(True, 12, False, None, False, None, 768, 12, 12, "cls")
+    shapes, digest = load_keyed(m, seed=47)
+    out["any_head/keys"] = np.array(sorted(shapes)); out["any_head/digest"] = np.array(digest)
+    y = m(imgs)
+    wy12 = torch.randn(y.shape, generator=torch.Generator("cpu").manual_seed(48))
+    (y * wy12).sum().backward()
+    out["any_head/cls"] = y.detach().numpy()
+    pack_grads(out, "any_head/", list(m.named_parameters()))
+    np.savez_compressed(os.path.join(HERE, "g11_vit_api.npz"), **out)
+    print("g11 ok")
+
+
+def resnet_stage_maps(seed, b=2, s=32):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return [torch.relu(torch.randn(b, c, s >> i, s >> i, generator=g)) for i, c in enumerate((256, 512, 1024, 2048))]
+
+
+def g12_resnet_dec():
+    from oracle import dpt_ref, resnet_ref
+    rm = import_reference_models()
+    ref_loss = _load_by_path("ref_losses", os.path.join(REF, "Depth_estimation", "Metrics", "losses.py"))
+    out = {}
+    m = rm.ResNet_from_Any(None, False, 1, False, "depth")
+    assert not any(k.startswith("fc.") for k in m.state_dict())
+    shapes, digest = load_keyed(m, seed=51)
+    out["keys"] = np.array(sorted(shapes)); out["digest"] = np.array(digest)
+    m.train()
+    # ---- (a) decode() on seeded stage maps: the reference's own decoder code (models.py:16-60,128-135)
+    maps = [t.requires_grad_(True) for t in resnet_stage_maps(52)]
+    g = torch.Generator("cpu").manual_seed(53)
+    target = torch.rand(2, 1, 128, 128, generator=g)
+    target = torch.where(torch.rand(2, 1, 128, 128, generator=g) < 0.1, torch.zeros(()), target)
+    pred = m.decode(maps)
+    loss = ref_loss.ScaleAndShiftInvariantLoss(alpha=0.1)(pred, target)
+    loss.backward()
+    out["dec/pred"] = pred.detach().numpy()
+    out["dec/loss"] = np.array(float(loss))
+    pack_grads(out, "dec/", [(k, p) for k, p in m.named_parameters() if p.grad is not None])
+    for i, t in enumerate(maps):
+        out[f"dec/map_grad_norm/{i}"] = np.array(float(t.grad.double().norm()))
+        out[f"dec/map_grad_slice/{i}"] = t.grad[:, :16, :4, :4].numpy().copy()
+    out["dec/running_mean/decoder_levels.0.chan_reduce.1"] = m.decoder_levels[0].chan_reduce[1].running_mean.numpy().copy()
+    out["dec/running_var/decoder_levels.2.blocks.2.process.7"] = m.decoder_levels[2].blocks[2].process[7].running_var.numpy().copy()
+    # oracle (fp64) must agree with the reference's decoder before anything is written
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in synth.keyed_state_dict(shapes, 51).items()}
+    with torch.no_grad():
+        mo = [t.detach().double() for t in maps]
+        o = resnet_ref.dec_level(sd64, "decoder_levels.0", mo[-1], mo[-2])
+        o = resnet_ref.dec_level(sd64, "decoder_levels.1", o, mo[-3])
+        o = resnet_ref.dec_level(sd64, "decoder_levels.2", o, mo[-4])
+        pred_o = resnet_ref.output_head(sd64, o)
+    np.testing.assert_allclose(pred_o.float().numpy(), pred.detach().numpy(), rtol=1e-3, atol=1e-5)
+    print(f"g12 decode: loss={float(loss):.6f} (oracle decoder agrees)")
+    # ---- (b) the whole model (trunk = torchvision restatement, unpinned at that boundary)
+    m.zero_grad(set_to_none=True)
+    load_keyed(m, seed=51)  # reset the running statistics
+    imgs = torch.randn(4, 3, 128, 128, generator=torch.Generator("cpu").manual_seed(54))
+    target = torch.rand(4, 1, 128, 128, generator=torch.Generator("cpu").manual_seed(55))
+    pred = m(imgs)
+    loss = ref_loss.ScaleAndShiftInvariantLoss(alpha=0.1)(pred, target)
+    loss.backward()
+    out["full/pred"] = pred.detach().numpy()
+    out["full/loss"] = np.array(float(loss))
+    pack_grads(out, "full/", list(m.named_parameters()), small=2048)
+    with torch.no_grad():
+        pred_o = resnet_ref.resnet50_dense(sd64, imgs.double())
+    np.testing.assert_allclose(pred_o.float().numpy(), pred.detach().numpy(), rtol=2e-3, atol=1e-4)
+    # ---- (c) classification path: pooled features + linear head (models.py:143-149)
+    m2 = rm.ResNet_from_Any(None, True, 6, False, None)
+    shapes2, digest2 = load_keyed(m2, seed=56)
+    out["cls/keys"] = np.array(sorted(shapes2)); out["cls/digest"] = np.array(digest2)
+    m2.train()
+    y = m2(imgs)
+    out["cls/logits"] = y.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "g12_resnet_dec.npz"), **out)
+    print(f"g12 ok: full loss={float(out['full/loss']):.6f}")
 
 
 def g_lr_sched():
@@ -426,6 +698,7 @@ def main():
         "g1": lambda: g1_masking(ref_mae), "g2": lambda: g2_patchify(ref_mae), "g3": g3_sincos,
         "g5tiny": lambda: g5_tiny(ref_mae), "g5vitb": lambda: g5_vitb(ref_mae),
         "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi, "g8": g8_moco, "g9": g9_dpt_seg,
+        "g3b": g3b_moco_sincos, "g10": g10_det, "g11": g11_vit_api, "g12": g12_resnet_dec,
         "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
             **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
             "g5_curve_tiny.npz"),
