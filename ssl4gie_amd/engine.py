@@ -191,7 +191,8 @@ class StackCfg:
     need_bwd: bool
     sink: GradSink
     lp: LPCache
-    on_block_grads: Optional[Callable[[int], None]] = None  # DDP overlap hook (parallel.py)
+    on_block_grads: Optional[Callable[[int], None]] = None  # optional per-block call-back (unused by
+    # parallel.DataParallel, which takes readiness from autograd's post-accumulate-grad hooks)
 
 
 def _block_params(blk):
@@ -574,7 +575,6 @@ class EngineModule(nn.Module):
         self._arena: Optional[ParamArena] = None
         self._lp = LPCache()
         self._sink = None
-        self._grad_hook = None  # set by parallel.DataParallel
         object.__setattr__(self, "_root", None)  # owning EngineModule when nested (not a child link)
 
     def adopt(self, child: "EngineModule"):
@@ -645,12 +645,4 @@ class EngineModule(nn.Module):
                               self.sink(), self._lp)
 
     def _blocks(self, blocks, x, heads, eps, taps=()):
-        return run_blocks(blocks, x, heads, eps, self.dtype_, self.sink(), taps=taps, lp=self._lp,
-                          on_block_grads=self._grad_hook_for(blocks))
-
-    def _grad_hook_for(self, blocks):
-        h = self._grad_hook
-        if h is None:
-            return None
-        blocks = list(blocks)
-        return lambda i: h(blocks[i])
+        return run_blocks(blocks, x, heads, eps, self.dtype_, self.sink(), taps=taps, lp=self._lp)

@@ -8,14 +8,15 @@ Models/mae/main_pretrain.py:175), the per-step `dist.all_reduce(loss)` + `/world
 
 Design (MI355X-first, not torch DDP's reducer):
   * gradients already live in ONE flat fp32 arena (engine.ParamArena) laid out in registration
-    order, and backward fills it strictly from the end towards the start (decoder_pred ...
+    order, and backward fills it roughly from the end towards the start (decoder_pred ...
     patch_embed).  A bucket is therefore just a contiguous slice [lo, hi) of the arena: no
-    flatten/unflatten copies, no per-parameter hooks;
-  * the block executor calls back after each transformer block's gradients are enqueued; once
-    >= bucket_bytes of arena have become final, the slice is all-reduced on a dedicated comm
-    stream that waits on an event of the compute stream — communication overlaps the rest of
-    backward.  Buckets are large (default 64 MiB): xGMI is point-to-point, few big collectives beat
-    many small ones;
+    flatten/unflatten copies, no per-bucket bookkeeping of parameter lists;
+  * a post-accumulate-grad hook per trainable parameter reports when its gradient is final (all
+    uses of the parameter in this backward have run); once >= bucket_bytes of arena above the
+    frontier have become final, the slice is all-reduced on a dedicated comm stream that waits on
+    an event of the compute stream — communication overlaps the rest of backward for every model
+    (transformer stacks, ResNet50 stages, DPT decoder, two-view wrappers).  Buckets are large
+    (default 64 MiB): xGMI is point-to-point, few big collectives beat many small ones;
   * parameters that never receive a gradient (the reference needs find_unused_parameters=True for
     `norm.*` in dense mode) are simply zeros in the arena: nothing waits for them;
   * averaging (1/world) is folded into the collective when the backend supports ReduceOp.AVG,
@@ -32,7 +33,23 @@ import torch.nn as nn
 
 class DataParallel:
     """Wraps an EngineModule-like model (anything exposing `.arena()` -> ParamArena-like object with
-    `.data`, `.grad`, `.span(params)` and an assignable `_grad_hook`)."""
+    `.data`, `.grad`, `.params`, `.span(params)`, `.grad_view(p)`).
+
+    Readiness is per PARAMETER and comes from autograd itself: a post-accumulate-grad hook on every
+    trainable parameter fires once per backward, after the LAST node that uses the parameter has
+    enqueued its kernels (autograd runs a leaf's AccumulateGrad only when every use has delivered
+    its contribution) — so a parameter used twice in one step (both views of MoCo / Barlow Twins),
+    a parameter of an adopted child module, a convolution or BatchNorm parameter are all handled by
+    the same rule, with no call-backs from the engine.  The arena is walked from its end: the
+    "frontier" is the lowest offset above which every trainable parameter is final (or is known
+    never to receive a gradient: learnt during the first step, the reference's
+    `find_unused_parameters=True`); whenever `bucket_bytes` of final gradients have accumulated above
+    the frontier, that contiguous slice is all-reduced on the comm stream.  Runs of frozen
+    parameters (MoCo's momentum encoder: half the arena) split the arena into segments and are never
+    communicated.  A parameter that turns up after its slice went out (graph changed) is reduced on
+    its own; anything not covered by hooks is covered by finish()."""
+
+    FROZEN_GAP_ELEMS = 1 << 18  # a frozen run >= 1 MiB ends a segment (not worth carrying along)
 
     def __init__(self, model, process_group=None, bucket_bytes: int = 64 << 20,
                  overlap: bool = True, broadcast_parameters: bool = True):
@@ -42,13 +59,16 @@ class DataParallel:
         self.world = dist.get_world_size(process_group)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = overlap
-        self._arena = model.arena()
+        self._arena = None
+        self._hooks: List = []
+        self._handles: List = []
+        self._step = 0
+        self.n_collectives = 0
+        self.n_late = 0  # parameters reduced on their own after their slice had gone out
+        self._bind(model.arena())
         self._is_cuda = self._arena.grad.is_cuda
         self._comm_stream = torch.cuda.Stream() if self._is_cuda else None
-        self._handles: List = []
-        self._hi = self._arena.grad.numel()  # everything in [self._hi, numel) already reduced
         self._avg_op = self._pick_avg_op()
-        self.n_collectives = 0
         if self._is_cuda and self.world > 1:
             # the 256x256 GEMM workgroups own a CU's whole LDS, so RCCL's kernels need CUs of their
             # own while a bucket is in flight: size the persistent GEMM grids for 256 - R CUs
@@ -59,16 +79,62 @@ class DataParallel:
                 _lib.check(_lib.load().ssl4gie_set_compute_cus(256 - r), "set_compute_cus")
         if broadcast_parameters and self.world > 1:
             dist.broadcast(self._arena.data, src=0, group=process_group)
+            # DDP also broadcasts buffers (BatchNorm running statistics) from rank 0
+            for b in (model.buffers() if hasattr(model, "buffers") else ()):
+                if b.numel():
+                    dist.broadcast(b, src=0, group=process_group)
             try:  # the flat buffer was written, not the parameter views: refresh operand caches
                 from .engine import bump_weights_epoch
                 bump_weights_epoch()
             except ImportError:  # toy models of the CPU tests do not load the engine
                 pass
-        model._grad_hook = self._on_module_grads if overlap else None
+
+    # ---------------------------------------------------------------- arena index
+    def _bind(self, arena):
+        """(Re)build the per-parameter index for `arena` and hang the readiness hooks."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._arena = arena
+        spans = []
+        for p in arena.params:
+            lo, hi = arena.span([p])
+            spans.append((lo, hi, p))
+        spans.sort(key=lambda t: -t[0])  # walk order: from the end of the arena
+        # segments = maximal runs of trainable parameters (small frozen gaps are carried along)
+        self._items = []     # trainable only: [lo, hi, param, segment]
+        self._seg_hi = []    # per segment: end offset
+        seg, gap, prev_lo = -1, self.FROZEN_GAP_ELEMS, None
+        for lo, hi, p in spans:
+            if not p.requires_grad:
+                gap += hi - lo
+                continue
+            if gap >= self.FROZEN_GAP_ELEMS or prev_lo is None:
+                seg += 1
+                self._seg_hi.append(hi)
+            gap, prev_lo = 0, lo
+            self._items.append((lo, hi, p, seg))
+        self._index = {id(p): i for i, (_, _, p, _) in enumerate(self._items)}
+        n = len(self._items)
+        self._stamp = [0] * n        # step in which the parameter's hook last fired
+        self._unused = [False] * n   # learnt: never receives a gradient
+        self._learnt = False
+        self._reset_pass()
+        if self.overlap and self.world > 1:
+            for _, _, p, _ in self._items:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_param))
+
+    def _reset_pass(self):
+        self._k = 0                  # items [0, k) are final
+        self._sent = 0               # items [0, sent) have been handed to a collective
+        self._fired = self._late = 0
+        self._step += 1
 
     # the model is used exactly like the wrapped module
     def __call__(self, *a, **k):
-        self._hi = self._arena.grad.numel()
+        arena = self.module.arena()
+        if arena is not self._arena:  # .to() / a new parameter rebuilt the arena
+            self._bind(arena)
         return self.module(*a, **k)
 
     def parameters(self):
@@ -102,22 +168,70 @@ class DataParallel:
             h = dist.all_reduce(g, group=self.pg, async_op=True)
             self._handles.append((h, g))
 
-    def _on_module_grads(self, module: nn.Module):
-        """Engine callback: the gradients of `module` (a Block) and of everything registered after
-        it are enqueued on the compute stream."""
-        ps = [p for p in module.parameters()]
-        if not ps:
+    def _adopt(self, p):
+        """a gradient autograd produced with torch ops (outside the engine's sinks) is moved into the
+        parameter's arena slice, so that it is communicated and the arena optimizers see it"""
+        v = self._arena.grad_view(p)
+        if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)
+            p.grad = v
+
+    def _send(self, upto: int, force: bool = False):
+        """hand items [sent, upto) to collectives: one slice per segment, a slice goes out when it
+        has reached bucket size, when its segment is complete, or when `force`"""
+        items = self._items
+        while self._sent < upto:
+            i = self._sent
+            seg = items[i][3]
+            j = i
+            while j < upto and items[j][3] == seg:
+                j += 1
+            seg_done = j == len(items) or items[j][3] != seg
+            hi = self._seg_hi[seg] if (i == 0 or items[i - 1][3] != seg) else items[i - 1][0]
+            lo = items[j - 1][0]
+            if not (force or seg_done or hi - lo >= self.bucket_elems):
+                return
+            self._reduce_slice(lo, hi)
+            self._sent = j
+
+    def _on_param(self, p):
+        i = self._index.get(id(p))
+        if i is None:
             return
-        lo, _ = self._arena.span(ps)
-        if self._hi - lo >= self.bucket_elems:
-            self._reduce_slice(lo, self._hi)
-            self._hi = lo
+        self._adopt(p)
+        self._stamp[i] = self._step
+        self._fired += 1
+        if i < self._sent:  # its slice has already gone out (a parameter we had learnt as unused)
+            self.n_late += 1
+            self._late += 1
+            self._reduce_slice(self._items[i][0], self._items[i][1])
+            return
+        k, n = self._k, len(self._items)
+        while k < n and (self._stamp[k] == self._step or self._unused[k]):
+            k += 1
+        if k != self._k:
+            self._k = k
+            self._send(k)
+
+    def _on_module_grads(self, module: nn.Module):
+        """Explicit readiness call for models that fill the arena without autograd leaves (kept for
+        callers that drive the engine by hand): marks the module's parameters final."""
+        for p in module.parameters():
+            if p.requires_grad:
+                self._on_param(p)
 
     def finish(self):
-        """Call after loss.backward() and before optimizer.step(): flushes the last bucket and makes
-        the compute stream wait for all communication."""
-        self._reduce_slice(0, self._hi)
-        self._hi = 0
+        """Call after loss.backward() and before optimizer.step(): sends whatever has not gone out
+        yet and makes the compute stream wait for all communication."""
+        if self.world > 1:
+            for _, _, p, _ in self._items[self._sent:]:
+                self._adopt(p)
+            if (not self._learnt or self._late) and self._fired:
+                # first step (or the graph changed): parameters whose hook did not fire do not
+                # take part in this graph
+                self._unused = [s != self._step for s in self._stamp]
+                self._learnt = True
+            self._send(len(self._items), force=True)
         for h, g in self._handles:
             h.wait()
             if self._avg_op is None and self.world > 1:
@@ -125,7 +239,7 @@ class DataParallel:
         self._handles.clear()
         if self._is_cuda:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
-        self._hi = self._arena.grad.numel()
+        self._reset_pass()
 
     # ---------------------------------------------------------------- small collectives
     def all_reduce_mean(self, t: torch.Tensor) -> torch.Tensor:

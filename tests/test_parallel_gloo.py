@@ -18,71 +18,187 @@ def _free_port():
     return p
 
 
-class _Toy(nn.Module):
-    """Stands in for an EngineModule: parameters in registration order, arena, _grad_hook."""
+class _SinkLinearFn(torch.autograd.Function):
+    """CPU stand-in for an engine node: y = x W^T + b whose backward asks the model's GradSink where
+    to put the parameter gradients (arena slice, first use writes / later uses accumulate) exactly
+    like engine.LinearFn does — only the arithmetic is torch instead of the HIP library."""
 
-    def __init__(self):
+    @staticmethod
+    def forward(ctx, x, w, b, sink):
+        ctx.save_for_backward(x, w, b)
+        ctx.sink = sink
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        (tw, tb), acc, rets = ctx.sink.plan([w, b])
+        dw, db = dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1]).sum(0)
+        for t, g in ((tw, dw), (tb, db)):
+            if t is not None:
+                t.add_(g) if acc else t.copy_(g)
+        return dy @ w, rets[0], rets[1], None
+
+
+class _Toy(nn.Module):
+    """Stands in for an EngineModule tree: parameters in registration order in ONE arena, an adopted
+    child (`head`, like the DPT decoder inside ViT_from_MAE) that shares the parent's sink, a frozen
+    twin (`momentum`, like MoCo's momentum encoder) in the middle of the arena, a parameter nothing
+    uses (`unused`, like `norm.*` in dense mode) and one whose gradient comes from plain torch ops
+    (`pos`, like the interpolated pos_embed of the detection trunk)."""
+
+    def __init__(self, width=32, depth=6, frozen=0):
         super().__init__()
-        self.stem = nn.Linear(8, 32)
-        self.blocks = nn.ModuleList([nn.Linear(32, 32) for _ in range(6)])
-        self.head = nn.Linear(32, 4)
-        self._grad_hook = None
+        self.pos = nn.Parameter(torch.zeros(1, width))
+        self.stem = nn.Linear(8, width)
+        self.blocks = nn.ModuleList([nn.Linear(width, width) for _ in range(depth)])
+        self.unused = nn.Linear(width, width)
+        if frozen:
+            self.momentum = nn.Linear(frozen, frozen)
+            for q in self.momentum.parameters():
+                q.requires_grad = False
+        self.head = nn.Module()
+        self.head.fc = nn.Linear(width, 4)
         self._a = None
+        self._s = None
 
     def arena(self):
-        from ssl4gie_amd.engine import ParamArena
+        from ssl4gie_amd.engine import GradSink, ParamArena
         if self._a is None:
             self._a = ParamArena(list(self.parameters()))
+            self._s = GradSink(self._a)
         return self._a
 
+    def _lin(self, x, lin):
+        return _SinkLinearFn.apply(x, lin.weight, lin.bias, self._s)
 
-def _worker(rank, world, port, q):
+    def trunk(self, x):
+        x = self._lin(x, self.stem) + self.pos * 2.0   # torch-op gradient for `pos`
+        for blk in self.blocks:
+            x = torch.tanh(self._lin(x, blk))
+        return self._lin(x, self.head.fc)
+
+    def forward(self, x1, x2=None):
+        self.arena()
+        self._s.new_pass()
+        y = self.trunk(x1)
+        if x2 is not None:  # two views through the SAME parameters (MoCo / Barlow Twins)
+            y = y + 0.5 * self.trunk(x2)
+        return (y ** 2).mean()
+
+
+def _single_process_grads(seed_model, batches, **kw):
+    """gradient of the mean loss over ranks, computed in one process with plain torch parameters"""
+    torch.manual_seed(seed_model)
+    m = _Toy(**kw)
+    total = 0
+    for b in batches:
+        m2 = m
+        x = b[0]
+        def lin(t, l):
+            return t @ l.weight.t() + l.bias
+        def trunk(t):
+            t = lin(t, m2.stem) + m2.pos * 2.0
+            for blk in m2.blocks:
+                t = torch.tanh(lin(t, blk))
+            return lin(t, m2.head.fc)
+        y = trunk(b[0])
+        if len(b) > 1:
+            y = y + 0.5 * trunk(b[1])
+        total = total + (y ** 2).mean() / len(batches)
+    total.backward()
+    return {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+
+
+def _batches(world, two_view):
+    out = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(500 + r)
+        b = [torch.randn(5, 8, generator=g)]
+        if two_view:
+            b.append(torch.randn(5, 8, generator=g))
+        out.append(b)
+    return out
+
+
+def _worker(rank, world, port, q, two_view, frozen, bucket_bytes):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ssl4gie_amd.parallel import DataParallel
     torch.manual_seed(1234 + rank)  # different initial weights per rank: broadcast must fix it
-    m = _Toy()
-    ddp = DataParallel(m, bucket_bytes=4 * 2000, overlap=True)
+    m = _Toy(frozen=frozen)
+    torch.manual_seed(1234)
+    ref_init = _Toy(frozen=frozen)  # rank 0's initial weights
+    ddp = DataParallel(m, bucket_bytes=bucket_bytes, overlap=True)
     a = m.arena()
-    w0 = a.data.clone()
-    gather = [torch.empty_like(w0) for _ in range(world)]
-    dist.all_gather(gather, w0)
-    same_weights = all(torch.equal(gather[0], g) for g in gather)
-    # emulate a backward that fills the arena from the end (head first, stem last)
-    gen = torch.Generator().manual_seed(77 + rank)
-    local = torch.randn(a.grad.numel(), generator=gen)
-    a.grad.copy_(local)
-    for blk in reversed(m.blocks):
-        m._grad_hook(blk)
-    fired_during_backward = ddp.n_collectives
-    ddp.finish()
-    expect = sum(torch.randn(a.grad.numel(), generator=torch.Generator().manual_seed(77 + r))
-                 for r in range(world)) / world
-    ok = torch.allclose(a.grad, expect, rtol=0, atol=1e-6)
+    same_weights = all(torch.equal(p, r) for p, r in zip(m.parameters(), ref_init.parameters()))
+    batches = _batches(world, two_view)
+    expect = _single_process_grads(1234, batches, frozen=frozen)
+    res = []
+    for step in range(3):  # step 0 learns the unused set; steps 1, 2 overlap fully
+        for p in m.parameters():
+            p.grad = None
+        before = ddp.n_collectives
+        loss = ddp(*batches[rank])
+        loss.backward()
+        during = ddp.n_collectives - before
+        ddp.finish()
+        ok = True
+        for k, p in m.named_parameters():
+            e = expect[k]
+            if e is None:
+                ok &= p.grad is None or float(p.grad.abs().max()) == 0.0
+            else:
+                ok &= p.grad is not None and torch.allclose(p.grad, e, rtol=1e-5, atol=1e-7)
+                ok &= p.grad.data_ptr() == a.grad_view(p).data_ptr()  # incl. the adopted torch-op gradient
+        res.append((bool(ok), during, ddp.n_collectives - before, ddp.n_late))
     loss_mean = ddp.all_reduce_mean(torch.tensor([float(rank + 1)]))
-    q.put((rank, same_weights, bool(ok), fired_during_backward, ddp.n_collectives,
-           float(loss_mean)))
+    q.put((rank, same_weights, res, float(loss_mean)))
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_bucketed_allreduce_world2():
+def _run(two_view, frozen, bucket_bytes):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, two_view, frozen, bucket_bytes)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=100) for _ in procs]
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    for rank, same_w, ok, during, total, lm in res:
+    return res
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("two_view", [False, True])
+def test_bucketed_allreduce_world2(two_view):
+    """gradient mean over 2 ranks == single-process gradient of the mean loss, with buckets going out
+    DURING backward — also when every parameter is used twice per step (the slice of a parameter
+    must not go out before its second use has accumulated into it), for the adopted child's and
+    the torch-op-produced gradients, and around a parameter that never receives a gradient"""
+    for rank, same_w, steps, lm in _run(two_view, 0, 4 * 2000):
         assert same_w, "rank-0 parameter broadcast"
-        assert ok, "gradient average"
-        assert during >= 2, "buckets must be launched while backward is still running"
-        assert total == during + 1
+        for ok, during, total, late in steps:
+            assert ok, "gradient average"
+            assert late == 0
+        # step 0: the never-used parameter sits above the blocks and holds the frontier until
+        # finish(); afterwards it is known and most slices leave while backward is still running
+        assert steps[1][1] >= 2 and steps[2][1] >= 2, steps
+        assert steps[1][2] <= steps[1][1] + 1
         assert abs(lm - 1.5) < 1e-6
+
+
+@pytest.mark.timeout(120)
+def test_frozen_run_is_not_communicated_world2():
+    """a large frozen block in the middle of the arena (MoCo's momentum encoder) splits it into
+    segments: trainable slices either side are averaged, the frozen run is never sent"""
+    for rank, same_w, steps, lm in _run(True, 600, 1 << 30):
+        assert same_w
+        for ok, during, total, late in steps:
+            assert ok and late == 0
+            assert total == 2, "one slice per trainable segment (bucket larger than either)"
 
 
 def _syncbn_worker(rank, world, port, q):
