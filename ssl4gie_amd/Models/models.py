@@ -13,9 +13,10 @@ lin_head.*`; ViT_from_MAE keeps `decoder_pos_embed`, reference :395-399).  The u
 (patch-embed GEMM, cls/pos assembly, 12 blocks with taps after blocks 2/5/8/11, final LayerNorm,
 linear head) runs on libssl4gie_hip.so.
 
-Scope (SURVEY §8, rows a8-a12 + §8f rank 2): `dense=None`, `dense="depth"` and `dense="seg"` (DPT
-decoder on the four tap tensors, `Models/DPT_decoder.py`) are complete; `det=True` (windowed
-attention + ViTDet FPN, §8f rank 1) raises NotImplementedError.
+Scope (SURVEY §8, rows a8-a12 + §8f ranks 1-2): `dense=None`, `dense="depth"` and `dense="seg"` (DPT
+decoder on the four tap tensors, `Models/DPT_decoder.py`) and `det=True` (windowed attention by
+token order + `ViTDet_FPN`, reference :155-259) — all pinned against the reference's own classes by
+tests/golden/g10_det.npz, g11_vit_api.npz, g12_resnet_dec.npz.
 """
 from __future__ import annotations
 
@@ -27,7 +28,7 @@ import torch.nn as nn
 
 from collections import OrderedDict
 
-from .. import ops
+from .. import checkpoints, ops
 from ..engine import EngineModule, LinearFn, PatchEmbedFn
 from .DPT_decoder import DPT_decoder
 from .resnet import ResNet50
@@ -85,15 +86,12 @@ class _ViTBackbone(EngineModule):
         return self._ln(tok, self.norm, out_dtype=torch.float32)
 
     # ------------------------------------------------------------------ detection trunk
-    def _pos_embed_interp(self):
+    def _pos_embed_interp(self, pos=None):
         """reference :310-320: the 14 x 14 grid part of pos_embed resized bilinearly
-        (align_corners=True) to the fixed_size / 16 grid -> [1, g*g, D] (torch ops: a 768 x 64 x 64
-        table, differentiable w.r.t. the parameter)"""
-        g = self.fixed_size // 16
-        D = self.embed_dim
-        p2 = self.pos_embed[:, 1:, :].transpose(1, 2).reshape(1, D, 14, 14)
-        p2 = nn.functional.interpolate(p2, size=(g, g), mode="bilinear", align_corners=True)
-        return p2.reshape(1, D, g * g).transpose(1, 2)
+        (align_corners=True) to the fixed_size / 16 grid -> [1, g*g, D] (torch ops on a
+        768 x 14 x 14 table: host-side plumbing, not hot-path arithmetic)"""
+        pos = self.pos_embed if pos is None else pos
+        return _interp_pos(pos, self.fixed_size // 16, self.embed_dim)
 
     def _trunk_det(self, imgs):
         """reference forward_features with det=True (:325-338).  The 16 x 16-token windows of
@@ -110,7 +108,7 @@ class _ViTBackbone(EngineModule):
         perm, inv = window_permutation(g, WINDOW, imgs.device)
         y = PatchEmbedDetFn.apply(imgs.float(), self.patch_embed.proj.weight, self.patch_embed.proj.bias,
                                   perm.unsqueeze(0).repeat(B, 1), 16, self.dtype_, self.sink(), self._lp)
-        x = y.view(B, N, D) + self._pos_embed_interp()[:, perm]
+        x = PosEmbedInterpAddFn.apply(y.view(B, N, D), self.pos_embed, perm, g, D, self.sink())
         nw = N // (WINDOW * WINDOW)
         i = 0
         while i < len(self.blocks):
@@ -150,6 +148,44 @@ class _ViTBackbone(EngineModule):
         if self.det:  # :355-356
             return self.fpn(x)
         return self._readout(x)
+
+
+def _interp_pos(pos, g, D):
+    p2 = pos[:, 1:, :].transpose(1, 2).reshape(1, D, 14, 14)
+    p2 = nn.functional.interpolate(p2, size=(g, g), mode="bilinear", align_corners=True)
+    return p2.reshape(1, D, g * g).transpose(1, 2)
+
+
+class PosEmbedInterpAddFn(torch.autograd.Function):
+    """x = y + interp(pos_embed)[:, perm] for the detection trunk (reference :310-323).  An engine
+    node rather than loose torch ops so that the table's gradient is written through the model's
+    GradSink into the gradient ARENA like every other parameter gradient (data-parallel buckets and
+    the arena optimizers read the arena, not `p.grad` objects autograd allocates elsewhere)."""
+
+    @staticmethod
+    def forward(ctx, y, pos, perm, g, D, sink):
+        with torch.no_grad():
+            table = _interp_pos(pos, g, D)[:, perm]
+        ctx.save_for_backward(pos, perm)
+        ctx.cfg = (g, D, sink)
+        return y + table
+
+    @staticmethod
+    def backward(ctx, dx):
+        pos, perm = ctx.saved_tensors
+        g, D, sink = ctx.cfg
+        (tp,), acc, rets = sink.plan([pos])
+        if tp is not None:
+            drow = torch.empty(g * g, D, dtype=dx.dtype, device=dx.device)
+            drow[perm] = dx.sum(0)  # back to row-major grid order
+            with torch.enable_grad():  # adjoint of the bilinear resize, by autograd on the small table
+                leaf = pos.detach().requires_grad_(True)
+                (gp,) = torch.autograd.grad(_interp_pos(leaf, g, D), leaf, drow[None])
+            if acc:
+                tp.add_(gp)
+            else:
+                tp.copy_(gp)
+        return dx, rets[0], None, None, None, None
 
 
 WINDOW = 16                                   # WindowedAttention(window_size=16), models.py:163
@@ -256,7 +292,7 @@ class ViT_from_MAE(_ViTBackbone):
                     nn.init.xavier_uniform_(m.weight)
                     nn.init.zeros_(m.bias)
         if weight_path is not None:
-            weights = torch.load(weight_path, map_location="cpu")["model"]
+            weights = checkpoints.load_file(weight_path)["model"]  # reference :392-394
             self.load_my_state_dict(weights)
         self._finish(head, num_classes, frozen, dense, det, fixed_size, out_token)
 
@@ -316,7 +352,7 @@ class ViT_from_MoCoV3(_ViTBackbone):
             nn.init.uniform_(self.patch_embed.proj.weight, -val, val)
             nn.init.zeros_(self.patch_embed.proj.bias)
         if weight_path is not None:
-            self.load_state_dict(torch.load(weight_path, map_location="cpu"))
+            self.load_state_dict(checkpoints.load_file(weight_path))  # reference :507-509 (strict)
         self._finish(head, num_classes, frozen, dense, det, fixed_size, out_token)
 
 
@@ -384,7 +420,7 @@ class ResNet_from_Any(ResNet50):
                                "network here — load a state_dict instead")
         self.fc = nn.Identity()
         if weight_path is not None:
-            self.load_state_dict(torch.load(weight_path, map_location="cpu"))
+            self.load_state_dict(checkpoints.load_file(weight_path))  # reference :78-80 (strict)
         self.head = head
         if head:
             self.lin_head = nn.Linear(2048, num_classes)

@@ -22,6 +22,23 @@ from __future__ import annotations
 from collections import OrderedDict
 
 
+def load_file(path, map_location="cpu"):
+    """`torch.load` for checkpoint files written by the reference's scripts.  Those hold more than
+    tensors — MAE saves `'args': argparse.Namespace` (`Models/mae/util/misc.py:301-307`), the finetune
+    apps save Python / NumPy RNG states (`train_depth.py:355-366`) — which torch >= 2.6's default
+    `weights_only=True` rejects.  First try the restricted unpickler with `argparse.Namespace`
+    allow-listed; a file that still needs more (RNG state tuples, numpy arrays) is loaded the way the
+    reference's torch did, unrestricted: these are the user's own training checkpoints."""
+    import argparse
+    import pickle
+    import torch
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location=map_location, weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError):
+        return torch.load(path, map_location=map_location, weights_only=False)
+
+
 def _unwrap(obj):
     """the tensor dict inside any of the wrappers above"""
     if isinstance(obj, dict):

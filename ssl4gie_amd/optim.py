@@ -37,7 +37,7 @@ class _ArenaOptimizer:
         self.param_groups = groups
         self.defaults = dict(defaults)
         self._tables_key = None
-        self._tables = None
+        self._hyper = None
         self.step_count = 0
 
     # ------------------------------------------------------------------ segment tables
@@ -45,9 +45,22 @@ class _ArenaOptimizer:
         a = self.model.arena()
         own = [p for g in self.param_groups for p in g["params"]]
         assert all(a.owns(p) for p in own), "every optimised parameter must live in the model's arena"
+        # a gradient autograd produced with torch ops lives outside the gradient arena the kernels
+        # read: move it into the parameter's slice (parallel.DataParallel does the same)
+        for p in own:
+            if p.grad is not None:
+                v = a.grad_view(p)
+                if p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                    p.grad = v
         return a
 
     def _build_tables(self, a):
+        """device tables [start | lr | wd | is_matrix] per arena parameter.  The layout (start, mat)
+        and the active mask are rebuilt only when the arena or the set of parameters with gradients
+        changes; a per-iteration learning-rate schedule (`lr_sched.adjust_learning_rate`) only
+        rewrites the small pinned host tables and refreshes the device copies with two non-blocking
+        copies on the compute stream — no host synchronisation per step."""
         n = len(a.params)
         group_of = {}
         for gi, g in enumerate(self.param_groups):
@@ -55,22 +68,54 @@ class _ArenaOptimizer:
                 group_of[id(p)] = gi
         active = tuple(id(p) in group_of and p.requires_grad and p.grad is not None for p in a.params)
         hyper = tuple((g["lr"], g["weight_decay"]) for g in self.param_groups)
-        key = (id(a), active, hyper)
-        if key == self._tables_key:
-            return self._tables
-        dev = a.data.device
-        start = torch.tensor(list(a.offsets) + [a.numel], dtype=torch.int64)
-        lr = torch.full((n,), -1.0)
-        wd = torch.zeros(n)
-        mat = torch.zeros(n)
-        for i, p in enumerate(a.params):
-            if active[i]:
-                g = self.param_groups[group_of[id(p)]]
-                lr[i], wd[i] = g["lr"], g["weight_decay"]
-                mat[i] = 1.0 if p.ndim > 1 else 0.0
-        self._tables = tuple(t.to(dev) for t in (start, lr, wd, mat)) + (n,)
-        self._tables_key = key
-        return self._tables
+        layout_key = (id(a), active)
+        if layout_key != self._tables_key:
+            dev = a.data.device
+            pin = dev.type == "cuda"
+            start = torch.tensor(list(a.offsets) + [a.numel], dtype=torch.int64)
+            mat = torch.tensor([1.0 if (active[i] and p.ndim > 1) else 0.0 for i, p in enumerate(a.params)])
+            self._host = (torch.empty(n, pin_memory=pin), torch.empty(n, pin_memory=pin))
+            self._dev = [start.to(dev), torch.empty(n, device=dev), torch.empty(n, device=dev), mat.to(dev)]
+            self._gidx = [group_of.get(id(p), -1) if active[i] else -1 for i, p in enumerate(a.params)]
+            self._tables_key, self._hyper = layout_key, None
+        if hyper != self._hyper:
+            lr_h, wd_h = self._host
+            lrs = [hyper[gi][0] if gi >= 0 else -1.0 for gi in self._gidx]
+            wds = [hyper[gi][1] if gi >= 0 else 0.0 for gi in self._gidx]
+            lr_h.copy_(torch.tensor(lrs))
+            wd_h.copy_(torch.tensor(wds))
+            self._dev[1].copy_(lr_h, non_blocking=True)
+            self._dev[2].copy_(wd_h, non_blocking=True)
+            self._hyper = hyper
+        return tuple(self._dev) + (n,)
+
+    # ------------------------------------------------------------------ checkpointing
+    def _state_buffers(self):
+        raise NotImplementedError
+
+    def state_dict(self):
+        """moments / momentum as flat arena-shaped fp32 tensors + step count + param_groups (without
+        the parameter objects) — what `save_model` (`Models/mae/util/misc.py:301-307`) and
+        `main_moco.py:310-316` store under "optimizer" for `--resume`"""
+        groups = [{k: v for k, v in g.items() if k != "params"} | {"n_params": len(g["params"])}
+                  for g in self.param_groups]
+        return {"kind": type(self).__name__, "step_count": self.step_count, "param_groups": groups,
+                "state": {k: (v.detach().clone() if v is not None else None)
+                          for k, v in self._state_buffers().items()}}
+
+    def load_state_dict(self, sd):
+        assert sd["kind"] == type(self).__name__, (sd["kind"], type(self).__name__)
+        assert len(sd["param_groups"]) == len(self.param_groups)
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            assert saved["n_params"] == len(g["params"]), "parameter groups differ from the saved ones"
+            g.update({k: v for k, v in saved.items() if k != "n_params"})
+        a = self._arena()
+        for k, v in sd["state"].items():
+            if v is not None:
+                assert v.numel() == a.numel, "optimizer state was saved for a different arena layout"
+                setattr(self, k, v.to(a.data.device, torch.float32).clone())
+        self.step_count = int(sd["step_count"])
+        self._hyper = None
 
     def zero_grad(self, set_to_none: bool = True):
         for g in self.param_groups:
@@ -88,6 +133,9 @@ class ArenaAdamW(_ArenaOptimizer):
         super().__init__(model, params, dict(lr=lr, weight_decay=weight_decay))
         self.betas, self.eps = betas, eps
         self.exp_avg = self.exp_avg_sq = None
+
+    def _state_buffers(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
 
     @torch.no_grad()
     def step(self):
@@ -112,6 +160,9 @@ class ArenaLARS(_ArenaOptimizer):
         self.momentum, self.trust = momentum, trust_coefficient
         self.mu = None
         self._ws = None
+
+    def _state_buffers(self):
+        return {"mu": self.mu}
 
     @torch.no_grad()
     def step(self):

@@ -95,21 +95,31 @@ class Subsample2Fn(torch.autograd.Function):
         return ops.subsample2_bwd(dy.contiguous(), *ctx.hw)
 
 
+SYNC_BN_COLLECTIVES = [0]  # collectives issued by SyncBatchNorm layers (read by the rehearsal / tests)
+
+
 def combine_batch_stats(mean_l, var_l, count_l, group=None):
     """Exchange step of SyncBatchNorm: per-rank (mean, biased var, count) -> global (mean, biased var,
     count) by the pooled-variance identity (ranks may hold different row counts).  One all_gather of
-    2C + 1 floats.  Pure torch on [W, 2C+1] floats; runs on gloo for the CPU tests."""
+    2C + 1 floats into one [W, 2C+1] buffer; everything, the total count included,
+    stays on the device (`total` is a 0-d tensor: no host synchronisation per layer).  Pure torch on
+    [W, 2C+1] floats; runs on gloo for the CPU tests."""
     import torch.distributed as dist
     C = mean_l.numel()
-    packed = torch.cat([mean_l, var_l, mean_l.new_tensor([float(count_l)])])
     world = dist.get_world_size(group)
-    gathered = [torch.empty_like(packed) for _ in range(world)]
-    dist.all_gather(gathered, packed, group=group)
-    g = torch.stack(gathered)  # [W, 2C+1]
+    packed = torch.empty(2 * C + 1, dtype=mean_l.dtype, device=mean_l.device)
+    packed[:C] = mean_l
+    packed[C:2 * C] = var_l
+    packed[2 * C] = float(count_l)
+    flat = torch.empty(world * (2 * C + 1), dtype=mean_l.dtype, device=mean_l.device)
+    dist.all_gather_into_tensor(flat, packed, group=group)
+    SYNC_BN_COLLECTIVES[0] += 1
+    g = flat.view(world, 2 * C + 1)
     n = g[:, 2 * C:]           # [W, 1]
     total = n.sum()
-    mean = (g[:, :C] * n).sum(0) / total
-    var = ((g[:, C:2 * C] + (g[:, :C] - mean) ** 2) * n).sum(0) / total
+    wgt = n / total            # [W, 1]
+    mean = (g[:, :C] * wgt).sum(0)
+    var = ((g[:, C:2 * C] + (g[:, :C] - mean) ** 2) * wgt).sum(0)
     return mean, var, total
 
 
@@ -141,7 +151,7 @@ class BatchNormFn(torch.autograd.Function):
         g = gamma.detach() if gamma is not None else None
         b = beta.detach() if beta is not None else None
         sync, group = _sync_group(bn)
-        count = float(x2.shape[0])
+        total = None  # SyncBatchNorm: 0-d device tensor, rows over all ranks
         if training and not sync:
             mom = bn.momentum if bn.momentum is not None else 0.1
             y, mean, rstd = ops.bn_fwd(x2, g, b, r2, bn.running_mean, bn.running_var, mom, bn.eps, relu,
@@ -149,13 +159,12 @@ class BatchNormFn(torch.autograd.Function):
         elif training:
             mean_l, var_l = ops.bn_stats(x2, partials=stats)
             mean, var, total = combine_batch_stats(mean_l, var_l, x2.shape[0], group)
-            count = float(total)
             rstd = torch.rsqrt(var + bn.eps)
             if bn.running_mean is not None:
                 mom = bn.momentum if bn.momentum is not None else 0.1
-                with torch.no_grad():
+                with torch.no_grad():  # unbiased variance: n / (n - 1), on the device
                     bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                    bn.running_var.mul_(1 - mom).add_(var * (count / max(count - 1.0, 1.0)), alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(var * (total / (total - 1.0).clamp_(min=1.0)), alpha=mom)
             y, _, _ = ops.bn_fwd(x2, g, b, r2, None, None, 0.0, bn.eps, relu, False, mean, rstd)
         else:
             mean = bn.running_mean
@@ -164,13 +173,13 @@ class BatchNormFn(torch.autograd.Function):
         if training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
         ctx.save_for_backward(x2, y if relu else None, gamma, beta, mean, rstd)
-        ctx.cfg = (shp, relu, res is not None, sink, training, sync, group, count)
+        ctx.cfg = (shp, relu, res is not None, sink, training, sync, group, total)
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, y, gamma, beta, mean, rstd = ctx.saved_tensors
-        shp, relu, has_res, sink, training, sync, group, count = ctx.cfg
+        shp, relu, has_res, sink, training, sync, group, total = ctx.cfg
         if not training:
             raise NotImplementedError("backward through BatchNorm in eval mode (frozen statistics) is "
                                       "not built: the reference freezes trunks under no_grad")
@@ -191,7 +200,9 @@ class BatchNormFn(torch.autograd.Function):
                         tgt.copy_(sums[row])
             gsums = sums.clone()
             dist.all_reduce(gsums, group=group)
-            dx = ops.bn_bwd_apply(dy2, y, x2, gd, mean, rstd, gsums, 1.0 / count, relu)
+            SYNC_BN_COLLECTIVES[0] += 1
+            gsums /= total  # the 1 / count of the dx formula, folded into the sums on the device
+            dx = ops.bn_bwd_apply(dy2, y, x2, gd, mean, rstd, gsums, 1.0, relu)
         gres = dres.view(shp) if has_res else None
         if gres is not None and ctx.join is not None:
             ctx.join.deposit(gres)  # joined in the data-gradient GEMM of the block's first convolution

@@ -192,3 +192,24 @@ def test_window_permutation_matches_reference_construction_cpu():
             want = (torch.arange(16)[:, None] + 16 * wi) * s + torch.arange(16)[None, :] + 16 * wj
             assert torch.equal(blk, want)
     assert WINDOWED_BLOCKS == det_ref.WINDOWED == (0, 1, 3, 4, 6, 7, 9, 10)
+
+
+def test_checkpoint_files_with_non_tensor_payload_load(tmp_path):
+    """the reference's MAE checkpoints carry `'args': argparse.Namespace` (mae/util/misc.py:301-307)
+    and its finetune checkpoints RNG states (train_depth.py:355-366): torch >= 2.6's default
+    weights_only unpickler rejects both; checkpoints.load_file reads them"""
+    import argparse
+    import random
+    from ssl4gie_amd import checkpoints
+    sd = {"cls_token": torch.randn(1, 1, 8), "blocks.0.norm1.weight": torch.ones(8)}
+    f1 = tmp_path / "mae.pth"
+    torch.save({"model": sd, "optimizer": {}, "epoch": 3, "scaler": {}, "args": argparse.Namespace(lr=1e-3)}, f1)
+    with pytest.raises(Exception):
+        torch.load(f1, map_location="cpu")  # what the round-1 code did
+    ck = checkpoints.load_file(str(f1))
+    assert ck["epoch"] == 3 and torch.equal(ck["model"]["cls_token"], sd["cls_token"]) and ck["args"].lr == 1e-3
+    f2 = tmp_path / "finetune.pth"
+    torch.save({"model_state_dict": sd, "py_state": random.getstate(), "np_state": np.random.get_state(),
+                "torch_state": torch.get_rng_state()}, f2)
+    ck = checkpoints.load_file(str(f2))
+    assert torch.equal(checkpoints._unwrap(ck)["blocks.0.norm1.weight"], sd["blocks.0.norm1.weight"])

@@ -65,6 +65,10 @@ def test_g10_det_trunk_512_matches_reference(prec, tol, gtol):
     assert abs(float(tok.detach().double().norm()) - n) < tol * n
     (tok * wgt.to(DEV)).sum().backward()
     _check_grads(g, "t512/", dict(m.named_parameters()), gtol, DET_NAMES)
+    # the interpolated position table's gradient is written through the GradSink into the arena
+    # (data-parallel buckets and the arena optimizers read the arena, not loose .grad tensors)
+    a = m.arena()
+    assert all(p.grad is None or p.grad.data_ptr() == a.grad_view(p).data_ptr() for p in m.parameters())
 
 
 def test_g10_det_backbone_and_pyramid_1024_matches_reference():

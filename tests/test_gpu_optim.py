@@ -63,13 +63,7 @@ def test_arena_adamw_matches_torch_adamw():
         _fake_grads(m, 10 + step)
         for (n1, p1), (n2, p2) in zip(m.named_parameters(), ref.named_parameters()):
             p2.grad = None if p1.grad is None else p1.grad.clone()
-        # grads must live in the arena for the kernel: copy them into the arena views
-        a = m.arena()
-        for p in m.parameters():
-            if p.grad is not None:
-                v = a.grad_view(p)
-                v.copy_(p.grad)
-                p.grad = v
+        # the gradients were produced outside the arena (plain tensors): step() adopts them
         if step == 2:  # a learning-rate schedule edits param_groups in place
             for g in opt.param_groups + topt.param_groups:
                 g["lr"] = 5e-3
@@ -125,3 +119,32 @@ def test_arena_adamw_trains_mae_and_refreshes_operand_caches():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < 0.9 * losses[0], losses
+
+
+def test_arena_optimizer_state_dict_round_trip():
+    """resume (reference `save_model` / `main_moco.py:310-316` store optimizer.state_dict()): a
+    restored ArenaAdamW / ArenaLARS continues bit-identically"""
+    from ssl4gie_amd.optim import ArenaAdamW, ArenaLARS
+    for cls, kw in ((ArenaAdamW, dict(lr=1e-2, betas=(0.9, 0.95))), (ArenaLARS, dict(lr=0.3, weight_decay=1e-2))):
+        m1 = _toy()
+        m2 = copy.deepcopy(m1)
+        m1.arena(), m2.arena()
+        mk = lambda m: cls(m, _groups(m) if cls is ArenaAdamW else [p for p in m.parameters() if p.requires_grad], **kw)
+        o1 = mk(m1)
+        for step in range(2):
+            _fake_grads(m1, 30 + step)
+            o1.step()
+        sd = o1.state_dict()
+        assert sd["step_count"] == 2 and all(v is not None for v in sd["state"].values())
+        m2.load_state_dict(m1.state_dict())
+        o2 = mk(m2)
+        o2.load_state_dict(sd)
+        for g in o1.param_groups + o2.param_groups:
+            g["lr"] = g["lr"] * 0.5
+        for o, m in ((o1, m1), (o2, m2)):
+            _fake_grads(m, 40)
+            o.step()
+        for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert torch.equal(p1, p2), n1
+        a = m1.arena()
+        assert all(p.grad is None or p.grad.data_ptr() == a.grad_view(p).data_ptr() for p in m1.parameters())
