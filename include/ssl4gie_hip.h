@@ -13,7 +13,9 @@
  *   - returns 0 on success, SSL4GIE_EARG (1000) for an invalid argument, otherwise a hipError_t;
  *   - callable from any host thread; the only mutable process-wide settings are the execution
  *     options ssl4gie_set_wgrad_stream / ssl4gie_set_compute_cus and the profiler;
- *   - ssl4gie_abi_version() = 2 (1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`);
+ *   - ssl4gie_abi_version() = 3 (1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`; 2: before
+ *     ssl4gie_block_bwd's `accumulate` became a flag word and the grouped / deferred weight-gradient
+ *     entry points existed);
  *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
  *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
  */
@@ -140,6 +142,16 @@ int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t workspace_b
 size_t ssl4gie_gemm_tn_pair_workspace_bytes(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b);
 int ssl4gie_gemm_tn_pair(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* n (1..16) weight-gradient (TN) products with the same contraction length K in ONE launch.  With
+ * enough output tiles in the group (>= 70 % of the CUs) every workgroup runs a whole-K tile and
+ * writes C directly: no split-K slabs, no slab reduction — the 8 + 8 products of two encoder blocks
+ * (216 tiles) or four decoder blocks (192 tiles) of the MAE step.  Smaller groups split K like the
+ * pair.  `descs` is an array of n descriptors (alpha / accumulate / colsum_a per product); products
+ * that do not qualify run as n ssl4gie_gemm calls.  Replaces the per-layer autograd weight-gradient
+ * GEMMs of nn.Linear (Models/mae/models_mae.py:39-41,53-55 via timm Block). */
+size_t ssl4gie_gemm_tn_group_workspace_bytes(const ssl4gie_gemm_desc* descs, int n);
+int ssl4gie_gemm_tn_group(const ssl4gie_gemm_desc* descs, int n, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- attention
  * replaces timm Attention.forward == Models/models.py:195-209 minus windowing:
@@ -242,7 +254,12 @@ int ssl4gie_block_fwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* 
                       const ssl4gie_block_act* a, const float* x_in, float* x_out,
                       void* workspace, void* stream);
 /* dx_out fp32 (+ dx_out_lp, its operand-type copy; may be NULL in f32 mode) -> dx_in fp32 and
- * dx_in_lp; parameter grads overwritten (accumulate=0) or accumulated. */
+ * dx_in_lp; parameter grads overwritten or accumulated.  `accumulate` is a flag word:
+ * SSL4GIE_BWD_ACCUMULATE (1) and SSL4GIE_BWD_DEFER_WGRAD (2): with the latter the four weight-gradient
+ * products (and the bias gradients riding on them) are NOT launched; `workspace` then holds their
+ * dY operands and must stay untouched until the caller has launched them (next two entries). */
+#define SSL4GIE_BWD_ACCUMULATE 1
+#define SSL4GIE_BWD_DEFER_WGRAD 2
 int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* w,
                       const ssl4gie_block_act* a, const ssl4gie_block_grads* g,
                       const float* x_in, const float* dx_out, const void* dx_out_lp,
@@ -255,6 +272,21 @@ int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* 
  * on = 0 folds them back onto `stream` (also: environment SSL4GIE_WGRAD_STREAM=0); bench.py does
  * that while it measures per-kernel durations. */
 int ssl4gie_set_wgrad_stream(int on);
+/* Deferred weight gradients: out4[0..3] = the dW_fc2, dW_fc1, dW_proj, dW_qkv product descriptors
+ * of a block whose ssl4gie_block_bwd ran with SSL4GIE_BWD_DEFER_WGRAD on `workspace` (dy = the
+ * dx_out_lp it was given; dx_out in f32 mode).  Collect the descriptors of several blocks and run
+ * them as one ssl4gie_gemm_tn_group: */
+int ssl4gie_block_wgrad_descs(const ssl4gie_block_dims* d, const ssl4gie_block_act* a,
+                              const ssl4gie_block_grads* g, const void* dy, void* workspace,
+                              int accumulate, ssl4gie_gemm_desc* out4);
+/* ssl4gie_gemm_tn_group on the weight-gradient side stream: the side stream first waits for all
+ * work enqueued on `stream` so far, and event `slot` (0..3) then marks the group's completion.
+ * Nothing waits for the group until ssl4gie_wgrad_wait(slot, s) makes stream `s` do so — the caller
+ * must issue that wait before anything reads the gradients or rewrites the operands (block
+ * workspaces, activations).  Without a side stream the group simply runs on `stream`. */
+int ssl4gie_wgrad_group(const ssl4gie_gemm_desc* descs, int n, void* workspace, size_t workspace_bytes,
+                        int slot, void* stream);
+int ssl4gie_wgrad_wait(int slot, void* stream);
 /* Number of CUs the persistent / one-workgroup-per-CU GEMM grids are sized for (8..256, default 240:
  * the weight-gradient side stream shares the chip; environment SSL4GIE_COMPUTE_CUS).  The 256x256 kernels hold all 160 KiB of a CU's LDS, so an RCCL
  * kernel running beside them needs CUs of its own: ssl4gie_amd.parallel reserves a few in

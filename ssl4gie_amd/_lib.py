@@ -13,9 +13,10 @@ LIB_PATH = os.path.join(_HERE, "libssl4gie_hip.so")
 
 # the one copy of the ABI revision on the Python side: build(), the tests and load() compare the
 # library's ssl4gie_abi_version() with it (include/ssl4gie_hip.h documents the history)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F32, BF16 = 0, 1
+BWD_ACCUMULATE, BWD_DEFER_WGRAD = 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX, \
     EPI_RELU_MASK_AUX, EPI_ADD_AUX = range(9)
 
@@ -128,6 +129,12 @@ PROTOTYPES = {
     "ssl4gie_map_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i64, vp]),
     "ssl4gie_gemm_tn_pair_workspace_bytes": (sz, [vp, vp]),
     "ssl4gie_gemm_tn_pair": (i32, [vp, vp, vp, sz, vp]),
+    "ssl4gie_gemm_tn_group_workspace_bytes": (sz, [vp, i32]),
+    "ssl4gie_gemm_tn_group": (i32, [vp, i32, vp, sz, vp]),
+    "ssl4gie_block_wgrad_descs": (i32, [C.POINTER(BlockDims), C.POINTER(BlockAct), C.POINTER(BlockGrads), vp, vp,
+                                        i32, vp]),
+    "ssl4gie_wgrad_group": (i32, [vp, i32, vp, sz, i32, vp]),
+    "ssl4gie_wgrad_wait": (i32, [i32, vp]),
     "ssl4gie_set_wgrad_stream": (i32, [i32]),
     "ssl4gie_set_compute_cus": (i32, [i32]),
     "ssl4gie_prof_begin": (i32, [i32]),

@@ -19,7 +19,7 @@
 #include <mutex>
 #include "prof.h"
 
-extern "C" int ssl4gie_abi_version(void) { return 2; }
+extern "C" int ssl4gie_abi_version(void) { return 3; }
 
 namespace { extern int g_wgrad_stream; }
 // 1: block weight gradients on the library's side stream (default), 0: everything on the caller's
@@ -82,7 +82,10 @@ namespace {
 // folds everything back onto the caller's stream — used when per-kernel durations are measured.
 struct SideStream {
     hipStream_t s = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // 0..4: fork / join points of ssl4gie_block_bwd; 5: fork of ssl4gie_wgrad_group;
+    // 6..9: completion of the group launched with slot 0..3 (ssl4gie_wgrad_wait)
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool slot_used[4] = {false, false, false, false};
 };
 int g_wgrad_stream = -1;  // -1: read the environment on first use
 SideStream* side_stream() {
@@ -100,7 +103,7 @@ SideStream* side_stream() {
     if (!ss->s) {
         hipStream_t st = nullptr;
         if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < 10; ++i) {
             if (hipEventCreateWithFlags(&ss->ev[i], hipEventDisableTiming) != hipSuccess) {
                 (void)hipStreamDestroy(st);
                 return nullptr;
@@ -249,6 +252,10 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     REQUIRE(dims_ok(d) && w && a && g && x_in && dx_out && dx_in && workspace);
     const int T = d->B * d->N, D = d->D, F = d->F, dt = d->dtype;
     REQUIRE(dt == SSL4GIE_F32 || dx_out_lp);
+    // `accumulate` carries flags: bit 0 accumulate, bit 1 SSL4GIE_BWD_DEFER_WGRAD (the caller launches
+    // the four dW products later: ssl4gie_block_wgrad_descs + ssl4gie_wgrad_group)
+    const bool defer = (accumulate & SSL4GIE_BWD_DEFER_WGRAD) != 0;
+    accumulate &= SSL4GIE_BWD_ACCUMULATE;
     const BwdLayout L = bwd_layout(d);
     char* ws = (char*)workspace;
     void* du = ws + L.du;
@@ -263,7 +270,7 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     ssl4gie_gemm_desc e, wg, wg2;
     // weight gradients go to the side stream when there is one (see SideStream)
     hipStream_t main_st = (hipStream_t)stream;
-    SideStream* ss = side_stream();
+    SideStream* ss = defer ? nullptr : side_stream();
     void* wst = ss ? (void*)ss->s : stream;
     int evi = 0;
     auto fork = [&]() -> int {  // side stream: wait for everything enqueued on the caller's so far
@@ -279,10 +286,12 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     e.C = du; e.ldc = F; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_MUL_AUX; e.aux = a->u;
     RC(linear_bwd_data(dy, w->wfc2, w->wfc2_t, T, D, F, dt, e, stream));
     // ---- dW_fc2 and dW_fc1 as one paired launch (both inputs exist once du does)
-    RC(fork());
-    wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, g->bfc2, dt, accumulate);
-    wg2 = wgrad_desc(F, D, T, du, a->h2, g->wfc1, g->bfc1, dt, accumulate);
-    RC(ssl4gie_gemm_tn_pair(&wg, &wg2, gws, L.gemm_ws_bytes, wst));
+    if (!defer) {
+        RC(fork());
+        wg = wgrad_desc(D, F, T, dy, a->g, g->wfc2, g->bfc2, dt, accumulate);
+        wg2 = wgrad_desc(F, D, T, du, a->h2, g->wfc1, g->bfc1, dt, accumulate);
+        RC(ssl4gie_gemm_tn_pair(&wg, &wg2, gws, L.gemm_ws_bytes, wst));
+    }
     // ---- fc1
     memset(&e, 0, sizeof(e));
     e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
@@ -299,10 +308,12 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     RC(ssl4gie_attn_bwd(a->qkv, a->attn, dattn, a->lse, dqkv, dt, d->B, d->N, d->H, D / d->H,
                         ws + L.attn_ws, stream));
     // ---- dW_proj and dW_qkv as one paired launch
-    RC(fork());
-    wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
-    wg2 = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
-    RC(ssl4gie_gemm_tn_pair(&wg, &wg2, gws, L.gemm_ws_bytes, wst));
+    if (!defer) {
+        RC(fork());
+        wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
+        wg2 = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
+        RC(ssl4gie_gemm_tn_pair(&wg, &wg2, gws, L.gemm_ws_bytes, wst));
+    }
     // ---- qkv
     memset(&e, 0, sizeof(e));
     e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
@@ -315,5 +326,46 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
         HIP_RET(hipEventRecord(ss->ev[4], ss->s));
         HIP_RET(hipStreamWaitEvent(main_st, ss->ev[4], 0));
     }
+    return 0;
+}
+
+// ---- deferred weight gradients (SSL4GIE_BWD_DEFER_WGRAD)
+extern "C" int ssl4gie_block_wgrad_descs(const ssl4gie_block_dims* d, const ssl4gie_block_act* a,
+                                         const ssl4gie_block_grads* g, const void* dy, void* workspace,
+                                         int accumulate, ssl4gie_gemm_desc* out4) {
+    REQUIRE(dims_ok(d) && a && g && dy && workspace && out4);
+    const int T = d->B * d->N, D = d->D, F = d->F, dt = d->dtype;
+    const BwdLayout L = bwd_layout(d);
+    char* ws = (char*)workspace;
+    const void* du = ws + L.du;
+    const void* dxmid_lp = (dt == SSL4GIE_F32) ? (const void*)(ws + L.dxmid) : (const void*)(ws + L.dxmid_lp);
+    const void* dqkv = ws + L.dqkv;
+    accumulate &= SSL4GIE_BWD_ACCUMULATE;
+    out4[0] = wgrad_desc(D, F, T, dy, a->g, g->wfc2, g->bfc2, dt, accumulate);
+    out4[1] = wgrad_desc(F, D, T, du, a->h2, g->wfc1, g->bfc1, dt, accumulate);
+    out4[2] = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
+    out4[3] = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
+    return 0;
+}
+
+extern "C" int ssl4gie_wgrad_group(const ssl4gie_gemm_desc* descs, int n, void* workspace,
+                                   size_t workspace_bytes, int slot, void* stream) {
+    REQUIRE(descs && n >= 1 && slot >= 0 && slot < 4);
+    hipStream_t main_st = (hipStream_t)stream;
+    SideStream* ss = side_stream();
+    if (!ss) return ssl4gie_gemm_tn_group(descs, n, workspace, workspace_bytes, stream);
+    HIP_RET(hipEventRecord(ss->ev[5], main_st));        // everything the products read is enqueued
+    HIP_RET(hipStreamWaitEvent(ss->s, ss->ev[5], 0));
+    RC(ssl4gie_gemm_tn_group(descs, n, workspace, workspace_bytes, (void*)ss->s));
+    HIP_RET(hipEventRecord(ss->ev[6 + slot], ss->s));
+    ss->slot_used[slot] = true;
+    return 0;
+}
+
+extern "C" int ssl4gie_wgrad_wait(int slot, void* stream) {
+    REQUIRE(slot >= 0 && slot < 4);
+    SideStream* ss = side_stream();
+    if (!ss || !ss->slot_used[slot]) return 0;
+    HIP_RET(hipStreamWaitEvent((hipStream_t)stream, ss->ev[6 + slot], 0));
     return 0;
 }

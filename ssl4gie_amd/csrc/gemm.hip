@@ -1033,3 +1033,89 @@ extern "C" int ssl4gie_gemm_tn_pair(const ssl4gie_gemm_desc* a, const ssl4gie_ge
     }
     return 0;
 }
+
+// ---- grouped weight-gradient products (ssl4gie_gemm_tn_group)
+static bool tn_group_ok(const ssl4gie_gemm_desc* ds, int n) {
+    if (!ds || n < 1 || n > TN_GROUP_MAX) return false;
+    for (int i = 0; i < n; ++i) {
+        const ssl4gie_gemm_desc* d = &ds[i];
+        if (nt_ok(d) || !tn_ok(d) || d->conv || !ssl4gie_internal_tn256_ok(d) || d->K != ds[0].K ||
+            d->N % 4 != 0 || d->dtype_c != SSL4GIE_F32)
+            return false;
+    }
+    return true;
+}
+struct GroupPlan {
+    int splits;
+    size_t slab_off[TN_GROUP_MAX], cs_off[TN_GROUP_MAX], total;
+};
+static GroupPlan group_plan(const ssl4gie_gemm_desc* ds, int n) {
+    GroupPlan p;
+    p.splits = ssl4gie_internal_tn256_group_splits(ds, n);
+    size_t o = 0;
+    for (int i = 0; i < n; ++i) {
+        p.slab_off[i] = o;
+        if (p.splits > 1) o += al256((size_t)p.splits * ds[i].M * ds[i].N * sizeof(float));
+    }
+    for (int i = 0; i < n; ++i) {
+        p.cs_off[i] = o;
+        if (p.splits > 1 && ds[i].colsum_a) o += al256((size_t)p.splits * ds[i].M * sizeof(float));
+    }
+    p.total = o;
+    return p;
+}
+extern "C" size_t ssl4gie_gemm_tn_group_workspace_bytes(const ssl4gie_gemm_desc* descs, int n) {
+    if (!descs || n < 1) return 0;
+    if (tn_group_ok(descs, n)) return group_plan(descs, n).total;
+    size_t m = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t w = ssl4gie_gemm_workspace_bytes(&descs[i]);
+        if (w > m) m = w;
+    }
+    return m;
+}
+extern "C" int ssl4gie_gemm_tn_group(const ssl4gie_gemm_desc* descs, int n, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    REQUIRE(descs && n >= 1);
+    if (!tn_group_ok(descs, n)) {  // products that do not qualify run one by one
+        for (int i = 0; i < n; ++i) {
+            const int rc = ssl4gie_gemm(&descs[i], workspace, workspace_bytes, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(descs[i].A && descs[i].B && descs[i].C);
+        REQUIRE(!descs[i].colsum_a || descs[i].sAk >= descs[i].M);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const GroupPlan p = group_plan(descs, n);
+    REQUIRE(p.total == 0 || (workspace && workspace_bytes >= p.total));
+    char* ws = (char*)workspace;
+    float* slabs[TN_GROUP_MAX];
+    float* cs[TN_GROUP_MAX];
+    double flops = 0;
+    for (int i = 0; i < n; ++i) {
+        slabs[i] = p.splits > 1 ? (float*)(ws + p.slab_off[i]) : nullptr;
+        cs[i] = (p.splits > 1 && descs[i].colsum_a) ? (float*)(ws + p.cs_off[i]) : nullptr;
+        flops += 2.0 * descs[i].K * (double)descs[i].M * descs[i].N;
+    }
+    {
+        ProfScope prof(PROF_GEMM_TN, flops, st);
+        const int rc = ssl4gie_internal_tn256_launch_group(descs, n, p.splits, slabs, cs, st);
+        if (rc) return rc;
+    }
+    if (p.splits > 1) {
+        for (int i = 0; i < n; ++i) {
+            const ssl4gie_gemm_desc* d = &descs[i];
+            const size_t total4 = (size_t)d->M * d->N / 4;
+            const unsigned c_blocks = (unsigned)((total4 + 255) / 256);
+            const unsigned b_blocks = d->colsum_a ? (unsigned)((d->M + 255) / 256) : 0;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(c_blocks + b_blocks), dim3(256), 0, st,
+                               (const float*)slabs[i], (float*)d->C, d->ldc, d->M, d->N, p.splits, d->alpha,
+                               d->accumulate, (const float*)cs[i], d->colsum_a, c_blocks);
+            LAUNCH_CHECK();
+        }
+    }
+    return 0;
+}

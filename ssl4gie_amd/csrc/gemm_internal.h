@@ -53,8 +53,10 @@ int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d);
 // `slabs` (splits > 1) and `colsum_part` ([splits][M], splits > 1 and d->colsum_a) are workspace
 int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, float* slabs, float* colsum_part,
                                   hipStream_t st);
-// Second problem of a paired launch (two TN products with the same contraction length K share one
-// grid: half the split-K slabs each would need alone).  ntiles == 0: no second problem.
+// Further problems of a grouped launch (TN products with the same contraction length K share one
+// grid: with enough output tiles in the group no split-K slabs are needed at all).  Problem 0 is
+// passed as plain kernel arguments, problems 1..n as this table; `tile0` is the first tile of the
+// problem in the group's tile order, after problem 0's tiles.
 struct TnSecond {
     const void* At; long long ldat;
     const void* Bt; long long ldbt;
@@ -62,7 +64,17 @@ struct TnSecond {
     float* slabs;
     int M, N, tiles_n, ntiles;
     float* colsum; float* colsum_part;
+    float alpha; int accumulate; int tile0;
 };
+#define TN_GROUP_MAX 16
+struct TnExtras {
+    int n, total_tiles;
+    TnSecond p[TN_GROUP_MAX - 1];
+};
+int ssl4gie_internal_tn256_group_splits(const ssl4gie_gemm_desc* descs, int n);
+// slabs[i] / cs[i]: split-K workspace of problem i (splits > 1), cs[i] only if it has colsum_a
+int ssl4gie_internal_tn256_launch_group(const ssl4gie_gemm_desc* descs, int n, int splits,
+                                        float* const* slabs, float* const* cs, hipStream_t st);
 int ssl4gie_internal_tn256_pair_splits(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b);
 int ssl4gie_internal_tn256_launch_pair(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b,
                                        int splits, float* slabs_a, float* cs_a, float* slabs_b,

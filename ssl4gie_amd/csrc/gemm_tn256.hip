@@ -50,22 +50,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     const bf16_t* __restrict__ At, long long ldat, const bf16_t* __restrict__ Bt, long long ldbt,
     float* __restrict__ C, long long ldc, float* __restrict__ slabs, int M, int N, int K,
     int tiles_n, int ntiles, int splits, float alpha, int accumulate, float* __restrict__ colsum,
-    float* __restrict__ colsum_part, ConvK cg, TnSecond sec) {
+    float* __restrict__ colsum_part, ConvK cg, TnExtras ex) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int all_tiles = ntiles + sec.ntiles;
+    const int all_tiles = ntiles + ex.total_tiles;
     const int split = bid / all_tiles;
     int tile = bid % all_tiles;
-    if (tile >= ntiles) {  // paired launch: this workgroup belongs to the second product (uniform)
-        tile -= ntiles;
-        At = (const bf16_t*)sec.At; ldat = sec.ldat;
-        Bt = (const bf16_t*)sec.Bt; ldbt = sec.ldbt;
-        C = sec.C; ldc = sec.ldc; slabs = sec.slabs;
-        M = sec.M; N = sec.N; tiles_n = sec.tiles_n;
-        colsum = sec.colsum; colsum_part = sec.colsum_part;
+    if (tile >= ntiles) {  // grouped launch: this workgroup belongs to a later product (uniform)
+        const int rel = tile - ntiles;
+#pragma unroll
+        for (int i = 0; i < TN_GROUP_MAX - 1; ++i) {
+            if (i < ex.n && rel >= ex.p[i].tile0 && rel < ex.p[i].tile0 + ex.p[i].ntiles) {
+                tile = rel - ex.p[i].tile0;
+                At = (const bf16_t*)ex.p[i].At; ldat = ex.p[i].ldat;
+                Bt = (const bf16_t*)ex.p[i].Bt; ldbt = ex.p[i].ldbt;
+                C = ex.p[i].C; ldc = ex.p[i].ldc; slabs = ex.p[i].slabs;
+                M = ex.p[i].M; N = ex.p[i].N; tiles_n = ex.p[i].tiles_n;
+                colsum = ex.p[i].colsum; colsum_part = ex.p[i].colsum_part;
+                alpha = ex.p[i].alpha; accumulate = ex.p[i].accumulate;
+            }
+        }
     }
     const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * P_BN;
     const int nkt = K / P_BK;
@@ -350,34 +357,64 @@ int ssl4gie_internal_tn256_pair_splits(const ssl4gie_gemm_desc* a, const ssl4gie
     return s;
 }
 
-static int tn256_launch_impl(const ssl4gie_gemm_desc* d, const ssl4gie_gemm_desc* d2, int splits,
-                             float* slabs, float* colsum_part, float* slabs2, float* colsum_part2,
-                             hipStream_t st);
+int ssl4gie_internal_tn256_group_splits(const ssl4gie_gemm_desc* descs, int n) {
+    int tiles = 0;
+    for (int i = 0; i < n; ++i)
+        tiles += ((descs[i].M + P_BM - 1) / P_BM) * ((descs[i].N + P_BN - 1) / P_BN);
+    const int nkt = descs[0].K / P_BK;
+    const int cus = ssl4gie_internal_compute_cus();
+    if (tiles * 10 >= cus * 7) return 1;  // >= 70 % of the CUs busy with whole-K tiles: no slabs at all
+    int s = (cus + tiles / 2) / tiles;
+    if (s > nkt / 8) s = nkt / 8;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, float* const* slabs,
+                             float* const* cs, hipStream_t st);
 
 int ssl4gie_internal_tn256_launch(const ssl4gie_gemm_desc* d, float* slabs, float* colsum_part,
                                   hipStream_t st) {
-    return tn256_launch_impl(d, nullptr, ssl4gie_internal_tn256_splits(d), slabs, colsum_part, nullptr,
-                             nullptr, st);
+    return tn256_launch_impl(d, 1, ssl4gie_internal_tn256_splits(d), &slabs, &colsum_part, st);
 }
 int ssl4gie_internal_tn256_launch_pair(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b,
                                        int splits, float* slabs_a, float* cs_a, float* slabs_b,
                                        float* cs_b, hipStream_t st) {
-    return tn256_launch_impl(a, b, splits, slabs_a, cs_a, slabs_b, cs_b, st);
+    const ssl4gie_gemm_desc ds[2] = {*a, *b};
+    float* sl[2] = {slabs_a, slabs_b};
+    float* cp[2] = {cs_a, cs_b};
+    return tn256_launch_impl(ds, 2, splits, sl, cp, st);
+}
+int ssl4gie_internal_tn256_launch_group(const ssl4gie_gemm_desc* descs, int n, int splits,
+                                        float* const* slabs, float* const* cs, hipStream_t st) {
+    return tn256_launch_impl(descs, n, splits, slabs, cs, st);
 }
 
-static int tn256_launch_impl(const ssl4gie_gemm_desc* d, const ssl4gie_gemm_desc* d2, int splits,
-                             float* slabs, float* colsum_part, float* slabs2, float* colsum_part2,
-                             hipStream_t st) {
+static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, float* const* slabs_v,
+                             float* const* cs_v, hipStream_t st) {
+    if (n < 1 || n > TN_GROUP_MAX) return ARG_ERR;
+    const ssl4gie_gemm_desc* d = &descs[0];
+    float* slabs = slabs_v[0];
+    float* colsum_part = cs_v[0];
     const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + P_BN - 1) / P_BN;
-    TnSecond sec{};
-    if (d2) {
+    TnExtras sec{};
+    bool any_colsum = d->colsum_a != nullptr;
+    for (int i = 1; i < n; ++i) {
+        const ssl4gie_gemm_desc* d2 = &descs[i];
+        if (d2->K != d->K || d2->conv) return ARG_ERR;
         const int tm2 = (d2->M + P_BM - 1) / P_BM, tn2 = (d2->N + P_BN - 1) / P_BN;
-        sec.At = d2->A; sec.ldat = d2->sAk; sec.Bt = d2->B; sec.ldbt = d2->sBk;
-        sec.C = (float*)d2->C; sec.ldc = d2->ldc; sec.slabs = slabs2;
-        sec.M = d2->M; sec.N = d2->N; sec.tiles_n = tn2; sec.ntiles = tm2 * tn2;
-        sec.colsum = d2->colsum_a; sec.colsum_part = colsum_part2;
+        TnSecond& q = sec.p[i - 1];
+        q.At = d2->A; q.ldat = d2->sAk; q.Bt = d2->B; q.ldbt = d2->sBk;
+        q.C = (float*)d2->C; q.ldc = d2->ldc; q.slabs = slabs_v[i];
+        q.M = d2->M; q.N = d2->N; q.tiles_n = tn2; q.ntiles = tm2 * tn2;
+        q.colsum = d2->colsum_a; q.colsum_part = cs_v[i];
+        q.alpha = d2->alpha; q.accumulate = d2->accumulate; q.tile0 = sec.total_tiles;
+        sec.total_tiles += q.ntiles;
+        any_colsum = any_colsum || d2->colsum_a != nullptr;
     }
-    dim3 grid((tm * tn + sec.ntiles) * splits), block(512);
+    sec.n = n - 1;
+    dim3 grid((tm * tn + sec.total_tiles) * splits), block(512);
     ConvK ck{};
     if (d->conv) {
         const int rc = ssl4gie_internal_conv_k(d->conv, &ck);
@@ -398,7 +435,7 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* d, const ssl4gie_gemm_desc
                            colsum_part, ck, sec);                                                  \
     } while (0)
     const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
-    if (d->colsum_a || (d2 && d2->colsum_a)) {
+    if (any_colsum) {
         if (cv == 0) Q_LAUNCH(true, 0);
         else if (cv == 1) Q_LAUNCH(true, 1);
         else Q_LAUNCH(true, 2);

@@ -137,6 +137,14 @@ class GradSink:
         # parameters whose arena slice has been written in the current backward pass while p.grad is
         # still None — i.e. autograd is holding the slice view as their (so far only) contribution
         self._written = set()
+        # optional observer (parallel.DataParallel): called with the parameters of ONE use whose
+        # gradient kernels have just been enqueued — lets buckets leave per transformer block
+        # instead of per autograd node (a whole block stack is a single node)
+        self.tracker = None
+
+    def note_done(self, params):
+        if self.tracker is not None:
+            self.tracker(params)
 
     def new_pass(self):
         """called at the top of every forward: whatever follows belongs to a new backward pass"""
@@ -293,6 +301,35 @@ class BlockStackFn(torch.autograd.Function):
         dx = dx.contiguous()
         pending_tap = tap_g.pop(depth - 1, None)
         dx, dx_lp = ops.add_cast(dx, pending_tap, want_f32=True, lp_dtype=lp)
+        # Deferred weight gradients (bf16 engine, opt-in: _wgrad_group_size): a block's four dW
+        # products only have 48-108 output tiles, so alone (or in pairs) they must split K over the
+        # CUs and pay for fp32 slabs and their reduction.  Here the products of `grp` consecutive
+        # blocks are collected and run as ONE grouped launch with ~200 whole-K tiles — no slabs at
+        # all — on the weight-gradient side stream, beside the next blocks' data-gradient chain.
+        # Every block of a group keeps its own workspace (the products' dY operands live there)
+        # from a ring of 2 groups.
+        grp = _wgrad_group_size(dims, depth) if lp is not None else 0
+        if grp:
+            ring = [ctx.ws] + [torch.empty_like(ctx.ws) for _ in range(2 * grp - 1)]
+            descs = (_lib.GemmDesc * (4 * grp))()
+            gws_bytes, gws = 0, [None, None]
+            pending, keep, n_groups = [], [[], []], 0
+            flags = int(accumulate) | _lib.BWD_DEFER_WGRAD
+
+            def launch_group():
+                nonlocal n_groups, gws_bytes
+                n = 4 * len(pending)
+                slot = n_groups % 2
+                need = L.ssl4gie_gemm_tn_group_workspace_bytes(descs, n)
+                if need and (gws[slot] is None or gws[slot].numel() < need):
+                    gws[slot] = torch.empty(need, dtype=torch.uint8, device=x0.device)
+                _lib.check(L.ssl4gie_wgrad_group(descs, n, ops.ptr(gws[slot]), need, slot, st), "wgrad_group")
+                n_groups += 1
+                done = list(pending)
+                pending.clear()
+                if cfg.on_block_grads is not None:
+                    for j in done:
+                        cfg.on_block_grads(j)
         for i in range(depth - 1, -1, -1):
             if i != depth - 1 and i in tap_g:
                 dx, dx_lp = ops.add_cast(dx, tap_g[i].contiguous(), want_f32=True, lp_dtype=lp)
@@ -309,16 +346,55 @@ class BlockStackFn(torch.autograd.Function):
             a = layout.struct(ctx.acts.data_ptr() + i * layout.total)
             dxn = torch.empty_like(x0)
             dxn_lp = torch.empty(x0.shape, dtype=lp, device=x0.device) if lp else None
-            _lib.check(L.ssl4gie_block_bwd(C.byref(dims), C.byref(ctx.wstructs[i]), C.byref(a),
-                                           C.byref(g), ctx.xs[i].data_ptr(), dx.data_ptr(),
-                                           ops.ptr(dx_lp), dxn.data_ptr(), ops.ptr(dxn_lp),
-                                           int(accumulate), ctx.ws.data_ptr(), st),
-                       f"block_bwd[{i}]")
+            if grp:
+                k = depth - 1 - i                      # blocks done so far
+                if k >= 2 * grp and k % grp == 0:      # about to reuse the workspaces of group k/grp - 2
+                    _lib.check(L.ssl4gie_wgrad_wait((k // grp) % 2, st), "wgrad_wait")
+                    keep[(k // grp) % 2].clear()
+                ws_i = ring[k % (2 * grp)]
+                _lib.check(L.ssl4gie_block_bwd(C.byref(dims), C.byref(ctx.wstructs[i]), C.byref(a),
+                                               C.byref(g), ctx.xs[i].data_ptr(), dx.data_ptr(),
+                                               ops.ptr(dx_lp), dxn.data_ptr(), ops.ptr(dxn_lp),
+                                               flags, ws_i.data_ptr(), st), f"block_bwd[{i}]")
+                _lib.check(L.ssl4gie_block_wgrad_descs(C.byref(dims), C.byref(a), C.byref(g), ops.ptr(dx_lp),
+                                                       ws_i.data_ptr(), int(accumulate),
+                                                       C.byref(descs, 4 * len(pending) * C.sizeof(_lib.GemmDesc))),
+                           f"block_wgrad_descs[{i}]")
+                pending.append(i)
+                keep[(k // grp) % 2] += [dx_lp, scratch]  # dY of dW_fc2 (+ frozen-parameter scratch)
+                if len(pending) == grp or i == 0:
+                    launch_group()
+            else:
+                _lib.check(L.ssl4gie_block_bwd(C.byref(dims), C.byref(ctx.wstructs[i]), C.byref(a),
+                                               C.byref(g), ctx.xs[i].data_ptr(), dx.data_ptr(),
+                                               ops.ptr(dx_lp), dxn.data_ptr(), ops.ptr(dxn_lp),
+                                               int(accumulate), ctx.ws.data_ptr(), st),
+                           f"block_bwd[{i}]")
+                if cfg.on_block_grads is not None:
+                    cfg.on_block_grads(i)
             dx, dx_lp = dxn, dxn_lp
-            if cfg.on_block_grads is not None:
-                cfg.on_block_grads(i)
+        if grp:  # the caller's stream continues after the last weight gradient; operands may go
+            for slot in range(min(n_groups, 2)):
+                _lib.check(L.ssl4gie_wgrad_wait(slot, st), "wgrad_wait")
+            keep[0].clear(); keep[1].clear()
         ctx.acts = ctx.xs = ctx.ws = ctx.keepalive = None
         return (dx, None) + tuple(returns)
+
+
+def _wgrad_group_size(dims, depth: int) -> int:
+    """blocks per grouped weight-gradient launch (SSL4GIE_WGRAD_GROUP = 1..4); 0 / unset = the
+    per-block paired launches.  Measured on the MAE ViT-B step (profiles/r02b_wgrad_group_ab.log):
+    with everything on one stream the grouped launches save 0.8 ms of slab traffic (25.55 -> 24.75 ms),
+    but beside the data-gradient chain the per-block pairs fill the CUs the chain leaves idle far
+    better (24.25 ms) than a burst of ~200 long workgroups every few blocks (24.6 ms) — so the
+    pairs stay the default and the groups are an option for single-stream runs."""
+    env = os.environ.get("SSL4GIE_WGRAD_GROUP", "").strip()
+    if not env:
+        return 0
+    D, F = dims.D, dims.F
+    if D % 4 or F % 4:
+        return 0
+    return max(0, min(int(env), 4, depth))
 
 
 def run_blocks(blocks: Sequence[nn.Module], x: torch.Tensor, heads: int, eps: float, dtype,
@@ -645,4 +721,10 @@ class EngineModule(nn.Module):
                               self.sink(), self._lp)
 
     def _blocks(self, blocks, x, heads, eps, taps=()):
-        return run_blocks(blocks, x, heads, eps, self.dtype_, self.sink(), taps=taps, lp=self._lp)
+        sink = self.sink()
+        hook = None
+        if sink.tracker is not None:
+            blist = list(blocks)
+            hook = lambda i: sink.note_done(_block_params(blist[i]))
+        return run_blocks(blocks, x, heads, eps, self.dtype_, sink, taps=taps, lp=self._lp,
+                          on_block_grads=hook)

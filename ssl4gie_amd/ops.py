@@ -253,6 +253,41 @@ def linear_bwd_weight_pair(dy_a, x_a, dy_b, x_b, bias_a=None, bias_b=None):
     return outs[0], outs[1]
 
 
+def linear_bwd_weight_group(pairs, accumulate_into=None):
+    """n weight-gradient products with the same token count in ONE launch (ssl4gie_gemm_tn_group).
+    pairs: [(dy [T, n_i], x [T, k_i], bias_out or None), ...] -> [dW_i [n_i, k_i]].
+    accumulate_into: optional list of existing fp32 dW tensors to accumulate into (C += dY^T X)."""
+    T = pairs[0][0].shape[0]
+    n = len(pairs)
+    descs = (GemmDesc * n)()
+    outs = []
+    for i, (dy, x, b) in enumerate(pairs):
+        _dev(dy, x, b)
+        assert dy.shape[0] == T and x.shape[0] == T
+        n_out, k_in = dy.shape[1], x.shape[1]
+        if accumulate_into is not None:
+            out = accumulate_into[i]
+            assert out.shape == (n_out, k_in) and out.dtype == torch.float32
+        else:
+            out = torch.empty(n_out, k_in, dtype=torch.float32, device=x.device)
+        d = descs[i]
+        d.M, d.N, d.K, d.batch1, d.batch2 = n_out, k_in, T, 1, 1
+        d.dtype_ab, d.dtype_c, d.alpha, d.epilogue = code(dy.dtype), F32, 1.0, _lib.EPI_NONE
+        d.A, d.sAm, d.sAk = ptr(dy), 1, n_out
+        d.B, d.sBk, d.sBn = ptr(x), k_in, 1
+        d.C, d.ldc = ptr(out), k_in
+        d.accumulate = 1 if accumulate_into is not None else 0
+        if b is not None:
+            assert b.dtype == torch.float32 and b.numel() == n_out
+            d.colsum_a = ptr(b)
+        outs.append(out)
+    L = _lib.load()
+    nbytes = L.ssl4gie_gemm_tn_group_workspace_bytes(descs, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pairs[0][0].device) if nbytes else None
+    _lib.check(L.ssl4gie_gemm_tn_group(descs, n, ptr(ws), nbytes, stream()), "gemm_tn_group")
+    return outs
+
+
 # ------------------------------------------------------------------ attention
 def attn_fwd(qkv, B, N, H, hd):
     _dev(qkv)

@@ -119,6 +119,11 @@ class DataParallel:
         self._stamp = [0] * n        # step in which the parameter's hook last fired
         self._unused = [False] * n   # learnt: never receives a gradient
         self._learnt = False
+        self._uses = [0] * n         # uses reported by the engine (GradSink.tracker) in this pass
+        self._expected = [0] * n     # learnt: uses per backward pass (2 for two-view models)
+        sink = getattr(self.module, "sink", None)
+        if callable(sink) and self.overlap and self.world > 1:
+            sink().tracker = self._on_use_done
         self._reset_pass()
         if self.overlap and self.world > 1:
             for _, _, p, _ in self._items:
@@ -128,6 +133,7 @@ class DataParallel:
         self._k = 0                  # items [0, k) are final
         self._sent = 0               # items [0, sent) have been handed to a collective
         self._fired = self._late = 0
+        self._uses = [0] * len(self._items) if hasattr(self, "_items") else []
         self._step += 1
 
     # the model is used exactly like the wrapped module
@@ -158,6 +164,7 @@ class DataParallel:
         self.n_collectives += 1
         if self._is_cuda:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
+            self._wait_wgrad_stream()
             with torch.cuda.stream(self._comm_stream):
                 if self._avg_op is not None:
                     h = dist.all_reduce(g, op=self._avg_op, group=self.pg, async_op=True)
@@ -167,6 +174,18 @@ class DataParallel:
         else:
             h = dist.all_reduce(g, group=self.pg, async_op=True)
             self._handles.append((h, g))
+
+    def _wait_wgrad_stream(self):
+        """gradients of deferred weight-gradient groups are produced on the library's side stream
+        (ssl4gie_wgrad_group): the comm stream waits for the latest group of either slot"""
+        try:
+            from . import _lib
+            L = _lib.load()
+        except Exception:
+            return
+        cs = self._comm_stream.cuda_stream
+        for slot in (0, 1):
+            L.ssl4gie_wgrad_wait(slot, cs)
 
     def _adopt(self, p):
         """a gradient autograd produced with torch ops (outside the engine's sinks) is moved into the
@@ -194,11 +213,25 @@ class DataParallel:
             self._reduce_slice(lo, hi)
             self._sent = j
 
-    def _on_param(self, p):
+    def _on_use_done(self, params):
+        """engine call-back (GradSink.tracker): the kernels of one use of `params` are enqueued.  A
+        parameter whose learnt number of uses per pass has been reached is final NOW — before
+        autograd gets round to its AccumulateGrad, which for a block stack (one autograd node for
+        8-12 blocks) is only after the whole stack."""
+        for p in params:
+            i = self._index.get(id(p))
+            if i is None:
+                continue
+            self._uses[i] += 1
+            if self._learnt and self._expected[i] and self._uses[i] == self._expected[i]:
+                self._on_param(p, early=True)
+
+    def _on_param(self, p, early=False):
         i = self._index.get(id(p))
-        if i is None:
+        if i is None or self._stamp[i] == self._step:
             return
-        self._adopt(p)
+        if not early:
+            self._adopt(p)
         self._stamp[i] = self._step
         self._fired += 1
         if i < self._sent:  # its slice has already gone out (a parameter we had learnt as unused)
@@ -230,6 +263,7 @@ class DataParallel:
                 # first step (or the graph changed): parameters whose hook did not fire do not
                 # take part in this graph
                 self._unused = [s != self._step for s in self._stamp]
+                self._expected = list(self._uses)
                 self._learnt = True
             self._send(len(self._items), force=True)
         for h, g in self._handles:

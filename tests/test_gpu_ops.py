@@ -483,6 +483,63 @@ def test_weight_gradient_pair_matches_two_products(T, na, ka, nb, kb):
     assert rel_err(wa2, wa) < 1e-6 and rel_err(wb2, wb) < 1e-6
 
 
+@pytest.mark.parametrize("T,shapes", [
+    (12800, [(768, 3072), (3072, 768), (768, 768), (2304, 768)] * 2),   # two encoder blocks: 216 tiles, no split-K
+    (4096, [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),        # one small block: split-K slabs
+    (1024, [(264, 136), (72, 520), (64, 64)]),                          # ragged tiles
+    (200, [(64, 64), (128, 40)])])                                      # K not a multiple of 64: per-product fallback
+def test_weight_gradient_group_matches_single_products(T, shapes):
+    """ssl4gie_gemm_tn_group: n TN products in one launch == each product alone (exact with integer
+    operands), bias gradients riding along, overwrite and accumulate"""
+    from ssl4gie_amd import ops
+    pairs, refs = [], []
+    for j, (n_out, k_in) in enumerate(shapes):
+        dy = ints((T, n_out), 300 + j, -1, 2)
+        x = ints((T, k_in), 400 + j, -2, 3)
+        refs.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+        pairs.append((dy.to(BF).to(DEV), x.to(BF).to(DEV), torch.empty(n_out, device=DEV) if j % 2 == 0 else None))
+    outs = ops.linear_bwd_weight_group(pairs)
+    for (dw, (rw, rb), (_, _, b)) in zip(outs, refs, pairs):
+        assert torch.equal(dw.cpu().double(), rw)
+        if b is not None:
+            assert torch.equal(b.cpu().double(), rb)
+    outs2 = ops.linear_bwd_weight_group(pairs, accumulate_into=[o.clone() for o in outs])
+    for (dw, (rw, rb), (_, _, b)) in zip(outs2, refs, pairs):
+        assert torch.equal(dw.cpu().double(), 2 * rw)
+        if b is not None:
+            assert torch.equal(b.cpu().double(), 2 * rb)
+
+
+@pytest.mark.parametrize("group", [1, 2, 3])
+def test_block_stack_deferred_weight_gradients_match_inline(group, monkeypatch):
+    """BlockStackFn with the weight gradients of `group` blocks collected into one launch on the side
+    stream (SSL4GIE_WGRAD_GROUP) == the per-block paired launches: same outputs, same gradients
+    (bf16 engine; the products are the same sums in a different split-K order)"""
+    import torch.nn as nn
+    from ssl4gie_amd import engine
+    from ssl4gie_amd.Models.vit_layers import Block
+    B, N, D, H, depth = 8, 64, 128, 4, 5
+    torch.manual_seed(3)
+    blocks = nn.ModuleList([Block(D, H, 4.0, qkv_bias=True, norm_layer=lambda d: nn.LayerNorm(d, eps=1e-6))
+                            for _ in range(depth)]).to(DEV)
+    x = torch.randn(B, N, D, generator=G(5)).to(DEV)
+    wgt = torch.randn(B, N, D, generator=G(6)).to(DEV)
+    res = {}
+    for g in (0, group):
+        monkeypatch.setenv("SSL4GIE_WGRAD_GROUP", str(g))
+        for p in blocks.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y, taps = engine.run_blocks(blocks, xi, H, 1e-6, BF, engine.GradSink(None), taps=(1,))
+        ((y * wgt).sum() + taps[0].sum()).backward()
+        torch.cuda.synchronize()
+        res[g] = (y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blocks.parameters()])
+    assert torch.equal(res[0][0], res[group][0])
+    assert rel_err(res[group][1], res[0][1]) < 1e-6
+    for a, b in zip(res[group][2], res[0][2]):
+        assert rel_err(a, b) < 2e-5
+
+
 def test_compute_cus_setting_changes_grids_not_results():
     from ssl4gie_amd import _lib, ops
     L = _lib.load()

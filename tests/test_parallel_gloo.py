@@ -37,6 +37,7 @@ class _SinkLinearFn(torch.autograd.Function):
         for t, g in ((tw, dw), (tb, db)):
             if t is not None:
                 t.add_(g) if acc else t.copy_(g)
+        ctx.sink.note_done([w, b])  # what the block executor reports per transformer block
         return dy @ w, rets[0], rets[1], None
 
 
@@ -68,6 +69,10 @@ class _Toy(nn.Module):
             self._a = ParamArena(list(self.parameters()))
             self._s = GradSink(self._a)
         return self._a
+
+    def sink(self):
+        self.arena()
+        return self._s
 
     def _lin(self, x, lin):
         return _SinkLinearFn.apply(x, lin.weight, lin.bias, self._s)
