@@ -51,9 +51,68 @@ def param_groups(model, wd=0.05):
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": wd}]
 
 
+def host_cores():
+    """threads for the CPU baseline: the physical cores this process may actually use — the smaller
+    of the affinity mask, the distinct (package, core) pairs in /proc/cpuinfo (no SMT siblings) and
+    the cgroup CPU quota (a GPU box hands one job a share of the host, e.g. 16 CPUs of 128: running
+    128 threads on that share is what made round 1's baseline slower than 8 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        phys, pkg = set(), "0"
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                phys.add((pkg, ln.split(":")[1].strip()))
+        if phys:
+            n = min(n, len(phys))
+    except OSError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("SSL4GIE_CPU_THREADS")
+    return max(1, int(env)) if env else max(1, n)
+
+
+def mae_nt_algorithmic_bytes(B, enc=(50, 768, 3072, 12), dec=(197, 512, 2048, 8)):
+    """HBM bytes the NT GEMM launches of one MAE step must move if every operand is read once and
+    every output written once (bf16 operands / activations, fp32 residual stream), averaged per
+    launch: per block forward qkv, proj(+residual), fc1(2 outputs), fc2(+residual) and the four
+    data-gradient products (dfc2 reads the saved GELU derivative)."""
+    total, launches = 0, 0
+    for n, D, F, depth in (enc, dec):
+        T = B * n
+        w = lambda a, b: 2 * a * b
+        per = 0
+        per += 2 * T * D + w(3 * D, D) + 2 * T * 3 * D                 # qkv
+        per += 2 * T * D + w(D, D) + 4 * T * D + 4 * T * D             # proj + fp32 residual in/out
+        per += 2 * T * D + w(F, D) + 2 * 2 * T * F                     # fc1 -> gelu', gelu
+        per += 2 * T * F + w(D, F) + 4 * T * D + 4 * T * D             # fc2 + residual
+        per += 2 * T * D + w(D, F) + 2 * T * F + 2 * T * F             # dfc2 (aux read, du write)
+        per += 2 * T * F + w(F, D) + 2 * T * D                         # dfc1
+        per += 2 * T * D + w(D, D) + 2 * T * D                         # dproj
+        per += 2 * T * 3 * D + w(3 * D, D) + 2 * T * D                 # dqkv
+        total += per * depth
+        launches += 8 * depth
+    T = B * 50
+    total += 2 * T * 768 + 2 * 768 * 768 + 2 * T * 768                 # patch embed (kept patches)
+    total += 2 * T * 768 + 2 * 512 * 768 + 2 * T * 512                 # decoder_embed
+    total += 2 * T * 512 + 2 * 768 * 512 + 2 * T * 768                 # d decoder_embed
+    Td = B * 197
+    total += 2 * Td * 512 + 2 * 768 * 512 + 4 * Td * 768               # decoder_pred (fp32 out)
+    total += 2 * Td * 768 + 2 * 768 * 512 + 2 * Td * 512               # d decoder_pred
+    launches += 5
+    return total, launches
+
+
 def cpu_baseline(steps=8, warmup=2, b=8):
     """CPU oracle step (fwd + bwd + AdamW) on the host cores; bounded sample (~10-30 s)."""
     from oracle import mae_ref, synth
+    torch.set_num_threads(host_cores())
     cfg = mae_ref.MAEConfig(**{**mae_ref.VIT_B.__dict__, "norm_pix_loss": True})
     sd = synth.mae_state_dict(cfg, 0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if "pos_embed" not in k}
@@ -478,8 +537,21 @@ def main():
                 traffic = json.load(f)["hbm_bytes_per_launch"].get(kinds[dom])
         except Exception:
             traffic = None
+        # the same kernel against the HBM roof (these GEMMs sit near the ridge: K = 512 / 768 makes
+        # the epilogue traffic first-order): bytes per launch / average launch duration / 8 TB/s
+        hbm = None
+        if kinds[dom] == "gemm_bf16_nt" and a.workload == "mae":
+            alg_b, alg_n = mae_nt_algorithmic_bytes(a.batch)
+            avg_s = 1e-3 * ms[dom] / max(nl[dom], 1)
+            hbm = {"algorithmic_bytes_per_launch": round(alg_b / alg_n),
+                   "achieved_algorithmic_GBs": round(alg_b / alg_n / avg_s / 1e9, 1),
+                   "achieved_measured_GBs": round(traffic / avg_s / 1e9, 1) if traffic else None,
+                   "peak_GBs": PEAK_HBM_GBS,
+                   "frac_algorithmic": round(alg_b / alg_n / avg_s / 1e9 / PEAK_HBM_GBS, 4),
+                   "frac_measured": round(traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4) if traffic else None}
         roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": round(ach, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "hbm_roof": hbm,
                 "traffic": traffic, "traffic_unit": "HBM bytes/launch (profiles/pmc_traffic.json)",
                 "flops_per_launch": round(fl[dom] / max(nl[dom], 1)),
                 "avg_launch_us": per[kinds[dom]]["avg_launch_us"],

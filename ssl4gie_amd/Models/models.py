@@ -315,9 +315,14 @@ class VisionTransformer_from_Any(_ViTBackbone):
     def __init__(self, head, num_classes, frozen, dense, det, fixed_size, embed_dim, depth,
                  num_heads, out_token, ImageNet_weights=False):
         super().__init__()
-        if ImageNet_weights:
-            raise RuntimeError("ImageNet augreg weights are downloaded by the reference "
-                               "(models.py:286-290); no network here — load a state_dict instead")
+        npz = None
+        if ImageNet_weights:  # reference :286-290 downloads the augreg ViT-B/16 .npz; here: a local file
+            import os
+            npz = os.environ.get("SSL4GIE_AUGREG_NPZ")
+            if not npz or not os.path.exists(npz):
+                raise RuntimeError("ImageNet augreg weights are downloaded by the reference "
+                                   "(models.py:286-290); no network here — point SSL4GIE_AUGREG_NPZ at the "
+                                   "B_16-i21k-300ep-...-res_224.npz file, or load a state_dict instead")
         self._build_trunk(embed_dim, depth, num_heads)
         with torch.no_grad():  # timm default init
             nn.init.trunc_normal_(self.pos_embed, std=.02, a=-2.0, b=2.0)
@@ -326,6 +331,8 @@ class VisionTransformer_from_Any(_ViTBackbone):
                 if isinstance(m, nn.Linear):
                     nn.init.trunc_normal_(m.weight, std=.02, a=-2.0, b=2.0)
                     nn.init.zeros_(m.bias)
+        if npz is not None:
+            checkpoints.load_augreg_npz(self, npz)
         self._finish(head, num_classes, frozen, dense, det, fixed_size, out_token)
 
 

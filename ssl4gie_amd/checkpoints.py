@@ -15,7 +15,12 @@ reference's own scripts do:
   * Barlow Twins (upstream checkpoints): {"model": {"module.backbone.*", "module.projector.*",
     "module.bn.*"}} or a bare ResNet50 state_dict -> backbone tensors without `fc.*`;
   * finetune checkpoints of this repo (`train_depth.py:355-366`): {"model_state_dict": ...} saved
-    from `model.module.state_dict()`.
+    from `model.module.state_dict()`;
+  * ImageNet "augreg" ViT-B/16 weights (`Models/models.py:286-290`): a Flax `.npz` that the reference
+    downloads and hands to timm's `VisionTransformer.load_pretrained` -> `_load_weights`.  timm 0.6.12
+    is pinned (`requirements.txt:7`) but not vendored, so `augreg_npz_to_state_dict` restates its
+    published mapping (names, HWIO -> OIHW, [in, heads, hd] -> [out, in], q/k/v concatenation);
+    there is no network here: the file is read from a local path.
 """
 from __future__ import annotations
 
@@ -97,3 +102,109 @@ def load_matching(model, state_dict, verbose=False):
     if verbose:
         print(f"Successfully loaded params for {len(loaded)} items")
     return loaded, missing, unexpected
+
+
+# ------------------------------------------------------------------ timm "augreg" .npz (Flax) weights
+def _n2p(w, t=True):
+    """timm 0.6.12 vision_transformer._load_weights._n2p: numpy (Flax layout) -> torch layout"""
+    import numpy as np
+    import torch
+    w = np.asarray(w)
+    if w.ndim == 4 and w.shape[0] == w.shape[1] == w.shape[2] == 1:
+        w = w.flatten()
+    if t:
+        if w.ndim == 4:
+            w = w.transpose([3, 2, 0, 1])   # HWIO -> OIHW
+        elif w.ndim == 3:
+            w = w.transpose([2, 0, 1])
+        elif w.ndim == 2:
+            w = w.transpose([1, 0])
+    return torch.from_numpy(np.ascontiguousarray(w))
+
+
+def augreg_npz_to_state_dict(npz, depth=12, prefix=""):
+    """Flax ViT checkpoint (dict-like of numpy arrays, e.g. numpy.load(path)) -> state_dict with the
+    timm / reference names.  Mapping of timm 0.6.12 `_load_weights` for the plain (non-hybrid) ViT:
+    `embedding/{kernel,bias}` -> patch_embed.proj, `cls` -> cls_token,
+    `Transformer/posembed_input/pos_embedding` -> pos_embed, `Transformer/encoder_norm/{scale,bias}` ->
+    norm, `Transformer/encoderblock_i/{LayerNorm_0, MultiHeadDotProductAttention_1/{query,key,value,out},
+    LayerNorm_2, MlpBlock_3/Dense_{0,1}}` -> blocks.i.{norm1, attn.qkv / attn.proj, norm2, mlp.fc1 / fc2}.
+    The classifier (`head/*`, `pre_logits/*`) is not mapped: the reference replaces it (models.py:291)."""
+    import torch
+    w = npz
+    sd = OrderedDict()
+    sd["patch_embed.proj.weight"] = _n2p(w[f"{prefix}embedding/kernel"])
+    sd["patch_embed.proj.bias"] = _n2p(w[f"{prefix}embedding/bias"])
+    sd["cls_token"] = _n2p(w[f"{prefix}cls"], t=False)
+    sd["pos_embed"] = _n2p(w[f"{prefix}Transformer/posembed_input/pos_embedding"], t=False)
+    sd["norm.weight"] = _n2p(w[f"{prefix}Transformer/encoder_norm/scale"])
+    sd["norm.bias"] = _n2p(w[f"{prefix}Transformer/encoder_norm/bias"])
+    for i in range(depth):
+        bp = f"{prefix}Transformer/encoderblock_{i}/"
+        mha = bp + "MultiHeadDotProductAttention_1/"
+        b = f"blocks.{i}."
+        sd[b + "norm1.weight"] = _n2p(w[bp + "LayerNorm_0/scale"])
+        sd[b + "norm1.bias"] = _n2p(w[bp + "LayerNorm_0/bias"])
+        sd[b + "attn.qkv.weight"] = torch.cat(
+            [_n2p(w[mha + n + "/kernel"], t=False).flatten(1).T for n in ("query", "key", "value")])
+        sd[b + "attn.qkv.bias"] = torch.cat(
+            [_n2p(w[mha + n + "/bias"], t=False).reshape(-1) for n in ("query", "key", "value")])
+        sd[b + "attn.proj.weight"] = _n2p(w[mha + "out/kernel"]).flatten(1)
+        sd[b + "attn.proj.bias"] = _n2p(w[mha + "out/bias"])
+        sd[b + "norm2.weight"] = _n2p(w[bp + "LayerNorm_2/scale"])
+        sd[b + "norm2.bias"] = _n2p(w[bp + "LayerNorm_2/bias"])
+        for r in range(2):
+            sd[b + f"mlp.fc{r + 1}.weight"] = _n2p(w[bp + f"MlpBlock_3/Dense_{r}/kernel"])
+            sd[b + f"mlp.fc{r + 1}.bias"] = _n2p(w[bp + f"MlpBlock_3/Dense_{r}/bias"])
+    return OrderedDict((k, v.contiguous().float()) for k, v in sd.items())
+
+
+def state_dict_to_augreg_npz(state_dict, heads=12):
+    """inverse of augreg_npz_to_state_dict (dict of numpy arrays in the Flax layout): lets a model of
+    this repo be exported to the file format the reference downloads, and pins the loader in the tests"""
+    import numpy as np
+    sd = {k: v.detach().cpu().float().numpy() for k, v in state_dict.items()}
+    D = sd["norm.weight"].shape[0]
+    hd = D // heads
+    out = {
+        "embedding/kernel": sd["patch_embed.proj.weight"].transpose(2, 3, 1, 0),  # OIHW -> HWIO
+        "embedding/bias": sd["patch_embed.proj.bias"],
+        "cls": sd["cls_token"],
+        "Transformer/posembed_input/pos_embedding": sd["pos_embed"],
+        "Transformer/encoder_norm/scale": sd["norm.weight"],
+        "Transformer/encoder_norm/bias": sd["norm.bias"],
+    }
+    i = 0
+    while f"blocks.{i}.norm1.weight" in sd:
+        b, bp = f"blocks.{i}.", f"Transformer/encoderblock_{i}/"
+        mha = bp + "MultiHeadDotProductAttention_1/"
+        out[bp + "LayerNorm_0/scale"], out[bp + "LayerNorm_0/bias"] = sd[b + "norm1.weight"], sd[b + "norm1.bias"]
+        out[bp + "LayerNorm_2/scale"], out[bp + "LayerNorm_2/bias"] = sd[b + "norm2.weight"], sd[b + "norm2.bias"]
+        for j, n in enumerate(("query", "key", "value")):
+            wj = sd[b + "attn.qkv.weight"][j * D:(j + 1) * D]            # [out, in]
+            out[mha + n + "/kernel"] = wj.T.reshape(D, heads, hd)          # [in, heads, hd]
+            out[mha + n + "/bias"] = sd[b + "attn.qkv.bias"][j * D:(j + 1) * D].reshape(heads, hd)
+        out[mha + "out/kernel"] = sd[b + "attn.proj.weight"].reshape(D, heads, hd).transpose(1, 2, 0)
+        out[mha + "out/bias"] = sd[b + "attn.proj.bias"]
+        for r in range(2):
+            out[bp + f"MlpBlock_3/Dense_{r}/kernel"] = sd[b + f"mlp.fc{r + 1}.weight"].T
+            out[bp + f"MlpBlock_3/Dense_{r}/bias"] = sd[b + f"mlp.fc{r + 1}.bias"]
+        i += 1
+    return {k: np.ascontiguousarray(v) for k, v in out.items()}
+
+
+def load_augreg_npz(model, path):
+    """`VisionTransformer.load_pretrained(npz)` of the reference's ImageNet path (models.py:286-290):
+    copies the trunk tensors of a Flax ViT-B/16 checkpoint into `model` (the pos_embed must already
+    have the model's token count: 197 for the 224 x 224 / patch 16 file the reference names)."""
+    import numpy as np
+    with np.load(path) as npz:
+        depth = 0
+        while f"Transformer/encoderblock_{depth}/LayerNorm_0/scale" in npz:
+            depth += 1
+        sd = augreg_npz_to_state_dict(npz, depth)
+    own = model.state_dict()
+    for k, v in sd.items():
+        if k in own and tuple(own[k].shape) != tuple(v.shape):
+            raise ValueError(f"{k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}")
+    return load_matching(model, sd)

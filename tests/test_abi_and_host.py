@@ -213,3 +213,33 @@ def test_checkpoint_files_with_non_tensor_payload_load(tmp_path):
                 "torch_state": torch.get_rng_state()}, f2)
     ck = checkpoints.load_file(str(f2))
     assert torch.equal(checkpoints._unwrap(ck)["blocks.0.norm1.weight"], sd["blocks.0.norm1.weight"])
+
+
+def test_augreg_npz_loader_round_trip(tmp_path, monkeypatch):
+    """the Flax `.npz` layout the reference's ImageNet path loads through timm
+    (models.py:286-290).  Export a seeded trunk to that layout, load it back through the loader the
+    `ImageNet_weights=True` constructor uses: every tensor identical; layouts spot-checked against
+    timm 0.6.12's published rules (HWIO conv kernel, [in, heads, hd] attention kernels)."""
+    from oracle import synth
+    from ssl4gie_amd import checkpoints
+    from ssl4gie_amd.Models import models
+    m = models.VisionTransformer_from_Any(False, 0, False, None, False, None, 768, 12, 12, "cls")
+    sd = synth.keyed_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 61)
+    flax = checkpoints.state_dict_to_augreg_npz(sd)
+    assert flax["embedding/kernel"].shape == (16, 16, 3, 768)
+    assert flax["Transformer/encoderblock_3/MultiHeadDotProductAttention_1/key/kernel"].shape == (768, 12, 64)
+    assert flax["Transformer/encoderblock_3/MultiHeadDotProductAttention_1/out/kernel"].shape == (12, 64, 768)
+    assert flax["Transformer/encoderblock_0/MlpBlock_3/Dense_0/kernel"].shape == (768, 3072)
+    # key head h, feature f of the Flax kernel is row D + h*64 + f of timm's fused qkv weight
+    k = flax["Transformer/encoderblock_3/MultiHeadDotProductAttention_1/key/kernel"]
+    assert np.array_equal(k[5, 7, 9], sd["blocks.3.attn.qkv.weight"][768 + 7 * 64 + 9, 5].numpy())
+    path = tmp_path / "B_16.npz"
+    np.savez(path, **flax)
+    monkeypatch.setenv("SSL4GIE_AUGREG_NPZ", str(path))
+    m2 = models.VisionTransformer_from_Any(False, 0, False, None, False, None, 768, 12, 12, "cls", ImageNet_weights=True)
+    got = m2.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(got[k], v), k
+    monkeypatch.delenv("SSL4GIE_AUGREG_NPZ")
+    with pytest.raises(RuntimeError, match="no network"):
+        models.VisionTransformer_from_Any(False, 0, False, None, False, None, 768, 12, 12, "cls", ImageNet_weights=True)
