@@ -9,7 +9,8 @@
  *     caller-allocated and sized by the matching `*_workspace_bytes()` query.  Three objects are
  *     created once per device on first use and live as long as the library: the 256-byte zero page
  *     of the implicit convolution, the weight-gradient side stream + its events
- *     (ssl4gie_set_wgrad_stream), and — opt-in — the launch profiler (ssl4gie_prof_*);
+ *     (ssl4gie_set_wgrad_stream), and — opt-in — the launch profiler (ssl4gie_prof_*); the direct
+ *     all-reduce owns one IPC exchange region per handle (ssl4gie_allreduce_direct_init / _destroy);
  *   - returns 0 on success, SSL4GIE_EARG (1000) for an invalid argument, otherwise a hipError_t;
  *   - callable from any host thread; the only mutable process-wide settings are the execution
  *     options ssl4gie_set_wgrad_stream / ssl4gie_set_compute_cus and the profiler;
@@ -455,6 +456,30 @@ int ssl4gie_map_layernorm_bwd(const void* x, const void* dy, const float* w, con
 int ssl4gie_prof_begin(int max_launches);
 int ssl4gie_prof_collect(double* ms, double* flops, long long* launches);
 int ssl4gie_prof_end(void);
+
+/* ---------------------------------------------------------------- direct xGMI gradient all-reduce
+ * replaces the NCCL bucket all-reduce of DistributedDataParallel (Models/mae/main_pretrain.py:175,
+ * Depth_estimation/train_depth.py:226-229, Models/moco_v3/main_moco.py:208) for ONE node of up to 8
+ * fully connected GPUs: every rank pushes chunk p of a bucket straight into peer p's memory
+ * (reduce-scatter), the owners push the reduced chunks back (all-gather) — one hop, all 7 links at
+ * once, instead of a ring bound by one link.  csrc/allreduce.hip has the protocol.
+ *   init     allocates this rank's exchange region (the ONE allocation this interface makes; sized for
+ *            buckets of up to max_elems fp32) and writes ssl4gie_allreduce_direct_blob_bytes() bytes
+ *            of IPC description to export_blob; the caller exchanges the blobs of all ranks by any
+ *            out-of-band means (ssl4gie_amd.parallel: torch.distributed.all_gather_object);
+ *   connect  maps the peers' regions from the `world` blobs laid end to end in rank order;
+ *   enqueue  grad[0 .. n_elems) <- scale * sum over ranks, in place, on `stream` (5 launches, no host
+ *            synchronisation).  Every rank must enqueue the same sequence of sizes; sums run in rank
+ *            order on every rank, so all ranks end with bitwise identical values;
+ *   destroy  unmaps / frees (after the streams that used the handle have drained). */
+typedef struct ssl4gie_ar_handle ssl4gie_ar_handle;
+size_t ssl4gie_allreduce_direct_blob_bytes(void);
+int ssl4gie_allreduce_direct_init(int rank, int world, size_t max_elems, void* export_blob,
+                                  ssl4gie_ar_handle** out);
+int ssl4gie_allreduce_direct_connect(ssl4gie_ar_handle* h, const void* all_blobs);
+int ssl4gie_allreduce_direct_enqueue(ssl4gie_ar_handle* h, float* grad, size_t n_elems, float scale,
+                                     void* stream);
+int ssl4gie_allreduce_direct_destroy(ssl4gie_ar_handle* h);
 
 #ifdef __cplusplus
 }

@@ -137,6 +137,11 @@ PROTOTYPES = {
     "ssl4gie_wgrad_wait": (i32, [i32, vp]),
     "ssl4gie_set_wgrad_stream": (i32, [i32]),
     "ssl4gie_set_compute_cus": (i32, [i32]),
+    "ssl4gie_allreduce_direct_blob_bytes": (sz, []),
+    "ssl4gie_allreduce_direct_init": (i32, [i32, i32, sz, vp, C.POINTER(vp)]),
+    "ssl4gie_allreduce_direct_connect": (i32, [vp, vp]),
+    "ssl4gie_allreduce_direct_enqueue": (i32, [vp, vp, sz, f32, vp]),
+    "ssl4gie_allreduce_direct_destroy": (i32, [vp]),
     "ssl4gie_prof_begin": (i32, [i32]),
     "ssl4gie_prof_collect": (i32, [vp, vp, vp]),
     "ssl4gie_prof_end": (i32, []),

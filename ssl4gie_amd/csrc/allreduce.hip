@@ -1,0 +1,248 @@
+// Direct (one-hop) gradient all-reduce over xGMI for one node of up to 8 MI355X: reduce-scatter by
+// PUSH + all-gather by PUSH, every rank talking to its 7 peers at once.
+//
+// Why: the 8 GPUs of a node are fully connected, 7 links x ~153 GB/s per GPU.  A ring all-reduce
+// is bound by ONE link (2 (W-1)/W S / BW_link: 446.6 MB of MAE gradients -> ~5.1 ms); with every
+// rank writing chunk p of its bucket straight into peer p's memory, all 7 links carry S/W bytes at
+// the same time (2 (S/W) / BW_link ~ 0.73 ms) — SURVEY §5.  Replaces the NCCL bucket all-reduce of
+// DistributedDataParallel (reference Models/mae/main_pretrain.py:175, Depth_estimation/
+// train_depth.py:226-229, Models/moco_v3/main_moco.py:208); ssl4gie_amd.parallel keeps RCCL as the
+// default transport and selects this one with SSL4GIE_ALLREDUCE=direct.
+//
+// Memory: each rank owns one fine-grained device allocation, exported with hipIpcGetMemHandle and
+// mapped by every peer (hipIpcOpenMemHandle).  Two parities (consecutive buckets alternate) of
+//     slots[W][chunk_cap]   what peer w pushed for MY chunk         (reduce-scatter input)
+//     result[W * chunk_cap] the reduced chunks pushed by their owners (all-gather output)
+// then  flag_a[2][W], flag_b[2][W]  (uint32 sequence numbers).
+//
+// One all-reduce of grad[offset .. offset+n) (same call, same order on every rank; seq = call count):
+//   K1  push   : for every rank p: slots_p[par][me][:] = grad[chunk p]            (remote stores)
+//   K1b signal : flag_a_p[par][me] = seq                                          (system scope)
+//   K2  reduce : wait flag_a_me[par][*] >= seq; r = scale * sum_w slots_me[par][w];
+//                grad[chunk me] = r; for every rank p: result_p[par][chunk me] = r
+//   K2b signal : flag_b_p[par][me] = seq
+//   K3  gather : wait flag_b_me[par][*] >= seq; grad[chunk w] = result_me[par][chunk w], w != me
+// Kernel boundaries on the rank's stream order K1 < K1b < K2 ... and give the data stores their
+// release (a kernel's stores are written back at its end); the flags are stored / polled with
+// system-scope atomics, and the waiting kernels issue a system-scope acquire fence after the
+// poll.  Reuse: parity par is rewritten by the bucket after next; a rank issues that bucket's K1
+// only after its own K3 of this bucket, i.e. after every peer's flag_b — which a peer sets after
+// its K2 has finished reading its slots, and K3 has finished reading result before the next K1.
+// Sums run in rank order w = 0..W-1 on every rank: bitwise identical results everywhere.
+//
+// Validated in this repository on ONE device with two processes mapping each other's regions
+// (tests/test_gpu_allreduce_direct.py): handles, protocol, parity reuse, uneven tails.  It has not
+// run across xGMI (the build box has one GPU).
+#include "common.h"
+#include "ssl4gie_hip.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define AR_MAX_WORLD 8
+
+struct ssl4gie_ar_handle {
+    int rank, world, dev;
+    size_t chunk_cap;       // floats per chunk
+    size_t region_bytes;
+    char* region[AR_MAX_WORLD];  // [rank] = own allocation, others = IPC mappings
+    unsigned seq;
+    bool connected;
+};
+
+struct ArLayout {
+    size_t slots[2], result[2], flag_a, flag_b, total;
+};
+static ArLayout ar_layout(int world, size_t chunk_cap) {
+    ArLayout L;
+    size_t o = 0;
+    for (int p = 0; p < 2; ++p) { L.slots[p] = o; o += (size_t)world * chunk_cap * sizeof(float); }
+    for (int p = 0; p < 2; ++p) { L.result[p] = o; o += (size_t)world * chunk_cap * sizeof(float); }
+    L.flag_a = o; o += 2 * AR_MAX_WORLD * sizeof(unsigned);
+    L.flag_b = o; o += 2 * AR_MAX_WORLD * sizeof(unsigned);
+    L.total = (o + 4095) & ~(size_t)4095;
+    return L;
+}
+
+struct ArPeers {
+    char* region[AR_MAX_WORLD];
+};
+
+// chunk w of a bucket of n floats: [w * per, min(n, (w + 1) * per)), per = ceil(n / W) rounded to 4
+DEVI size_t ar_per(size_t n, int W) { return ((n + W - 1) / W + 3) & ~(size_t)3; }
+
+__global__ void ar_push_kernel(const float* __restrict__ grad, size_t n, int me, int W, ArPeers peers,
+                               size_t slots_off, size_t chunk_cap) {
+    const int p = blockIdx.y;  // destination rank
+    const size_t per = ar_per(n, W);
+    const size_t lo = (size_t)p * per;
+    if (lo >= n) return;
+    const size_t len = (n - lo < per) ? n - lo : per;
+    float* dst = (float*)(peers.region[p] + slots_off) + (size_t)me * chunk_cap;
+    const float* src = grad + lo;
+    const size_t n4 = len / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        ((f32x4*)dst)[i] = ((const f32x4*)src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (len & 3)) dst[n4 * 4 + threadIdx.x] = src[n4 * 4 + threadIdx.x];
+    __threadfence_system();  // this workgroup's XCD writes its lines back before the kernel retires
+}
+
+__global__ void ar_signal_kernel(ArPeers peers, size_t flag_off, int me, int W, unsigned seq) {
+    const int p = threadIdx.x;
+    if (p < W) {
+        unsigned* f = (unsigned*)(peers.region[p] + flag_off) + me;
+        __hip_atomic_store(f, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// every workgroup polls the W flags itself (W loads): no grid-wide dependency
+DEVI void ar_wait(const unsigned* flags, int W, unsigned seq) {
+    if (threadIdx.x < (unsigned)W) {
+        // sequence numbers only grow; the difference is taken modulo 2^32.  The poll is bounded
+        // (~10 s): a peer that died must not leave waves spinning on the device for ever — the
+        // kernel then finishes with stale data and the caller's next collective / check fails
+        long long spins = 0;
+        while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0 &&
+               ++spins < (1ll << 25))
+            __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system-scope acquire: peers' data stores are visible
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+__global__ void ar_reduce_kernel(float* __restrict__ grad, size_t n, int me, int W, ArPeers peers,
+                                 size_t slots_off, size_t result_off, size_t flag_off,
+                                 size_t chunk_cap, float scale, unsigned seq) {
+    ar_wait((const unsigned*)(peers.region[me] + flag_off), W, seq);
+    const size_t per = ar_per(n, W);
+    const size_t lo = (size_t)me * per;
+    if (lo >= n) return;
+    const size_t len = (n - lo < per) ? n - lo : per;
+    const float* slots = (const float*)(peers.region[me] + slots_off);
+    const size_t n4 = (len + 3) / 4;  // slots are padded to chunk_cap (multiple of 4): whole vectors
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 acc = ((const f32x4*)slots)[i];
+        for (int w = 1; w < W; ++w) acc += ((const f32x4*)(slots + (size_t)w * chunk_cap))[i];
+        acc *= scale;
+        for (int p = 0; p < W; ++p)
+            ((f32x4*)((float*)(peers.region[p] + result_off) + (size_t)me * chunk_cap))[i] = acc;
+        const size_t e = 4 * i;
+        if (e + 4 <= len) ((f32x4*)(grad + lo))[i] = acc;
+        else for (size_t j = e; j < len; ++j) grad[lo + j] = acc[j - e];
+    }
+    __threadfence_system();
+}
+
+__global__ void ar_gather_kernel(float* __restrict__ grad, size_t n, int me, int W, ArPeers peers,
+                                 size_t result_off, size_t flag_off, size_t chunk_cap, unsigned seq) {
+    ar_wait((const unsigned*)(peers.region[me] + flag_off), W, seq);
+    const int w = blockIdx.y;
+    if (w == me) return;
+    const size_t per = ar_per(n, W);
+    const size_t lo = (size_t)w * per;
+    if (lo >= n) return;
+    const size_t len = (n - lo < per) ? n - lo : per;
+    const float* src = (const float*)(peers.region[me] + result_off) + (size_t)w * chunk_cap;
+    float* dst = grad + lo;
+    const size_t n4 = len / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        ((f32x4*)dst)[i] = ((const f32x4*)src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (len & 3)) dst[n4 * 4 + threadIdx.x] = src[n4 * 4 + threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t ssl4gie_allreduce_direct_blob_bytes(void) { return sizeof(hipIpcMemHandle_t) + 16; }
+
+extern "C" int ssl4gie_allreduce_direct_init(int rank, int world, size_t max_elems, void* export_blob,
+                                             ssl4gie_ar_handle** out) {
+    REQUIRE(out && export_blob && world >= 1 && world <= AR_MAX_WORLD && rank >= 0 && rank < world &&
+            max_elems > 0);
+    ssl4gie_ar_handle* h = (ssl4gie_ar_handle*)calloc(1, sizeof(ssl4gie_ar_handle));
+    if (!h) return (int)hipErrorOutOfMemory;
+    h->rank = rank; h->world = world;
+    HIP_RET(hipGetDevice(&h->dev));
+    h->chunk_cap = (((max_elems + world - 1) / world + 3) & ~(size_t)3);
+    const ArLayout L = ar_layout(world, h->chunk_cap);
+    h->region_bytes = L.total;
+    // fine-grained device memory: peers' system-scope stores / loads of flags and data are coherent
+    // with this device's caches without waiting for a kernel boundary (what RCCL's p2p buffers use)
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, L.total, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, L.total); }
+    if (e != hipSuccess) { free(h); return (int)e; }
+    e = hipMemset(p, 0, L.total);
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // zeroed flags are visible before anyone maps them
+    if (e != hipSuccess) { (void)hipFree(p); free(h); return (int)e; }
+    h->region[rank] = (char*)p;
+    hipIpcMemHandle_t ipc;
+    e = hipIpcGetMemHandle(&ipc, p);
+    if (e != hipSuccess) { (void)hipFree(p); free(h); return (int)e; }
+    memset(export_blob, 0, ssl4gie_allreduce_direct_blob_bytes());
+    memcpy(export_blob, &ipc, sizeof(ipc));
+    unsigned long long meta[2] = {(unsigned long long)h->chunk_cap, (unsigned long long)world};
+    memcpy((char*)export_blob + sizeof(ipc), meta, 16);
+    *out = h;
+    return 0;
+}
+
+extern "C" int ssl4gie_allreduce_direct_connect(ssl4gie_ar_handle* h, const void* all_blobs) {
+    REQUIRE(h && all_blobs && !h->connected);
+    const size_t bb = ssl4gie_allreduce_direct_blob_bytes();
+    for (int p = 0; p < h->world; ++p) {
+        const char* blob = (const char*)all_blobs + (size_t)p * bb;
+        unsigned long long meta[2];
+        memcpy(meta, blob + sizeof(hipIpcMemHandle_t), 16);
+        REQUIRE(meta[0] == h->chunk_cap && meta[1] == (unsigned long long)h->world);  // same sizes everywhere
+        if (p == h->rank) continue;
+        hipIpcMemHandle_t ipc;
+        memcpy(&ipc, blob, sizeof(ipc));
+        void* q = nullptr;
+        HIP_RET(hipIpcOpenMemHandle(&q, ipc, hipIpcMemLazyEnablePeerAccess));
+        h->region[p] = (char*)q;
+    }
+    h->connected = true;
+    return 0;
+}
+
+extern "C" int ssl4gie_allreduce_direct_enqueue(ssl4gie_ar_handle* h, float* grad, size_t n_elems,
+                                                float scale, void* stream) {
+    REQUIRE(h && h->connected && grad);
+    if (n_elems == 0) return 0;
+    REQUIRE(n_elems <= h->chunk_cap * (size_t)h->world && ((uintptr_t)grad & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int W = h->world, me = h->rank;
+    const unsigned seq = ++h->seq;
+    const int par = seq & 1;
+    const ArLayout L = ar_layout(W, h->chunk_cap);
+    ArPeers peers;
+    for (int p = 0; p < AR_MAX_WORLD; ++p) peers.region[p] = p < W ? h->region[p] : nullptr;
+    const size_t per = (((n_elems + W - 1) / W + 3) & ~(size_t)3);
+    unsigned bx = (unsigned)((per / 4 + 255) / 256);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;  // 64 x W workgroups keep 7 links busy and leave the CUs to backward
+    const size_t fa = L.flag_a + (size_t)par * AR_MAX_WORLD * sizeof(unsigned);
+    const size_t fb = L.flag_b + (size_t)par * AR_MAX_WORLD * sizeof(unsigned);
+    hipLaunchKernelGGL(ar_push_kernel, dim3(bx, W), dim3(256), 0, st, (const float*)grad, n_elems, me, W, peers,
+                       L.slots[par], h->chunk_cap);
+    hipLaunchKernelGGL(ar_signal_kernel, dim3(1), dim3(64), 0, st, peers, fa, me, W, seq);
+    hipLaunchKernelGGL(ar_reduce_kernel, dim3(bx * 2), dim3(256), 0, st, grad, n_elems, me, W, peers, L.slots[par],
+                       L.result[par], fa, h->chunk_cap, scale, seq);
+    hipLaunchKernelGGL(ar_signal_kernel, dim3(1), dim3(64), 0, st, peers, fb, me, W, seq);
+    hipLaunchKernelGGL(ar_gather_kernel, dim3(bx, W), dim3(256), 0, st, grad, n_elems, me, W, peers, L.result[par],
+                       fb, h->chunk_cap, seq);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ssl4gie_allreduce_direct_destroy(ssl4gie_ar_handle* h) {
+    if (!h) return 0;
+    int rc = 0;
+    for (int p = 0; p < h->world; ++p) {
+        if (!h->region[p]) continue;
+        const hipError_t e = (p == h->rank) ? hipFree(h->region[p]) : hipIpcCloseMemHandle(h->region[p]);
+        if (e != hipSuccess && !rc) rc = (int)e;
+    }
+    free(h);
+    return rc;
+}

@@ -69,6 +69,11 @@ class DataParallel:
         self._is_cuda = self._arena.grad.is_cuda
         self._comm_stream = torch.cuda.Stream() if self._is_cuda else None
         self._avg_op = self._pick_avg_op()
+        # transport of the bucket all-reduce: RCCL (default) or the library's direct xGMI exchange
+        self._direct = None
+        import os
+        if self._is_cuda and self.world > 1 and os.environ.get("SSL4GIE_ALLREDUCE", "rccl").lower() == "direct":
+            self._direct = DirectAllReduce(min(self.bucket_elems * 2, self._arena.grad.numel()), process_group)
         if self._is_cuda and self.world > 1:
             # the 256x256 GEMM workgroups own a CU's whole LDS, so RCCL's kernels need CUs of their
             # own while a bucket is in flight: size the persistent GEMM grids for 256 - R CUs
@@ -165,6 +170,9 @@ class DataParallel:
         if self._is_cuda:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             self._wait_wgrad_stream()
+            if self._direct is not None:
+                self._direct.all_reduce_(g, 1.0 / self.world, self._comm_stream)
+                return
             with torch.cuda.stream(self._comm_stream):
                 if self._avg_op is not None:
                     h = dist.all_reduce(g, op=self._avg_op, group=self.pg, async_op=True)
@@ -283,6 +291,47 @@ class DataParallel:
         t = t.detach().clone()
         dist.all_reduce(t, group=self.pg)
         return t / self.world
+
+
+class DirectAllReduce:
+    """ssl4gie_allreduce_direct_* behind the interface DataParallel needs: one-hop reduce-scatter +
+    all-gather over the node's xGMI links by peer-to-peer stores (csrc/allreduce.hip).  The IPC
+    descriptions of the ranks' exchange regions travel through torch.distributed (any backend)."""
+
+    def __init__(self, max_elems: int, process_group=None):
+        import ctypes as C
+        from . import _lib
+        self.L = _lib.load()
+        self._check = _lib.check
+        self.rank = dist.get_rank(process_group)
+        self.world = dist.get_world_size(process_group)
+        nb = self.L.ssl4gie_allreduce_direct_blob_bytes()
+        blob = C.create_string_buffer(nb)
+        self.h = C.c_void_p()
+        self._check(self.L.ssl4gie_allreduce_direct_init(self.rank, self.world, int(max_elems), blob, C.byref(self.h)),
+                    "allreduce_direct_init")
+        blobs = [None] * self.world
+        dist.all_gather_object(blobs, bytes(blob.raw), group=process_group)
+        self._check(self.L.ssl4gie_allreduce_direct_connect(self.h, b"".join(blobs)), "allreduce_direct_connect")
+        dist.barrier(group=process_group)  # every rank has mapped every region before the first push
+        self.max_elems = int(max_elems)
+
+    def all_reduce_(self, t: torch.Tensor, scale: float, stream=None):
+        """t (fp32, contiguous, 16-byte aligned) <- scale * sum over ranks, enqueued on `stream`"""
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        n, off = t.numel(), 0
+        while off < n:  # larger than the exchange region: several rounds
+            m = min(self.max_elems, n - off)
+            self._check(self.L.ssl4gie_allreduce_direct_enqueue(self.h, t.data_ptr() + 4 * off, m, float(scale), st),
+                        "allreduce_direct_enqueue")
+            off += m
+
+    def close(self):
+        if self.h:
+            torch.cuda.synchronize()
+            self.L.ssl4gie_allreduce_direct_destroy(self.h)
+            self.h = None
 
 
 def comm_cus() -> int:

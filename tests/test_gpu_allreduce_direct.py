@@ -1,0 +1,155 @@
+"""GPU: the direct gradient all-reduce (csrc/allreduce.hip, ssl4gie_allreduce_direct_*) rehearsed by TWO
+processes on ONE device: each maps the other's exchange region through HIP IPC handles and runs the
+push / signal / reduce / gather protocol.  The build box has a single GPU, so this checks handles,
+the flag protocol, parity reuse over consecutive buckets, tails and multi-round buckets — not xGMI
+transport.  Also: DataParallel with SSL4GIE_ALLREDUCE=direct == the gloo/RCCL path on a toy arena."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _expect(n, seed, world):
+    return sum(torch.randn(n, generator=torch.Generator().manual_seed(seed * 10 + r)) for r in range(world))
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from ssl4gie_amd.parallel import DirectAllReduce
+    ok, detail = True, []
+    try:
+        ar = DirectAllReduce(max_elems=1 << 20)
+        # consecutive buckets of different sizes (parity reuse), tails that are not multiples of 4 or
+        # of the world size, a one-element bucket, and one larger than the exchange region (3 rounds)
+        for it, n in enumerate([1 << 20, 1000003, 4096, 7, 1, 5, (1 << 20) * 2 + 12345, 64, 1 << 18]):
+            g = torch.randn(n, generator=torch.Generator().manual_seed(it * 10 + rank)).cuda()
+            ar.all_reduce_(g, 0.5)
+            torch.cuda.synchronize()
+            ref = 0.5 * _expect(n, it, world)
+            err = float((g.cpu() - ref).abs().max())
+            detail.append((n, err))
+            ok &= err <= 1e-6
+        # many small buckets back to back without host synchronisation in between
+        bufs = [torch.full((257,), float(rank + 1 + i), device="cuda") for i in range(40)]
+        for b in bufs:
+            ar.all_reduce_(b, 1.0)
+        torch.cuda.synchronize()
+        for i, b in enumerate(bufs):
+            ok &= bool((b == float(sum(r + 1 + i for r in range(world)))).all())
+        # identical bits on every rank (same summation order everywhere)
+        g = torch.randn(99999, generator=torch.Generator().manual_seed(777 + rank)).cuda()
+        ar.all_reduce_(g, 1.0 / world)
+        torch.cuda.synchronize()
+        mine = g.cpu()
+        others = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(others, mine)
+        ok &= all(torch.equal(o, others[0]) for o in others)
+        ar.close()
+    except Exception as e:  # noqa
+        ok, detail = False, repr(e)
+    q.put((rank, ok, detail))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_direct_allreduce_two_processes_one_device():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, detail in res:
+        assert ok, (rank, detail)
+
+
+def _dp_worker(rank, world, port, q, transport):
+    import torch.distributed as dist
+    import torch.nn as nn
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SSL4GIE_ALLREDUCE=transport,
+                      SSL4GIE_COMM_CUS="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from ssl4gie_amd.engine import ParamArena
+    from ssl4gie_amd.parallel import DataParallel
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = nn.ModuleList([nn.Linear(96, 96) for _ in range(6)])
+            self._a = None
+
+        def arena(self):
+            if self._a is None:
+                self._a = ParamArena(list(self.parameters()))
+            return self._a
+
+        def forward(self, x):
+            for l in self.layers:
+                x = torch.tanh(l(x))
+            return (x ** 2).mean()
+
+    torch.manual_seed(5)
+    m = Toy().cuda()
+    ddp = DataParallel(m, bucket_bytes=4 * 20000)
+    x = torch.randn(16, 96, generator=torch.Generator().manual_seed(100 + rank)).cuda()
+    out = []
+    for step in range(3):
+        for p in m.parameters():
+            p.grad = None
+        ddp(x).backward()
+        ddp.finish()
+        torch.cuda.synchronize()
+        out.append(torch.cat([p.grad.flatten() for p in m.parameters()]).cpu())
+    q.put((rank, transport, out, ddp.n_collectives))
+    if ddp._direct is not None:
+        ddp._direct.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_direct_transport_equals_default():
+    """same toy, same data: gradients after DataParallel.finish() with the direct transport == with
+    torch.distributed's all-reduce (gloo here), bucket slices going out during backward"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    results = {}
+    for transport in ("rccl", "direct"):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, transport)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=240) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+        results[transport] = {r: (out, n) for r, _, out, n in res}
+    for r in (0, 1):
+        a, na = results["rccl"][r]
+        b, nb = results["direct"][r]
+        assert na == nb and na >= 3
+        for ga, gb in zip(a, b):
+            assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-8)
+    assert all(torch.equal(x, y) for x, y in zip(results["direct"][0][0], results["direct"][1][0]))
