@@ -6,6 +6,7 @@ transport.  Also: DataParallel with SSL4GIE_ALLREDUCE=direct == the gloo/RCCL pa
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 
@@ -120,7 +121,7 @@ def _dp_worker(rank, world, port, q, transport):
         ddp(x).backward()
         ddp.finish()
         torch.cuda.synchronize()
-        out.append(torch.cat([p.grad.flatten() for p in m.parameters()]).cpu())
+        out.append(torch.cat([p.grad.flatten() for p in m.parameters()]).cpu().numpy())  # by value
     q.put((rank, transport, out, ddp.n_collectives))
     if ddp._direct is not None:
         ddp._direct.close()
@@ -151,5 +152,5 @@ def test_data_parallel_direct_transport_equals_default():
         b, nb = results["direct"][r]
         assert na == nb and na >= 3
         for ga, gb in zip(a, b):
-            assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-8)
-    assert all(torch.equal(x, y) for x, y in zip(results["direct"][0][0], results["direct"][1][0]))
+            assert np.allclose(ga, gb, rtol=1e-6, atol=1e-8)
+    assert all(np.array_equal(x, y) for x, y in zip(results["direct"][0][0], results["direct"][1][0]))
