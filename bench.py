@@ -41,6 +41,18 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
+def dp_info(ddp, steps_run):
+    """data-parallel bookkeeping for the N > 1 lines: gradient collectives per step (how many left
+    during backward is visible from the count: 1 = everything at finish()), parameters that had to
+    be reduced late, SyncBatchNorm collectives per step"""
+    if ddp is None:
+        return {}
+    from ssl4gie_amd import resnet_engine
+    return {"dp": {"grad_collectives_per_step": round(ddp.n_collectives / max(steps_run, 1), 2),
+                   "late_params": ddp.n_late, "transport": "direct" if ddp._direct is not None else "rccl",
+                   "syncbn_collectives_per_step": round(resnet_engine.SYNC_BN_COLLECTIVES[0] / max(steps_run, 1), 1)}}
+
+
 def param_groups(model, wd=0.05):
     """timm add_weight_decay semantics used by the reference driver (main_pretrain.py:179)."""
     decay, no_decay = [], []
@@ -201,7 +213,7 @@ def bench_depth(a):
     loss, dt = timed_steps(step, a, world, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
-        print(json.dumps({
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
             "metric": "images/sec (fwd+bwd+AdamW) ViT-B + DPT depth finetune 224x224 (BASELINE.json configs[3])",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -261,7 +273,7 @@ def bench_moco(a):
     loss, dt = timed_steps(step, a, world, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
-        print(json.dumps({
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
             "metric": "image pairs/sec (fwd+bwd+LARS) MoCo-v3 ResNet50 224x224 (BASELINE.json configs[2])",
             "value": round(ips, 1), "unit": "image pairs/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -309,7 +321,7 @@ def bench_vit(a):
     loss, dt = timed_steps(step, a, world, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
-        print(json.dumps({
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
             "metric": "images/sec (fwd+bwd+AdamW) ViT-B 224x224 linear-head finetune, un-masked trunk",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -363,7 +375,7 @@ def bench_det(a):
         gmac = (12 * N * 12 * D * D + 8 * 2 * N * 256 * D + 4 * 2 * N * N * D + N * D * D
                 + 2 * (N * D * 4 * D) + 2 * (4 * N * D * 4 * D) + (N // 4 + N + 4 * N + 16 * N) * D * 256
                 + (N // 4 + N + 4 * N + 16 * N) * 9 * 256 * 256) / 1e9
-        print(json.dumps({
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
             "metric": "images/sec (fwd+bwd+AdamW) detection ViT-B backbone + ViTDet FPN 1024x1024 (SURVEY 8f-1)",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -423,7 +435,7 @@ def bench_bt(a):
         # 212.44 GFLOP per image (two views, trunk + projector, fwd+bwd) + the three
         # 8192 x 8192 x B cross-correlation products (c, dz_A, dz_B) = 6 * 8192^2 FLOP per image
         gflop_img = 212.44 + 6 * 8192 * 8192 / 1e9
-        print(json.dumps({
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
             "metric": "images/sec (two views, fwd+bwd+LARS) Barlow Twins ViT-B 224x224 (BASELINE.json configs[4])",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -575,6 +587,7 @@ def main():
             "model_mfma_frac": round(ips / world * GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS, 4),
             "final_loss": round(final_loss, 5),
         }
+        line.update(dp_info(ddp, a.steps + a.warmup + a.prof_steps))
         if roof is not None:
             line["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
