@@ -457,6 +457,21 @@ int ssl4gie_prof_begin(int max_launches);
 int ssl4gie_prof_collect(double* ms, double* flops, long long* launches);
 int ssl4gie_prof_end(void);
 
+/* ---------------------------------------------------------------- finetune losses (value + gradient)
+ * ScaleAndShiftInvariantLoss(alpha, scales) of the depth finetune step
+ * (Depth_estimation/Metrics/losses.py:120-146; used at train_depth.py:43,280): pred, target fp32
+ * [B, H, W] (the [B, 1, H, W] maps), valid pixels = target > 0.  Writes the scalar loss and
+ * dpred = dloss/dpred (fp32 [B, H, W]) in five launches; deterministic two-stage reductions.
+ * SoftDiceLoss(smooth) of the segmentation step (Binary_segmentation/Metrics/losses.py:5-24): logits,
+ * target fp32 [B, n]; loss = 1 - mean_b 2 (sum s t + smooth) / (sum s^2 + sum t^2 + smooth),
+ * s = sigmoid(logits); writes the loss and dlogits. */
+size_t ssl4gie_ssi_loss_workspace_bytes(int B, int H, int W);
+int ssl4gie_ssi_loss(const float* pred, const float* target, float* loss, float* dpred, int B, int H,
+                     int W, float alpha, int scales, void* workspace, void* stream);
+size_t ssl4gie_dice_loss_workspace_bytes(int B);
+int ssl4gie_dice_loss(const float* logits, const float* target, float* loss, float* dlogits, int B,
+                      long long n, float smooth, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------- direct xGMI gradient all-reduce
  * replaces the NCCL bucket all-reduce of DistributedDataParallel (Models/mae/main_pretrain.py:175,
  * Depth_estimation/train_depth.py:226-229, Models/moco_v3/main_moco.py:208) for ONE node of up to 8

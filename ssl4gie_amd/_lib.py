@@ -137,6 +137,10 @@ PROTOTYPES = {
     "ssl4gie_wgrad_wait": (i32, [i32, vp]),
     "ssl4gie_set_wgrad_stream": (i32, [i32]),
     "ssl4gie_set_compute_cus": (i32, [i32]),
+    "ssl4gie_ssi_loss_workspace_bytes": (sz, [i32, i32, i32]),
+    "ssl4gie_ssi_loss": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),
+    "ssl4gie_dice_loss_workspace_bytes": (sz, [i32]),
+    "ssl4gie_dice_loss": (i32, [vp, vp, vp, vp, i32, i64, f32, vp, vp]),
     "ssl4gie_allreduce_direct_blob_bytes": (sz, []),
     "ssl4gie_allreduce_direct_init": (i32, [i32, i32, sz, vp, C.POINTER(vp)]),
     "ssl4gie_allreduce_direct_connect": (i32, [vp, vp]),
