@@ -349,7 +349,10 @@ extern "C" int ssl4gie_decoder_assemble_bwd(const float* dxd, const long long* i
 }
 
 // ------------------------------------------------------------------ MAE loss (+ its gradient)
-// one wave per patch; P = C*p*p target values gathered in 'nhwpqc' order (NV = ceil(P/64) per lane)
+// one wave per patch; P = C*p*p target values gathered in 'nhwpqc' order.  A lane owns NV groups of
+// 4 consecutive values (k = 4 lane + 256 i): pred / dpred move as 16-byte accesses, 1 KiB per wave
+// instruction; the matching target pixels are 4 scalar reads of the image (served by L1: a patch
+// row of one channel is 64 contiguous bytes shared by neighbouring lanes).
 template <int NV>
 __global__ __launch_bounds__(256) void mae_loss_kernel(
     const float* __restrict__ pred, const float* __restrict__ img, const float* __restrict__ mask,
@@ -363,24 +366,27 @@ __global__ __launch_bounds__(256) void mae_loss_kernel(
     float* dr = dpred ? dpred + (size_t)row * P : nullptr;
     if (has_cls && t == 0) {  // cls row: no loss, zero gradient
         if (dr)
-            for (int k = lane; k < P; k += 64) dr[k] = 0.f;
+            for (int k = 4 * lane; k < P; k += 256) st4(dr + k, f32x4{0.f, 0.f, 0.f, 0.f});
         return;
     }
     const int l = t - has_cls, gy = l / gw, gx = l % gw;
-    const float* ib = img + (size_t)b * C * H * W;
+    const float* ib = img + (size_t)b * C * H * W + (size_t)(gy * p) * W + gx * p;
     const float* pr = pred + (size_t)row * P;
-    float tv[NV], pv[NV];
+    f32x4 tv[NV], pv[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int k = lane + 64 * i;
-        tv[i] = 0.f;
-        pv[i] = 0.f;
+        const int k = 4 * lane + 256 * i;
+        tv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (k < P) {
-            const int c = k % C, pix = k / C, py = pix / p, px = pix % p;
-            tv[i] = ib[((size_t)c * H + gy * p + py) * W + gx * p + px];
-            pv[i] = pr[k];
-            s += tv[i];
+            pv[i] = ld4(pr + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = k + j, c = kk % C, pix = kk / C, py = pix / p, px = pix - py * p;
+                tv[i][j] = ib[((size_t)c * H + py) * W + px];
+            }
+            s += (tv[i][0] + tv[i][1]) + (tv[i][2] + tv[i][3]);
         }
     }
     if (norm_pix) {
@@ -388,9 +394,9 @@ __global__ __launch_bounds__(256) void mae_loss_kernel(
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            if (lane + 64 * i < P) {
-                const float d = tv[i] - mean;
-                q += d * d;
+            if (4 * lane + 256 * i < P) {
+                const f32x4 d = tv[i] - mean;
+                q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
         const float inv = rsqrtf(wave_sum(q) / (float)(P - 1) + 1.0e-6f);  // unbiased var
 #pragma unroll
@@ -400,9 +406,9 @@ __global__ __launch_bounds__(256) void mae_loss_kernel(
     float e = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        if (lane + 64 * i < P) {
-            const float d = pv[i] - tv[i];
-            e += d * d;
+        if (4 * lane + 256 * i < P) {
+            const f32x4 d = pv[i] - tv[i];
+            e += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
     e = wave_sum(e) / (float)P;
     if (per_patch && lane == 0) per_patch[(size_t)b * L + l] = e * m;
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(256) void mae_loss_kernel(
         const float gs = gscale_host * (gpp ? gpp[(size_t)b * L + l] : 1.f) * m * 2.0f / (float)P;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            if (lane + 64 * i < P) dr[lane + 64 * i] = gs * (pv[i] - tv[i]);
+            if (4 * lane + 256 * i < P) st4(dr + 4 * lane + 256 * i, (pv[i] - tv[i]) * gs);
     }
 }
 extern "C" int ssl4gie_mae_loss(const float* pred, const float* img, const float* mask,
@@ -420,19 +426,19 @@ extern "C" int ssl4gie_mae_loss(const float* pred, const float* img, const float
     REQUIRE(pred && img && mask && B >= 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0);
     REQUIRE(has_cls == 0 || has_cls == 1);
     const int P = C * p * p;
-    REQUIRE(P <= 64 * 16);
+    REQUIRE(P <= 64 * 16 && P % 4 == 0);
     if (B == 0) return 0;
     const long long rows = (long long)B * ((H / p) * (W / p) + has_cls);
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (P <= 64 * 4)
-        hipLaunchKernelGGL(mae_loss_kernel<4>, grid, block, 0, st, pred, img, mask, per_patch, dpred,
+        hipLaunchKernelGGL(mae_loss_kernel<1>, grid, block, 0, st, pred, img, mask, per_patch, dpred,
                            gpp, gscale_host, norm_pix, has_cls, B, C, H, W, p);
     else if (P <= 64 * 12)
-        hipLaunchKernelGGL(mae_loss_kernel<12>, grid, block, 0, st, pred, img, mask, per_patch,
+        hipLaunchKernelGGL(mae_loss_kernel<3>, grid, block, 0, st, pred, img, mask, per_patch,
                            dpred, gpp, gscale_host, norm_pix, has_cls, B, C, H, W, p);
     else
-        hipLaunchKernelGGL(mae_loss_kernel<16>, grid, block, 0, st, pred, img, mask, per_patch,
+        hipLaunchKernelGGL(mae_loss_kernel<4>, grid, block, 0, st, pred, img, mask, per_patch,
                            dpred, gpp, gscale_host, norm_pix, has_cls, B, C, H, W, p);
     LAUNCH_CHECK();
     return 0;
