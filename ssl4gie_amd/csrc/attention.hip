@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 // ------------------------------------------------------------------ LDS image helpers
 template <int HD> DEVI int kv_swz(int row) { return HD == 64 ? (row & 6) : ((row >> 1) & 2); }
@@ -80,6 +81,21 @@ DEVI float group_max(float v) {  // across the 4 lane groups (lanes l, l^16, l^3
 DEVI float group_sum(float v) {
     v += __shfl_xor(v, 16, 64);
     return v + __shfl_xor(v, 32, 64);
+}
+// P = exp2(S c - l) and dS = P (dP - delta) for four scores of a lane, in packed fp32 (v_pk_fma_f32 /
+// v_pk_add_f32 / v_pk_mul_f32 handle two values per instruction); ndl = -delta (a packed add is
+// selected, a packed subtract is not)
+DEVI void softmax_bwd4(const f32x4 s, const f32x4 dp, const f32x4 l, const f32x4 ndl, const float c,
+                       f32x4& p, f32x4& ds) {
+    const f32x2 c2 = {c, c};
+    f32x2 a = f32x2{s[0], s[1]} * c2 - f32x2{l[0], l[1]};
+    f32x2 b = f32x2{s[2], s[3]} * c2 - f32x2{l[2], l[3]};
+    a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
+    b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
+    const f32x2 da = a * (f32x2{dp[0], dp[1]} + f32x2{ndl[0], ndl[1]});
+    const f32x2 db = b * (f32x2{dp[2], dp[3]} + f32x2{ndl[2], ndl[3]});
+    p = f32x4{a[0], a[1], b[0], b[1]};
+    ds = f32x4{da[0], da[1], db[0], db[1]};
 }
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
@@ -137,8 +153,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
     stage_qkv<HD, NPAD, 64 * WAVES>(Kimg, Vimg, Qimg, qb + D, qb + 2 * D, qb, rs, N, tid);
     __syncthreads();                              // inside the per-tile dependency chains
     const float c = scale * 1.44269504088896340736f;
+    const f32x2 c2 = {c, c};
     const int nqt = (N + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += WAVES) {
+    // the wave that takes the extra query tile rotates with the head, so that no SIMD of the CU
+    // is always the one with the longer share
+    for (int qt = (wave + bh) & (WAVES - 1); qt < nqt; qt += WAVES) {
         const int q = qt * 16 + (lane & 15);
         bf16x8 qf[KS];
 #pragma unroll
@@ -153,25 +172,30 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
         }
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt >= NKT - 2) {  // 16 (NKT - 2) < N: only the last two tiles hold padded keys
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (kt * 16 + 16 > N) {  // wave-uniform: only the last tile(s) hold padded keys
+                for (int r = 0; r < 4; ++r)
                     if (kt * 16 + 4 * g + r >= N) s[kt][r] = -INFINITY;
-                }
-                mx = fmaxf(mx, s[kt][r]);
             }
+            mx = fmaxf(fmaxf(mx, s[kt][0]), s[kt][1]);  // v_max3_f32
+            mx = fmaxf(fmaxf(mx, s[kt][2]), s[kt][3]);
+        }
         mx = group_max(mx);
-        const float mc = mx * c;
-        float sum = 0.f;
+        const f32x2 nmc2 = {-mx * c, -mx * c};
+        f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kt][r] * c - mc);
-                s[kt][r] = p;
-                sum += p;
-            }
+        for (int kt = 0; kt < NKT; ++kt) {  // packed fp32: one v_pk_fma / v_pk_add per two scores
+            f32x2 a = {s[kt][0], s[kt][1]}, bq = {s[kt][2], s[kt][3]};
+            a = a * c2 + nmc2;
+            bq = bq * c2 + nmc2;
+            a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
+            bq[0] = __builtin_amdgcn_exp2f(bq[0]); bq[1] = __builtin_amdgcn_exp2f(bq[1]);
+            sum2 += a;
+            sum2 += bq;
+            s[kt] = f32x4{a[0], a[1], bq[0], bq[1]};
+        }
+        float sum = sum2[0] + sum2[1];
         sum = group_sum(sum);
         f32x4 o[DT];
 #pragma unroll
@@ -190,6 +214,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
             for (int dt = 0; dt < DT; ++dt) st4(orow + dt * 16, o[dt] * inv);
             if (g == 0) lse[((size_t)b * H + h) * N + q] = mx * scale + __logf(sum);
         }
+        if (NKT <= WAVES) break;  // at most one tile per wave: not a loop
     }
 }
 
@@ -198,9 +223,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
 // saved log-sum-exp and delta_q = sum_d dO[q,d] O[q,d] (computed while dO is staged): after the
 // prologue no wave ever waits on a global load inside its per-tile dependency chain (at 2 waves
 // per SIMD an exposed ~2 us HBM round trip per query tile used to dominate this kernel).
-#define ATTN_BWD_WAVES 8  // 512 threads share one set of images: 2 workgroups = 16 waves per CU
+// Waves per workgroup: each phase hands out NKT (or NKT - 1) 16-row tiles, so the wave count is
+// chosen to divide that evenly — one tile per wave up to 8 tiles (never fewer than 4 waves), two per
+// wave above (N = 197: 13 tiles on 7 waves instead of 8 waves of which three would get one).  The
+// waves of a workgroup share one set of LDS images; 2-4 workgroups fit a CU.
+template <int NKT> struct AttnBwdWaves {
+    static constexpr int value = NKT <= 4 ? 4 : (NKT <= 8 ? NKT : NKT / 2);
+};
 template <int HD, int NKT>
-__global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
+__global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf16_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
     int N, int H, float scale) {
@@ -211,7 +242,7 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
     char* Qimg = smem + 2 * NPAD * RB;
     char* Oimg = smem + 3 * NPAD * RB;  // dO
     float* lse_s = (float*)(smem + 4 * NPAD * RB);
-    float* del_s = lse_s + NPAD;
+    float* del_s = lse_s + NPAD;  // -delta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     // consecutive (b, h) ids share an XCD: with hd = 32 two neighbouring heads share every 128-B
     // line of the packed qkv rows, so the second one hits in that XCD's L2
@@ -227,7 +258,7 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
     const float LOG2E = 1.44269504088896340736f;
     const float c = scale * LOG2E;
 
-    constexpr int NTH = 64 * ATTN_BWD_WAVES;
+    constexpr int ATTN_BWD_WAVES = AttnBwdWaves<NKT>::value, NTH = 64 * ATTN_BWD_WAVES;
     // ---------------- prologue: stage K, V, Q, dO; delta and lse rows
     stage_qkv<HD, NPAD, NTH>(Kimg, Vimg, Qimg, qb + D, qb + 2 * D, qb, rs, N, tid);
     {  // dO image + delta rows; loads first, then arithmetic and LDS writes (one HBM round trip)
@@ -253,11 +284,11 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
                 *(u32x4*)(Oimg + img_off<HD>(row, ch)) = vv[i];
 #pragma unroll
                 for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);  // the row's CPR lanes
-                if (ch == 0) del_s[row] = dot;
+                if (ch == 0) del_s[row] = -dot;  // kept negated: see softmax_bwd4
             }
         }
     }
-    for (int i = tid; i < NPAD; i += NTH) lse_s[i] = i < N ? lrow[i] * LOG2E : 0.f;
+    for (int i = tid; i < NPAD; i += NTH) lse_s[i] = i < N ? lrow[i] * LOG2E : INFINITY;  // padded queries: P = 0
     __syncthreads();
     const int nqt = (N + 15) >> 4;
 
@@ -273,11 +304,11 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
         const float dl = del_s[q];
         const float l2 = lse_s[q];
         // dS^T needs only the saved row statistics, so key tiles are consumed pair by pair
+        const f32x4 l4 = {l2, l2, l2, l2}, dl4 = {dl, dl, dl, dl};
         f32x4 dq[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
-#pragma unroll 1
-        for (int kp = 0; kp < NKT / 2; ++kp) {
+        auto pairA = [&](const int kp, auto tail) {
             f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -286,29 +317,32 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
                 p0 = MFMA16(row_frag<HD>(Vimg, kp * 32, ks, lane), dof[ks], p0);
                 p1 = MFMA16(row_frag<HD>(Vimg, kp * 32 + 16, ks, lane), dof[ks], p1);
             }
-            const int ka = kp * 32 + 4 * g;
-            const bool tail = kp * 32 + 32 > N;  // wave-uniform: padded keys only in the last pair
+            f32x4 pa, pb, dsa, dsb;
+            softmax_bwd4(s0, p0, l4, dl4, c, pa, dsa);
+            softmax_bwd4(s1, p1, l4, dl4, c, pb, dsb);
+            if constexpr (decltype(tail)::value) {
+                const int ka = kp * 32 + 4 * g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pa = __builtin_amdgcn_exp2f(s0[r] * c - l2);
-                float pb = __builtin_amdgcn_exp2f(s1[r] * c - l2);
-                if (tail) {
-                    pa = (ka + r < N) ? pa : 0.f;
-                    pb = (ka + 16 + r < N) ? pb : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    dsa[r] = (ka + r < N) ? dsa[r] : 0.f;
+                    dsb[r] = (ka + 16 + r < N) ? dsb[r] : 0.f;
                 }
-                s0[r] = pa * (p0[r] - dl);  // dS^T
-                s1[r] = pb * (p1[r] - dl);
             }
-            const bf16x8 dsf = pack8(s0, s1);
+            const bf16x8 dsf = pack8(dsa, dsb);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
                 dq[dt] = MFMA16(tr_frag<HD>(Kimg, kp * 32, dt * 16, lane), dsf, dq[dt]);
-        }
+        };
+        // 16 (NKT - 2) < N: padded keys only in the last pair, which is peeled
+#pragma unroll 1
+        for (int kp = 0; kp < NKT / 2 - 1; ++kp) pairA(kp, std::false_type{});
+        pairA(NKT / 2 - 1, std::true_type{});
         if (q < N) {
             bf16_t* r = dqb + (size_t)q * rs + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) st4(r + dt * 16, dq[dt] * scale);
         }
+        if (NKT <= ATTN_BWD_WAVES) break;  // at most one tile per wave: not a loop
     }
 
     // ---------------- phase B: dK, dV (waves own key tiles); same LDS images, no restaging
@@ -336,23 +370,14 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
                 p0 = MFMA16(row_frag<HD>(Oimg, qp * 32, ks, lane), vf[ks], p0);
                 p1 = MFMA16(row_frag<HD>(Oimg, qp * 32 + 16, ks, lane), vf[ks], p1);
             }
-            // lane holds S[q = qp*32 (+16) + 4g + r][key]; p0/p1 hold dP
+            // lane holds S[q = qp*32 (+16) + 4g + r][key]; p0/p1 hold dP.  Padded queries carry
+            // lse = +inf (P = 0) and zero dO / delta rows, so they need no mask here.
             const int qa = qp * 32 + 4 * g;
             const f32x4 la = *(const f32x4*)(lse_s + qa), lb = *(const f32x4*)(lse_s + qa + 16);
             const f32x4 da = *(const f32x4*)(del_s + qa), db = *(const f32x4*)(del_s + qa + 16);
             f32x4 pa, pb, dsa, dsb;
-            const bool tail = qp * 32 + 32 > N;  // wave-uniform: padded queries only in the last pair
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pa[r] = __builtin_amdgcn_exp2f(s0[r] * c - la[r]);
-                pb[r] = __builtin_amdgcn_exp2f(s1[r] * c - lb[r]);
-                if (tail) {
-                    pa[r] = (qa + r < N) ? pa[r] : 0.f;
-                    pb[r] = (qa + 16 + r < N) ? pb[r] : 0.f;
-                }
-                dsa[r] = pa[r] * (p0[r] - da[r]);
-                dsb[r] = pb[r] * (p1[r] - db[r]);
-            }
+            softmax_bwd4(s0, p0, la, da, c, pa, dsa);
+            softmax_bwd4(s1, p1, lb, db, c, pb, dsb);
             const bf16x8 pf = pack8(pa, pb), dsf = pack8(dsa, dsb);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -368,6 +393,7 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES, 4) void attn_bwd_bf16_kernel(
                 st4(r + 2 * D + dt * 16, dv[dt]);
             }
         }
+        if (NKT <= ATTN_BWD_WAVES) break;
     }
 }
 
@@ -824,7 +850,7 @@ static int launch_bwd(const void* qkv, const void* out, const void* dout, const 
     if (lds > 65536)
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * HD, st);
-    hipLaunchKernelGGL(k, dim3(B * H), dim3(64 * ATTN_BWD_WAVES), lds, st, (const bf16_t*)qkv,
+    hipLaunchKernelGGL(k, dim3(B * H), dim3(64 * AttnBwdWaves<NKT>::value), lds, st, (const bf16_t*)qkv,
                        (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
     LAUNCH_CHECK();
     return 0;
@@ -862,10 +888,19 @@ extern "C" int ssl4gie_attn_fwd(const void* qkv, void* out, float* lse, int dtyp
             return 0;
         }
         REQUIRE(N <= 256);
-#define FWD(HD_)                                                                      \
-    if (N <= 64) return launch_fwd<HD_, 4>(qkv, out, lse, B, N, H, scale, st);        \
-    if (N <= 224) return launch_fwd<HD_, 14>(qkv, out, lse, B, N, H, scale, st);      \
-    return launch_fwd<HD_, 16>(qkv, out, lse, B, N, H, scale, st);
+// the kernels are instantiated for every even number of 16-key tiles: 16 (NKT - 2) < N <= 16 NKT,
+// so that only the last tile pair can hold padded keys (the kernels rely on it)
+#define FWD(HD_)                                                                          \
+    switch ((N + 31) >> 5) {                                                              \
+    case 1: return launch_fwd<HD_, 2>(qkv, out, lse, B, N, H, scale, st);                 \
+    case 2: return launch_fwd<HD_, 4>(qkv, out, lse, B, N, H, scale, st);                 \
+    case 3: return launch_fwd<HD_, 6>(qkv, out, lse, B, N, H, scale, st);                 \
+    case 4: return launch_fwd<HD_, 8>(qkv, out, lse, B, N, H, scale, st);                 \
+    case 5: return launch_fwd<HD_, 10>(qkv, out, lse, B, N, H, scale, st);                \
+    case 6: return launch_fwd<HD_, 12>(qkv, out, lse, B, N, H, scale, st);                \
+    case 7: return launch_fwd<HD_, 14>(qkv, out, lse, B, N, H, scale, st);                \
+    default: return launch_fwd<HD_, 16>(qkv, out, lse, B, N, H, scale, st);               \
+    }
         if (hd == 64) { FWD(64) } else { FWD(32) }
 #undef FWD
     }
@@ -942,10 +977,17 @@ extern "C" int ssl4gie_attn_bwd(const void* qkv, const void* out, const void* do
             return 0;
         }
         REQUIRE(N <= 256);
-#define BWD(HD_)                                                                               \
-    if (N <= 64) return launch_bwd<HD_, 4>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);     \
-    if (N <= 224) return launch_bwd<HD_, 14>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);   \
-    return launch_bwd<HD_, 16>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);
+#define BWD(HD_)                                                                                   \
+    switch ((N + 31) >> 5) {                                                                       \
+    case 1: return launch_bwd<HD_, 2>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);              \
+    case 2: return launch_bwd<HD_, 4>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);              \
+    case 3: return launch_bwd<HD_, 6>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);              \
+    case 4: return launch_bwd<HD_, 8>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);              \
+    case 5: return launch_bwd<HD_, 10>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);             \
+    case 6: return launch_bwd<HD_, 12>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);             \
+    case 7: return launch_bwd<HD_, 14>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);             \
+    default: return launch_bwd<HD_, 16>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);            \
+    }
         if (hd == 64) { BWD(64) } else { BWD(32) }
 #undef BWD
     }

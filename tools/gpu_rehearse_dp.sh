@@ -9,6 +9,7 @@ export SSL4GIE_DIST_BACKEND=gloo SSL4GIE_BENCH_SAME_DATA=1 HSA_ENABLE_IPC_MODE_L
 run2() { timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $1 bench.py --gpus 2 "${@:2}"; }
 echo "== mae 1 rank"; timeout -k 10 300 python bench.py --gpus 1 --steps 4 --warmup 2 --batch 64 --no-cpu-baseline --prof-steps 0 2>/dev/null | tail -1 | cut -c1-900
 echo "== mae 2 ranks (same data)"; run2 29511 --steps 4 --warmup 2 --batch 64 --no-cpu-baseline --prof-steps 0 2>&1 | grep -a "^{" | cut -c1-900
+echo "== mae 2 ranks (same data), direct all-reduce transport (csrc/allreduce.hip over HIP IPC on the one device)"; SSL4GIE_ALLREDUCE=direct run2 29515 --steps 4 --warmup 2 --batch 64 --no-cpu-baseline --prof-steps 0 2>&1 | grep -a "^{" | cut -c1-900
 echo "== depth 2 ranks"; run2 29512 --workload depth --steps 2 --warmup 1 --batch 16 2>&1 | grep -a "^{\|Error\|error" | cut -c1-600
 echo "== moco 2 ranks (SyncBN)"; run2 29513 --workload moco --steps 2 --warmup 1 --batch 32 2>&1 | grep -a "^{\|Error\|error" | cut -c1-600
 echo "== bt 2 ranks"; run2 29514 --workload bt --steps 2 --warmup 1 --batch 64 2>&1 | grep -a "^{\|Error\|error" | cut -c1-600
