@@ -309,6 +309,28 @@ int ssl4gie_im2col3x3(const void* x, void* cols, int dtype, int B, int H, int W,
                       int relu, long long ld, void* stream);
 int ssl4gie_col2im3x3(const void* dcols, void* dx, int dtype, int B, int H, int W, int C,
                       int stride, long long ld, void* stream);
+/* Direct 3x3 convolution, stride 1, pad 1, bf16, for NARROW channel counts — the DPT output head's
+ * nn.Conv2d(128, 32, 3, 1, 1) (output_conv.2, DPT_decoder.py:473-478) and its gradients, where the
+ * gathered 256x256 GEMM tiles would be 7/8 padding.  x [B,H,W,Cin], w2 [Cout, 9*Cin] (the layout
+ * of the implicit-GEMM path: taps row-major, channels innermost), y [B,H,W,Cout]:
+ *     y = conv(relu_in ? relu(x) : x, w2) (+ bias[Cout] fp32)  (then y = relu_mask > 0 ? y : 0, with
+ *     relu_mask [B,H,W,Cout] bf16 — the data gradient of a convolution behind a ReLU)
+ * The data gradient is the same call on dy with w2 := weight.flip(2,3) as [Cin, 9*Cout].
+ * _ok(): Cin % 32 == 0 and Cout % 8 == 0 (any H, W); otherwise the calls return SSL4GIE_EARG.
+ * Meant for Cout <= 64 or Cin == 32; wider layers belong to ssl4gie_gemm with `conv`. */
+int ssl4gie_conv3x3_direct_ok(int B, int H, int W, int Cin, int Cout);
+int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const float* bias,
+                               const void* relu_mask, void* y, int B, int H, int W, int Cin,
+                               int Cout, int relu_in, void* stream);
+/* dW2 [Cout = 32, 9*Cin] fp32 (+)= sum over pixels of dy [B,H,W,32] x patch(relu_in ? relu(x) : x);
+ * Cin % 64 == 0; dbias [32] fp32 (+)= sum over pixels of dy, or NULL (it rides on a spare
+ * accumulator of the same kernel).  Persistent workgroups write one fp32 partial each into the
+ * workspace, a second kernel sums them in a fixed order (deterministic, no atomics). */
+int ssl4gie_conv3x3_direct_wgrad_ok(int B, int H, int W, int Cin, int Cout);
+size_t ssl4gie_conv3x3_direct_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float* dw2, float* dbias,
+                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin,
+                                 int Cout, int relu_in, int accumulate, void* stream);
 /* F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) (:293-295, Interpolate :69-104)
  * x [B,H,W,C] -> y [B,2H,2W,C]; backward in gather form (no atomics) */
 int ssl4gie_bilinear2x_fwd(const void* x, void* y, int dtype, int B, int H, int W, int C,

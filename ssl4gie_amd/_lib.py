@@ -91,6 +91,11 @@ PROTOTYPES = {
     "ssl4gie_mae_loss": (i32, [vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_im2col3x3": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, vp]),
     "ssl4gie_col2im3x3": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i64, vp]),
+    "ssl4gie_conv3x3_direct_ok": (i32, [i32, i32, i32, i32, i32]),
+    "ssl4gie_conv3x3_direct_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_conv3x3_direct_wgrad_ok": (i32, [i32, i32, i32, i32, i32]),
+    "ssl4gie_conv3x3_direct_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "ssl4gie_conv3x3_direct_wgrad": (i32, [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_bilinear2x_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_bilinear2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_pixel_shuffle": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -1,0 +1,435 @@
+// Direct 3x3 convolutions (stride 1, pad 1) for the NARROW ends of the DPT output head on gfx950.
+//
+// Replaces nn.Conv2d(128, 32, 3, 1, 1) of output_conv.2 (Models/DPT_decoder.py:473-478) and its two
+// gradients.  As implicit GEMMs these have N = 32 (forward), K-per-tap = 32 (data gradient) or a
+// 32 x 1152 output (weight gradient): in the 256x256-tile GEMM kernels 7/8 of every tile is padding
+// (forward 133 TFLOP/s, weight gradient 113 TFLOP/s, and the data gradient needs a materialised
+// patch matrix — tools/dpt_head_bench.py).  Here a workgroup owns an 8 x 32 pixel tile instead:
+//
+//  * conv3x3_direct_kernel (forward; the data gradient is the same kernel on dy with the flipped,
+//    transposed weight): the tile's input halo (10 x 34 pixels x CK channels) and the weight slice
+//    [32 NCB couts][9 taps][CK] are staged ONCE into LDS, and the nine taps are nine shifted reads
+//    of the same halo — each input element is written to LDS once and read nine times, where the
+//    gathered GEMM re-stages it per tap.  v_mfma_f32_32x32x16_bf16 (a <- 32 couts, b <- 32 pixels
+//    of one tile row): twice the flops per LDS byte of the 16x16x32 form, which is what a 32-wide
+//    output needs.  A lane ends up with 4 x 4 consecutive couts of one pixel.  XOR swizzles on the
+//    16-byte chunk index make both ds_read_b128 streams conflict-free (see DcLay).  Two workgroups
+//    share a CU (80 KiB LDS each at CK = 64), so one stages while the other computes.
+//  * conv3x3_wgrad_direct_kernel: dW[co][tap][ci] = sum_pixels dy[p][co] x[p + tap][ci].  The
+//    contraction runs over pixels, so both MFMA operands are read TRANSPOSED out of pixel-major LDS
+//    images with ds_read_b64_tr_b16 (k = 16 consecutive pixels of a tile row); the nine taps are
+//    nine shifted reads again.  Persistent workgroups (2 per CU) each keep their share of the
+//    32 x 9 x 64 accumulator block in registers across all their tiles and write ONE fp32 partial;
+//    a small kernel sums the partials in a fixed order (no atomics).
+#include "common.h"
+#include "internal.h"
+#include "gemm_internal.h"
+#include "ssl4gie_hip.h"
+#include "prof.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+#define DC_TH 8                 // tile rows (4 waves x 2)
+#define DC_TW 32                // tile columns = one 32-pixel MFMA operand
+#define DC_HH (DC_TH + 2)
+#define DC_HW (DC_TW + 2)
+#define DC_THREADS 256
+
+DEVI u32x4 relu_bf16x8(u32x4 v) {  // clears every 16-bit half whose sign bit is set
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned s = (v[i] >> 15) & 0x00010001u;
+        o[i] = v[i] & ~((s << 16) - s);
+    }
+    return o;
+}
+
+// LDS images of the forward kernel.  X: pixel-major halo, CK channels (CPP 16-byte chunks) per
+// pixel; chunk c of halo column hx sits at position c ^ f(hx), with f chosen so that the 16 pixels a
+// lane group reads (consecutive hx, one chunk index) fall into 16 different 16-byte bank slots:
+// CK = 64 (128 B / pixel): slot = 8 (hx & 1) + (c ^ ((hx >> 1) & 7)); CK = 32 (64 B / pixel):
+// slot = 4 (lin & 3) + (c ^ ((hx >> 2) & 3)).  W: one row of 9 CK values per cout, chunk cc at
+// cc ^ s(row): rows are 72 (36) slots apart = 8 (4) mod 16, so s = (row >> 1) & 7 ((row >> 2) & 3).
+template <int CK> struct DcLay {
+    static constexpr int CPP = CK / 8, PS = CK * 2;
+    static constexpr int XS_BYTES = DC_HH * DC_HW * PS;
+    static constexpr int WROW = 9 * CK * 2;
+    static DEVI int x_off(int hy, int hx, int c) {
+        const int f = CK == 64 ? ((hx >> 1) & 7) : ((hx >> 2) & 3);
+        return (hy * DC_HW + hx) * PS + ((c ^ f) << 4);
+    }
+    static DEVI int w_off(int row, int cc) {
+        const int s = CK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+        return row * WROW + ((cc ^ s) << 4);
+    }
+};
+
+// y[b, oy, ox, co] = sum_{tap, ci} act(x)[b, oy + dy - 1, ox + dx - 1, ci] w2[co, tap * Cin + ci]
+// (+ bias[co]) (masked by relu_mask > 0).  grid = (tiles_x * tiles_y * B, ceil(Cout / (32 NCB))).
+template <int CK, int NCB>
+__global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w2, const float* __restrict__ bias,
+    const bf16_t* __restrict__ relu_mask, bf16_t* __restrict__ y, int H, int W, int Cin, int Cout,
+    int relu_in, int tiles_x, int tiles_y) {
+    using L = DcLay<CK>;
+    constexpr int CPP = L::CPP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xs = smem;
+    char* Ws = smem + L::XS_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int tx0 = (bid % tiles_x) * DC_TW;
+    bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * DC_TH;
+    const int b = bid / tiles_y;
+    const int co0 = blockIdx.y * (32 * NCB);
+
+    f32x16 acc[2][NCB];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int n = 0; n < NCB; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[pb][n][j] = 0.f;
+
+    constexpr int NX = DC_HH * DC_HW * CPP, IX = (NX + DC_THREADS - 1) / DC_THREADS;
+    constexpr int NW = NCB * 32 * 9 * CPP, IW = (NW + DC_THREADS - 1) / DC_THREADS;
+    for (int cin0 = 0; cin0 < Cin; cin0 += CK) {
+        // ---- stage the halo and the weight slice: all global loads first, then the LDS writes
+        u32x4 xv[IX], wv[IW];
+#pragma unroll
+        for (int i = 0; i < IX; ++i) {
+            const int idx = tid + i * DC_THREADS, pi = idx / CPP, c = idx % CPP;
+            const int hy = pi / DC_HW, hx = pi % DC_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            xv[i] = u32x4{0, 0, 0, 0};
+            if (idx < NX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                xv[i] = *(const u32x4*)(x + (((size_t)b * H + gy) * W + gx) * Cin + cin0 + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < IW; ++i) {
+            const int idx = tid + i * DC_THREADS, row = idx / (9 * CPP), cc = idx % (9 * CPP);
+            const int tap = cc / CPP, c = cc % CPP;
+            wv[i] = u32x4{0, 0, 0, 0};
+            if (idx < NW && co0 + row < Cout)
+                wv[i] = *(const u32x4*)(w2 + (size_t)(co0 + row) * 9 * Cin + tap * Cin + cin0 + c * 8);
+        }
+        if (cin0) __syncthreads();  // the previous channel slice has been consumed
+#pragma unroll
+        for (int i = 0; i < IX; ++i) {
+            const int idx = tid + i * DC_THREADS, pi = idx / CPP, c = idx % CPP;
+            if (idx < NX)
+                *(u32x4*)(Xs + L::x_off(pi / DC_HW, pi % DC_HW, c)) = relu_in ? relu_bf16x8(xv[i]) : xv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < IW; ++i) {
+            const int idx = tid + i * DC_THREADS;
+            if (idx < NW) *(u32x4*)(Ws + L::w_off(idx / (9 * CPP), idx % (9 * CPP))) = wv[i];
+        }
+        __syncthreads();
+        // ---- nine shifted reads of the same halo
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int ks = 0; ks < CK / 16; ++ks) {
+                const int c = ks * 2 + half;
+                bf16x8 a[NCB];
+#pragma unroll
+                for (int n = 0; n < NCB; ++n)
+                    a[n] = *(const bf16x8*)(Ws + L::w_off(n * 32 + l31, tap * CPP + c));
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    const bf16x8 xf = *(const bf16x8*)(Xs + L::x_off(2 * wave + pb + dy, l31 + dx, c));
+#pragma unroll
+                    for (int n = 0; n < NCB; ++n) acc[pb][n] = MFMA32(a[n], xf, acc[pb][n]);
+                }
+            }
+        }
+    }
+    // ---- epilogue: accumulator j of a lane = cout 8 (j >> 2) + 4 half + (j & 3) of pixel l31
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const int gy = ty0 + 2 * wave + pb, gx = tx0 + l31;
+        if (gy < H && gx < W) {
+            const size_t pix = (((size_t)b * H + gy) * W + gx) * Cout;
+#pragma unroll
+            for (int n = 0; n < NCB; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = co0 + n * 32 + 8 * q + 4 * half;
+                    if (co < Cout) {
+                        f32x4 v = {acc[pb][n][4 * q], acc[pb][n][4 * q + 1], acc[pb][n][4 * q + 2],
+                                   acc[pb][n][4 * q + 3]};
+                        if (bias) v += ld4(bias + co);
+                        if (relu_mask) {
+                            const f32x4 m = ld4(relu_mask + pix + co);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+                        }
+                        st4(y + pix + co, v);
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight gradient
+// One workgroup = (channel slice of 64 input channels, a strided share of the 8 x 32 tiles).
+// Wave w: input-channel block cb = w >> 1 (32 channels), taps 0-4 (w & 1 == 0) or 5-8.
+// LDS: X halo [10][34][64 ch] (the 64-byte halves of a pixel swapped by (hx >> 1) & 1, which keeps
+// the four pixel rows of a transposed read on different banks for every tap shift) and the dy tile
+// [256 pixels][32 couts].  k-step = 16 consecutive pixels of a tile row.
+#define WG_XS_BYTES (DC_HH * DC_HW * 128)
+#define WG_DY_BYTES (DC_TH * DC_TW * 64)
+DEVI int wg_x_off(int hy, int hx, int ch) {  // byte offset of channel ch (0..63) of a halo pixel
+    return (hy * DC_HW + hx) * 128 + ((((ch >> 5) ^ (hx >> 1)) & 1) << 6) + ((ch & 31) << 1);
+}
+// transposed 32 x 16 MFMA operand: lane (n = lane & 31, half) gets, for column n of a 32-column block,
+// the 8 k-rows (pixels) 8 half .. 8 half + 7 of a run.  Each 16-lane group transposes a 4 (k) x 16
+// (columns) block per ds_read_b64_tr_b16: lane i supplies the address of row i >> 2, columns
+// 4 (i & 3) .. + 3, and receives column i.  `p` = this lane's address in the first block (row
+// 8 half + (i >> 2)), `rs` = bytes per pixel row: the second block is 4 rows further on.
+DEVI bf16x8 tr_operand32(const char* p, const int rs) {
+    typedef __attribute__((address_space(3))) s16x4* lp_t;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(p + 4 * rs));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// one staged tile: 16 k-steps (tile row ks >> 1, columns 16 (ks & 1) ..) x the wave's taps.  Fully
+// unrolled with compile-time taps: every LDS address is a per-lane base (dbase; xbase[dx], which
+// carries the swizzle of the lane's pixel column) plus an immediate.
+// BIAS (one four-tap wave of the slice-0 workgroups): the spare fifth accumulator takes the bias
+// gradient — dy^T against a ones operand puts sum_pixels dy[p][co] into every column of row co.
+template <int TAP0, int NTAP, bool BIAS>
+DEVI void wgrad_tile(f32x16 (&acc)[5], const char* dbase, const char* const (&xbase)[3]) {
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+#pragma unroll
+    for (int ks = 0; ks < DC_TH * 2; ++ks) {
+        const int r = ks >> 1, c0 = (ks & 1) * 16;
+        const bf16x8 a = tr_operand32(dbase + (r * DC_TW + c0) * 64, 64);
+        if (BIAS) acc[4] = MFMA32(a, ones, acc[4]);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            const int tap = TAP0 + t, dyy = tap / 3, dxx = tap % 3;
+            const bf16x8 xf = tr_operand32(xbase[dxx] + ((r + dyy) * DC_HW + c0) * 128, 128);
+            acc[t] = MFMA32(a, xf, acc[t]);
+        }
+    }
+}
+
+// partial[wg][co 32][tap 9][ci 64] fp32, then partial_b[wg][co 32] (written by the workgroups of
+// slice 0 only); wg = blockIdx.x: channel slice = wg % nslice
+__global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
+    float* __restrict__ partial_b,
+    int Bn, int H, int W, int Cin, int relu_in, int tiles_x, int tiles_y, int nslice) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xs = smem;
+    char* Ds = smem + WG_XS_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.x % nslice, cin0 = slice * 64;
+    const int wgs_per_slice = gridDim.x / nslice, me = blockIdx.x / nslice;
+    const int cb = wave >> 1, tap0 = (wave & 1) * 5, ntap = (wave & 1) ? 4 : 5;  // wgrad_tile<tap0, ntap>
+    const int ntiles = tiles_x * tiles_y * Bn;
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+    // per-lane LDS bases of the transposed reads: pixel row k0 = 8 half + (i >> 2) of a 16-pixel
+    // run, columns 4 (i & 3) .. of the lane group's 16-column half (wg_x_off's swizzle depends on
+    // the pixel column only through (k0 + dx) >> 1: runs start at multiples of 16)
+    const int li = lane & 15, k0 = 8 * (lane >> 5) + (li >> 2), colb = (((lane >> 4) & 1) * 16 + 4 * (li & 3)) * 2;
+    const char* dbase = Ds + k0 * 64 + colb;
+    const char* const xbase[3] = {Xs + wg_x_off(0, k0, cb * 32) + colb, Xs + wg_x_off(0, k0 + 1, cb * 32) + colb,
+                                  Xs + wg_x_off(0, k0 + 2, cb * 32) + colb};
+    constexpr int NX = DC_HH * DC_HW * 8, IX = (NX + DC_THREADS - 1) / DC_THREADS;  // 16-byte chunks
+    constexpr int ND = DC_TH * DC_TW * 4, ID = ND / DC_THREADS;
+    for (int tile = me; tile < ntiles; tile += wgs_per_slice) {
+        int t = tile;
+        const int tx0 = (t % tiles_x) * DC_TW;
+        t /= tiles_x;
+        const int ty0 = (t % tiles_y) * DC_TH;
+        const int b = t / tiles_y;
+        u32x4 xv[IX], dv[ID];
+#pragma unroll
+        for (int i = 0; i < IX; ++i) {
+            const int idx = tid + i * DC_THREADS, pi = idx >> 3, c = idx & 7;
+            const int hy = pi / DC_HW, hx = pi % DC_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            xv[i] = u32x4{0, 0, 0, 0};
+            if (idx < NX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                xv[i] = *(const u32x4*)(x + (((size_t)b * H + gy) * W + gx) * Cin + cin0 + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < ID; ++i) {  // dy tile: pixel p = row * 32 + col, 4 chunks of 8 couts
+            const int idx = tid + i * DC_THREADS, p = idx >> 2, c = idx & 3;
+            const int gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
+            dv[i] = u32x4{0, 0, 0, 0};
+            if (gy < H && gx < W) dv[i] = *(const u32x4*)(dy + (((size_t)b * H + gy) * W + gx) * 32 + c * 8);
+        }
+        __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+        for (int i = 0; i < IX; ++i) {
+            const int idx = tid + i * DC_THREADS, pi = idx >> 3, c = idx & 7;
+            if (idx < NX)
+                *(u32x4*)(Xs + wg_x_off(pi / DC_HW, pi % DC_HW, c * 8)) = relu_in ? relu_bf16x8(xv[i]) : xv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < ID; ++i) {
+            const int idx = tid + i * DC_THREADS;
+            *(u32x4*)(Ds + (idx >> 2) * 64 + ((idx & 3) << 4)) = dv[i];
+        }
+        __syncthreads();
+        if (wave == 1 && slice == 0) wgrad_tile<5, 4, true>(acc, dbase, xbase);
+        else if (wave & 1) wgrad_tile<5, 4, false>(acc, dbase, xbase);
+        else wgrad_tile<0, 5, false>(acc, dbase, xbase);
+    }
+    // acc[t][j]: row (cout) = 8 (j >> 2) + 4 half + (j & 3), column (ci) = cb * 32 + (lane & 31)
+    float* out = partial + (size_t)blockIdx.x * (32 * 9 * 64);
+    const int half = lane >> 5, ci = cb * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+        if (t < ntap)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int co = 8 * (j >> 2) + 4 * half + (j & 3);
+                out[(co * 9 + tap0 + t) * 64 + ci] = acc[t][j];
+            }
+    if (wave == 1 && slice == 0 && (lane & 31) == 0)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) partial_b[blockIdx.x * 32 + 8 * (j >> 2) + 4 * half + (j & 3)] = acc[4][j];
+}
+
+// dW2[co, tap * Cin + ci] (+)= sum over the workgroups of ci's slice, in workgroup order; the last 32
+// threads do the same for dbias[co] over the workgroups of slice 0
+__global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial,
+                                            const float* __restrict__ partial_b, float* __restrict__ dw2,
+                                            float* __restrict__ dbias, int Cin, int nslice,
+                                            int wgs_per_slice, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over 32 * 9 * Cin (+ 32)
+    const int nw = 32 * 9 * Cin;
+    if (idx >= nw) {
+        const int co = idx - nw;
+        if (co < 32 && dbias) {
+            float s = 0.f;
+            for (int g = 0; g < wgs_per_slice; ++g) s += partial_b[(size_t)(g * nslice) * 32 + co];
+            dbias[co] = accumulate ? dbias[co] + s : s;
+        }
+        return;
+    }
+    const int ci = idx % Cin, tap = (idx / Cin) % 9, co = idx / (9 * Cin);
+    const int slice = ci >> 6, cl = ci & 63;
+    float s = 0.f;
+    for (int g = 0; g < wgs_per_slice; ++g)
+        s += partial[(size_t)(g * nslice + slice) * (32 * 9 * 64) + (co * 9 + tap) * 64 + cl];
+    float* o = dw2 + (size_t)co * 9 * Cin + tap * Cin + ci;
+    *o = accumulate ? *o + s : s;
+}
+
+// ------------------------------------------------------------------ C ABI
+static int direct_cfg(int Cin, int Cout, int* ck, int* ncb) {
+    if (Cin % 64 == 0) { *ck = 64; *ncb = 1; return 0; }
+    if (Cin % 32 == 0) { *ck = 32; *ncb = Cout > 32 ? 2 : 1; return 0; }
+    return 1;
+}
+
+extern "C" int ssl4gie_conv3x3_direct_ok(int B, int H, int W, int Cin, int Cout) {
+    int ck, ncb;
+    return B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && !direct_cfg(Cin, Cout, &ck, &ncb) &&
+           (long long)B * H * W * (Cin > Cout ? Cin : Cout) * 2 < (1LL << 40);
+}
+
+extern "C" int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const float* bias,
+                                          const void* relu_mask, void* y, int B, int H, int W, int Cin,
+                                          int Cout, int relu_in, void* stream) {
+    REQUIRE(x && w2 && y && ssl4gie_conv3x3_direct_ok(B, H, W, Cin, Cout));
+    int ck = 0, ncb = 0;
+    direct_cfg(Cin, Cout, &ck, &ncb);
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_x = (W + DC_TW - 1) / DC_TW, tiles_y = (H + DC_TH - 1) / DC_TH;
+    const dim3 grid((unsigned)(tiles_x * tiles_y * B), (unsigned)((Cout + 32 * ncb - 1) / (32 * ncb)));
+    ProfScope prof(PROF_GEMM_NT, 2.0 * B * H * (double)W * Cout * 9 * Cin, st);
+#define DC_LAUNCH(CK_, NCB_)                                                                          \
+    do {                                                                                              \
+        auto k = conv3x3_direct_kernel<CK_, NCB_>;                                                    \
+        const int lds = DcLay<CK_>::XS_BYTES + NCB_ * 32 * DcLay<CK_>::WROW;                          \
+        static bool attr = false;                                                                     \
+        if (!attr) {                                                                                  \
+            HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            attr = true;                                                                              \
+        }                                                                                             \
+        hipLaunchKernelGGL(k, grid, dim3(DC_THREADS), lds, st, (const bf16_t*)x, (const bf16_t*)w2,   \
+                           bias, (const bf16_t*)relu_mask, (bf16_t*)y, H, W, Cin, Cout, relu_in,      \
+                           tiles_x, tiles_y);                                                         \
+    } while (0)
+    if (ck == 64) DC_LAUNCH(64, 1);
+    else if (ncb == 2) DC_LAUNCH(32, 2);
+    else DC_LAUNCH(32, 1);
+#undef DC_LAUNCH
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static int wgrad_grid(int B, int H, int W, int Cin, int* nslice, int* wgs_per_slice) {
+    const int tiles = ((W + DC_TW - 1) / DC_TW) * ((H + DC_TH - 1) / DC_TH) * B;
+    *nslice = Cin / 64;
+    int per = (2 * ssl4gie_internal_compute_cus()) / *nslice;  // two workgroups per CU in all
+    if (per < 1) per = 1;
+    if (per > tiles) per = tiles;
+    *wgs_per_slice = per;
+    return *nslice * per;
+}
+
+extern "C" int ssl4gie_conv3x3_direct_wgrad_ok(int B, int H, int W, int Cin, int Cout) {
+    return B > 0 && H > 0 && W > 0 && Cout == 32 && Cin % 64 == 0 && Cin <= 512;
+}
+
+extern "C" size_t ssl4gie_conv3x3_direct_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, Cout)) return 0;
+    int ns, per;
+    return (size_t)wgrad_grid(B, H, W, Cin, &ns, &per) * (32 * 9 * 64 + 32) * sizeof(float);
+}
+
+extern "C" int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float* dw2, float* dbias,
+                                            void* workspace, size_t workspace_bytes, int B, int H,
+                                            int W, int Cin, int Cout, int relu_in, int accumulate,
+                                            void* stream) {
+    REQUIRE(dy && x && dw2 && workspace && ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, Cout));
+    REQUIRE(workspace_bytes >= ssl4gie_conv3x3_direct_wgrad_workspace_bytes(B, H, W, Cin, Cout));
+    hipStream_t st = (hipStream_t)stream;
+    int ns, per;
+    const int grid = wgrad_grid(B, H, W, Cin, &ns, &per);
+    const int tiles_x = (W + DC_TW - 1) / DC_TW, tiles_y = (H + DC_TH - 1) / DC_TH;
+    const int lds = WG_XS_BYTES + WG_DY_BYTES;
+    float* part_b = (float*)workspace + (size_t)grid * 32 * 9 * 64;
+    static bool attr = false;
+    if (!attr) {
+        HIP_RET(hipFuncSetAttribute((const void*)conv3x3_wgrad_direct_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    {
+        ProfScope prof(PROF_GEMM_TN, 2.0 * B * H * (double)W * Cout * 9 * Cin, st);
+        hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel, dim3(grid), dim3(DC_THREADS), lds, st,
+                           (const bf16_t*)dy, (const bf16_t*)x, (float*)workspace, part_b, B, H, W, Cin,
+                           relu_in, tiles_x, tiles_y, ns);
+        LAUNCH_CHECK();
+    }
+    const int n = 32 * 9 * Cin + 32;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
+                       (const float*)workspace, (const float*)part_b, dw2, dbias, Cin, ns, per, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -25,6 +25,8 @@ from .engine import GradSink, LPCache, weights_epoch
 
 # SSL4GIE_IMPLICIT_CONV=0 forces the materialised patch matrix (A/B measurements, parity tests)
 _IMPLICIT = os.environ.get("SSL4GIE_IMPLICIT_CONV", "1") != "0"
+# SSL4GIE_DIRECT_CONV=0 sends the narrow head convolutions through the GEMM paths again (A/B)
+_DIRECT = os.environ.get("SSL4GIE_DIRECT_CONV", "1") != "0"
 
 
 def _fills_chip(x, stride, n_out):
@@ -33,6 +35,12 @@ def _fills_chip(x, stride, n_out):
     B, H, W, _ = x.shape
     Ho, Wo = ops.conv_out_hw(H, W, stride)
     return ((B * Ho * Wo + 255) // 256) * ((n_out + 255) // 256) >= 96
+
+
+def _w_direct(lp, weight, dtype):
+    """[Cout, 9 Cin] operand of the direct kernels (taps row-major, channels innermost, unpadded)"""
+    Cout = weight.shape[0]
+    return _derived(lp, weight, "c3x", dtype, lambda w: w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
 
 
 def _derived(lp: LPCache, p: torch.Tensor, tag: str, dtype, fn):
@@ -112,6 +120,10 @@ class Conv3x3Fn(torch.autograd.Function):
                                           colstats=True)
                 y = y.view(B, Ho, Wo, Cout)
             ctx.mark_non_differentiable(stats)
+        elif _DIRECT and stride == 1 and ops.conv3x3_direct_ok(x, Cout):
+            # narrow layer (output_conv.2: 128 -> 32): halo-in-LDS kernel instead of a GEMM tile that
+            # would be 7/8 padding
+            y = ops.conv3x3_direct_fwd(x, w2 if ld == 9 * Cin else _w_direct(lp, weight, dt), b, relu_in)
         elif implicit and _fills_chip(x, stride, Cout):
             y = ops.conv3x3_fwd(x, w2, b, stride, relu_in)  # patch matrix gathered in the GEMM
         else:
@@ -130,7 +142,9 @@ class Conv3x3Fn(torch.autograd.Function):
         (tw, tb), acc, rets = sink.plan([weight, bias])
         if tw is not None:
             fuse_b = tb is not None and not acc  # the bias gradient rides on the same product
-            if _IMPLICIT and ops.conv3x3_implicit_ok(x, stride, Cout, wgrad=True):
+            if _DIRECT and stride == 1 and ops.conv3x3_direct_wgrad_ok(x, Cout):
+                dw2 = ops.conv3x3_direct_wgrad(dy2, x, relu_in, bias_out=tb if fuse_b else None)
+            elif _IMPLICIT and ops.conv3x3_implicit_ok(x, stride, Cout, wgrad=True):
                 dw2 = ops.conv3x3_bwd_weight(dy2, x, stride, relu_in, bias_out=tb if fuse_b else None)
             else:
                 cols = ops.im2col3x3(x, stride, relu_in, ld)  # recomputed, not kept
@@ -148,6 +162,12 @@ class Conv3x3Fn(torch.autograd.Function):
                 wd = _derived(lp, weight, f"c3d:{ld2}", dt,
                               lambda w: _pad_cols(w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout), ld2))
                 dy4 = dy.view(B, H, W, Cout)
+                if _DIRECT and ops.conv3x3_direct_ok(dy4, Cin):
+                    # the data gradient is the same direct kernel on dy with the flipped weight
+                    wdd = _derived(lp, weight, "c3dd", dt,
+                                   lambda w: w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous())
+                    dxr = ops.conv3x3_direct_fwd(dy4, wdd, None, relu_mask=x if relu_in else None)
+                    return dxr, rets[0], rets[1], None, None, None, None, None
                 if _IMPLICIT and ld2 == 9 * Cout and _fills_chip(dy4, 1, Cin) and \
                         ops.conv3x3_implicit_ok(dy4, 1, Cin):
                     # the ReLU in front of this convolution masks its data gradient in the epilogue

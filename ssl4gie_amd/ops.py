@@ -588,6 +588,60 @@ def conv3x3_bwd_weight(dy2d, x, stride=1, relu=False, bias_out=None):
     return out
 
 
+def conv3x3_direct_ok(x, n_out):
+    """whether the direct (halo-in-LDS) kernel takes this map: narrow layers the 256-wide GEMM tiles
+    would mostly pad (ssl4gie_conv3x3_direct_fwd)"""
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        return False
+    B, H, W, Cin = x.shape
+    return (n_out <= 64 or Cin == 32) and bool(_lib.load().ssl4gie_conv3x3_direct_ok(B, H, W, Cin, n_out))
+
+
+def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None):
+    """stride-1 3x3 convolution of the bf16 map x [B,H,W,Cin] with w2 [Cout, 9 Cin] on the direct
+    kernel; semantics of conv3x3_fwd (bias and relu_mask may be combined with relu here)."""
+    _dev(x, w2, bias, relu_mask)
+    B, H, W, Cin = _nhwc(x)
+    Cout, K = w2.shape
+    assert K == 9 * Cin and w2.dtype == x.dtype == torch.bfloat16 and w2.is_contiguous() and x.is_contiguous()
+    if bias is not None:
+        _f32(bias)
+        assert bias.numel() == Cout
+    if relu_mask is not None:
+        assert relu_mask.dtype == x.dtype and relu_mask.is_contiguous() and relu_mask.numel() == B * H * W * Cout
+    y = torch.empty(B, H, W, Cout, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().ssl4gie_conv3x3_direct_fwd(ptr(x), ptr(w2), ptr(bias), ptr(relu_mask), ptr(y),
+                                                      B, H, W, Cin, Cout, int(relu), stream()),
+               "conv3x3_direct_fwd")
+    return y
+
+
+def conv3x3_direct_wgrad_ok(x, n_out):
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        return False
+    B, H, W, Cin = x.shape
+    return bool(_lib.load().ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, n_out))
+
+
+def conv3x3_direct_wgrad(dy, x, relu=False, bias_out=None):
+    """dW2 [32, 9 Cin] fp32 of the direct convolution: dy [B,H,W,32] (or [B*H*W, 32]), x [B,H,W,Cin];
+    with `bias_out` [32] fp32 the bias gradient is produced by the same kernel"""
+    _dev(dy, x, bias_out)
+    if bias_out is not None:
+        assert bias_out.dtype == torch.float32 and bias_out.numel() == dy.shape[-1]
+    B, H, W, Cin = _nhwc(x)
+    Cout = dy.shape[-1]
+    assert dy.numel() == B * H * W * Cout and dy.dtype == x.dtype and dy.is_contiguous()
+    lib = _lib.load()
+    nbytes = lib.ssl4gie_conv3x3_direct_wgrad_workspace_bytes(B, H, W, Cin, Cout)
+    assert nbytes > 0, "conv3x3_direct_wgrad: unsupported geometry"
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty(Cout, 9 * Cin, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ssl4gie_conv3x3_direct_wgrad(ptr(dy), ptr(x), ptr(out), ptr(bias_out), ptr(ws), nbytes, B, H, W, Cin,
+                                                Cout, int(relu), 0, stream()), "conv3x3_direct_wgrad")
+    return out
+
+
 def col2im3x3(dcols, B, H, W, C, stride):
     _dev(dcols)
     dx = torch.empty(B, H, W, C, dtype=dcols.dtype, device=dcols.device)
