@@ -220,6 +220,39 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     }
 }
 
+// tall and narrow (cols in {4, 8, .., 128}: the 32-channel map in front of the depth head has millions
+// of rows): a wave covers 64 / lpr consecutive rows per load (lpr = cols / 4 lanes per row), so its
+// loads stay 256-1024 B contiguous, and folds its row groups with shuffles before the LDS stage
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_narrow_kernel(const T* __restrict__ x,
+                                                                    float* __restrict__ partial,
+                                                                    int rows, int cols, size_t ld,
+                                                                    int lpr) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = 64 / lpr, rl = lane / lpr, c = (lane % lpr) * 4;
+    f32x4 acc = {0, 0, 0, 0};
+    const int step = gridDim.y * 4 * rpw;
+    int r = (blockIdx.y * 4 + wave) * rpw + rl;
+    for (; r + 3 * step < rows; r += 4 * step) {  // four independent loads in flight
+        const f32x4 v0 = ld4(x + (size_t)r * ld + c), v1 = ld4(x + (size_t)(r + step) * ld + c);
+        const f32x4 v2 = ld4(x + (size_t)(r + 2 * step) * ld + c), v3 = ld4(x + (size_t)(r + 3 * step) * ld + c);
+        acc += (v0 + v1) + (v2 + v3);
+    }
+    for (; r < rows; r += step) acc += ld4(x + (size_t)r * ld + c);
+    for (int o = lpr; o < 64; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && lane < lpr) {
+        acc += red[0][lane];
+        acc += red[1][lane];
+        acc += red[2][lane];
+        st4(partial + (size_t)blockIdx.y * cols + c, acc);
+    }
+}
+
 int ssl4gie_internal_reduce_partials(const float* partial, float* out, int nparts, int n_out,
                                      size_t stride, int accumulate, hipStream_t st) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_out + 63) / 64), dim3(64 * RP_WAVES), 0, st,
@@ -318,22 +351,31 @@ extern "C" int ssl4gie_layernorm_bwd(const void* dy, int dy_dtype, const float* 
     return 0;
 }
 
-static int colsum_parts(int rows) {
+static bool colsum_narrow(int cols) { return cols <= 128 && cols % 4 == 0 && ((cols / 4) & (cols / 4 - 1)) == 0; }
+static int colsum_parts(int rows, int cols) {
+    const int cap = colsum_narrow(cols) ? 2048 : 256;  // narrow rows: partials are tiny, so more blocks
     int p = (rows + 63) / 64;
-    return p < 256 ? (p < 1 ? 1 : p) : 256;
+    return p < cap ? (p < 1 ? 1 : p) : cap;
 }
 extern "C" size_t ssl4gie_colsum_workspace_bytes(int rows, int cols) {
-    return (size_t)colsum_parts(rows) * cols * sizeof(float);
+    return (size_t)colsum_parts(rows, cols) * cols * sizeof(float);
 }
 extern "C" int ssl4gie_colsum(const void* x, int dtype, float* out, int accumulate,
                               float* workspace, int rows, int cols, long long ld, void* stream) {
     REQUIRE(x && out && workspace && rows >= 0 && cols > 0 && ld >= cols);
     REQUIRE(dtype == SSL4GIE_F32 || dtype == SSL4GIE_BF16);
     hipStream_t st = (hipStream_t)stream;
-    const int parts = colsum_parts(rows);
+    const int parts = colsum_parts(rows, cols);
     dim3 grid((cols + 255) / 256, parts), block(256);
     const bool vec = (cols % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
-    if (dtype == SSL4GIE_BF16) {
+    if (vec && colsum_narrow(cols)) {
+        if (dtype == SSL4GIE_BF16)
+            hipLaunchKernelGGL(colsum_partial_narrow_kernel<bf16_t>, dim3(1, parts), block, 0, st,
+                               (const bf16_t*)x, workspace, rows, cols, (size_t)ld, cols / 4);
+        else
+            hipLaunchKernelGGL(colsum_partial_narrow_kernel<float>, dim3(1, parts), block, 0, st,
+                               (const float*)x, workspace, rows, cols, (size_t)ld, cols / 4);
+    } else if (dtype == SSL4GIE_BF16) {
         if (vec)
             hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x,
                                workspace, rows, cols, (size_t)ld);

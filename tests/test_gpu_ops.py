@@ -70,6 +70,16 @@ def test_colsum():
         assert rel_err(out, xs.double().sum(0)) < tol
         odd = xs[:37, :6].contiguous()  # 6-class head: not a multiple of 4 columns
         assert rel_err(ops.colsum(odd.to(DEV)), odd.double().sum(0)) < tol
+    # tall and narrow (the 32-channel map in front of the depth head): the several-rows-per-wave
+    # kernel, exact with small integers; row counts around the block / unroll boundaries
+    for rows, cols in ((100003, 32), (5, 8), (4096 * 37 + 1, 4), (70001, 128), (2049, 64)):
+        xi = torch.randint(-3, 4, (rows, cols), generator=G(10)).float()
+        for dt in (F32, BF):
+            got = ops.colsum(xi.to(dt).to(DEV))
+            assert torch.equal(got.cpu().double(), xi.double().sum(0)), (rows, cols, dt)
+        acc = torch.ones(cols, device=DEV)
+        ops.colsum(xi.to(BF).to(DEV), out=acc, accumulate=True)
+        assert torch.equal(acc.cpu().double(), xi.double().sum(0) + 1)
 
 
 # ------------------------------------------------------------------ generic f32 GEMM
