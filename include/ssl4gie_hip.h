@@ -317,13 +317,13 @@ int ssl4gie_col2im3x3(const void* dcols, void* dx, int dtype, int B, int H, int 
  *     relu_mask [B,H,W,Cout] bf16 — the data gradient of a convolution behind a ReLU)
  * The data gradient is the same call on dy with w2 := weight.flip(2,3) as [Cin, 9*Cout].
  * _ok(): Cin % 32 == 0 and Cout % 8 == 0 (any H, W); otherwise the calls return SSL4GIE_EARG.
- * Meant for Cout <= 64 or Cin == 32; wider layers belong to ssl4gie_gemm with `conv`. */
+ * Meant for Cout <= 128 or Cin == 32 (at 256 -> 256 it merely ties the gathered GEMM). */
 int ssl4gie_conv3x3_direct_ok(int B, int H, int W, int Cin, int Cout);
 int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const float* bias,
                                const void* relu_mask, void* y, int B, int H, int W, int Cin,
                                int Cout, int relu_in, void* stream);
-/* dW2 [Cout = 32, 9*Cin] fp32 (+)= sum over pixels of dy [B,H,W,32] x patch(relu_in ? relu(x) : x);
- * Cin % 64 == 0; dbias [32] fp32 (+)= sum over pixels of dy, or NULL (it rides on a spare
+/* dW2 [Cout, 9*Cin] fp32 (+)= sum over pixels of dy [B,H,W,Cout] x patch(relu_in ? relu(x) : x);
+ * Cout % 32 == 0 (<= 256), Cin % 64 == 0 (<= 512); dbias [Cout] fp32 (+)= sum over pixels of dy, or NULL (it rides on a spare
  * accumulator of the same kernel).  Persistent workgroups write one fp32 partial each into the
  * workspace, a second kernel sums them in a fixed order (deterministic, no atomics). */
 int ssl4gie_conv3x3_direct_wgrad_ok(int B, int H, int W, int Cin, int Cout);

@@ -13,8 +13,8 @@
 //    gathered GEMM re-stages it per tap.  v_mfma_f32_32x32x16_bf16 (a <- 32 couts, b <- 32 pixels
 //    of one tile row): twice the flops per LDS byte of the 16x16x32 form, which is what a 32-wide
 //    output needs.  A lane ends up with 4 x 4 consecutive couts of one pixel.  XOR swizzles on the
-//    16-byte chunk index make both ds_read_b128 streams conflict-free (see DcLay).  Two workgroups
-//    share a CU (80 KiB LDS each at CK = 64), so one stages while the other computes.
+//    16-byte chunk index make both ds_read_b128 streams conflict-free (see DcLay).  Two or three
+//    workgroups share a CU (58 KiB LDS each), so one stages while the others compute.
 //  * conv3x3_wgrad_direct_kernel: dW[co][tap][ci] = sum_pixels dy[p][co] x[p + tap][ci].  The
 //    contraction runs over pixels, so both MFMA operands are read TRANSPOSED out of pixel-major LDS
 //    images with ds_read_b64_tr_b16 (k = 16 consecutive pixels of a tile row); the nine taps are
@@ -226,18 +226,21 @@ DEVI void wgrad_tile(f32x16 (&acc)[5], const char* dbase, const char* const (&xb
 }
 
 // partial[wg][co 32][tap 9][ci 64] fp32, then partial_b[wg][co 32] (written by the workgroups of
-// slice 0 only); wg = blockIdx.x: channel slice = wg % nslice
+// slice 0 only); wg = blockIdx.x: combo = wg % (nslice * ngroups) = group * nslice + slice picks the
+// 64 input channels and the 32 couts, wg / ncombo the share of the tiles
 __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
     float* __restrict__ partial_b,
-    int Bn, int H, int W, int Cin, int relu_in, int tiles_x, int tiles_y, int nslice) {
+    int Bn, int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y, int nslice,
+    int ncombo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xs = smem;
     char* Ds = smem + WG_XS_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slice = blockIdx.x % nslice, cin0 = slice * 64;
-    const int wgs_per_slice = gridDim.x / nslice, me = blockIdx.x / nslice;
+    const int combo = blockIdx.x % ncombo, slice = combo % nslice, cin0 = slice * 64;
+    const int co0 = (combo / nslice) * 32;
+    const int wgs_per_slice = gridDim.x / ncombo, me = blockIdx.x / ncombo;
     const int cb = wave >> 1, tap0 = (wave & 1) * 5, ntap = (wave & 1) ? 4 : 5;  // wgrad_tile<tap0, ntap>
     const int ntiles = tiles_x * tiles_y * Bn;
 
@@ -277,7 +280,8 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
             const int idx = tid + i * DC_THREADS, p = idx >> 2, c = idx & 3;
             const int gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
             dv[i] = u32x4{0, 0, 0, 0};
-            if (gy < H && gx < W) dv[i] = *(const u32x4*)(dy + (((size_t)b * H + gy) * W + gx) * 32 + c * 8);
+            if (gy < H && gx < W)
+                dv[i] = *(const u32x4*)(dy + (((size_t)b * H + gy) * W + gx) * Cout + co0 + c * 8);
         }
         __syncthreads();  // the previous tile has been consumed
 #pragma unroll
@@ -312,37 +316,42 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
         for (int j = 0; j < 16; ++j) partial_b[blockIdx.x * 32 + 8 * (j >> 2) + 4 * half + (j & 3)] = acc[4][j];
 }
 
-// dW2[co, tap * Cin + ci] (+)= sum over the workgroups of ci's slice, in workgroup order; the last 32
-// threads do the same for dbias[co] over the workgroups of slice 0
+// dW2[co, tap * Cin + ci] (+)= sum over the workgroups of (co's group, ci's slice), in workgroup
+// order; the last Cout threads do the same for dbias[co] over the slice-0 workgroups of co's group
 __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial,
                                             const float* __restrict__ partial_b, float* __restrict__ dw2,
-                                            float* __restrict__ dbias, int Cin, int nslice,
-                                            int wgs_per_slice, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over 32 * 9 * Cin (+ 32)
-    const int nw = 32 * 9 * Cin;
+                                            float* __restrict__ dbias, int Cin, int Cout, int nslice,
+                                            int ncombo, int wgs_per_combo, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over Cout * 9 * Cin (+ Cout)
+    const int nw = Cout * 9 * Cin;
     if (idx >= nw) {
         const int co = idx - nw;
-        if (co < 32 && dbias) {
+        if (co < Cout && dbias) {
             float s = 0.f;
-            for (int g = 0; g < wgs_per_slice; ++g) s += partial_b[(size_t)(g * nslice) * 32 + co];
+            for (int g = 0; g < wgs_per_combo; ++g)
+                s += partial_b[(size_t)(g * ncombo + (co >> 5) * nslice) * 32 + (co & 31)];
             dbias[co] = accumulate ? dbias[co] + s : s;
         }
         return;
     }
     const int ci = idx % Cin, tap = (idx / Cin) % 9, co = idx / (9 * Cin);
-    const int slice = ci >> 6, cl = ci & 63;
+    const int combo = (co >> 5) * nslice + (ci >> 6), cl = ci & 63;
     float s = 0.f;
-    for (int g = 0; g < wgs_per_slice; ++g)
-        s += partial[(size_t)(g * nslice + slice) * (32 * 9 * 64) + (co * 9 + tap) * 64 + cl];
+    for (int g = 0; g < wgs_per_combo; ++g)
+        s += partial[(size_t)(g * ncombo + combo) * (32 * 9 * 64) + ((co & 31) * 9 + tap) * 64 + cl];
     float* o = dw2 + (size_t)co * 9 * Cin + tap * Cin + ci;
     *o = accumulate ? *o + s : s;
 }
 
 // ------------------------------------------------------------------ C ABI
+// 32 staged channels per pass and up to 64 couts per workgroup: 58 KiB of LDS, so two to three
+// workgroups overlap their staging on a CU.  (64-channel passes with 32 couts — 80 KiB — measured
+// slower at every geometry tried: 128 -> 32 @224 746 vs 666 us, 256 -> 128 @112 1532 vs 1227 us.)
 static int direct_cfg(int Cin, int Cout, int* ck, int* ncb) {
-    if (Cin % 64 == 0) { *ck = 64; *ncb = 1; return 0; }
-    if (Cin % 32 == 0) { *ck = 32; *ncb = Cout > 32 ? 2 : 1; return 0; }
-    return 1;
+    if (Cin % 32 != 0) return 1;
+    *ck = 32;
+    *ncb = Cout > 32 ? 2 : 1;
+    return 0;
 }
 
 extern "C" int ssl4gie_conv3x3_direct_ok(int B, int H, int W, int Cin, int Cout) {
@@ -374,32 +383,33 @@ extern "C" int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const f
                            bias, (const bf16_t*)relu_mask, (bf16_t*)y, H, W, Cin, Cout, relu_in,      \
                            tiles_x, tiles_y);                                                         \
     } while (0)
-    if (ck == 64) DC_LAUNCH(64, 1);
-    else if (ncb == 2) DC_LAUNCH(32, 2);
+    if (ncb == 2) DC_LAUNCH(32, 2);
     else DC_LAUNCH(32, 1);
 #undef DC_LAUNCH
     LAUNCH_CHECK();
     return 0;
 }
 
-static int wgrad_grid(int B, int H, int W, int Cin, int* nslice, int* wgs_per_slice) {
+static int wgrad_grid(int B, int H, int W, int Cin, int Cout, int* nslice, int* ncombo, int* per_combo) {
     const int tiles = ((W + DC_TW - 1) / DC_TW) * ((H + DC_TH - 1) / DC_TH) * B;
     *nslice = Cin / 64;
-    int per = (2 * ssl4gie_internal_compute_cus()) / *nslice;  // two workgroups per CU in all
+    *ncombo = *nslice * (Cout / 32);
+    int per = (2 * ssl4gie_internal_compute_cus()) / *ncombo;  // two workgroups per CU in all
     if (per < 1) per = 1;
     if (per > tiles) per = tiles;
-    *wgs_per_slice = per;
-    return *nslice * per;
+    *per_combo = per;
+    return *ncombo * per;
 }
 
 extern "C" int ssl4gie_conv3x3_direct_wgrad_ok(int B, int H, int W, int Cin, int Cout) {
-    return B > 0 && H > 0 && W > 0 && Cout == 32 && Cin % 64 == 0 && Cin <= 512;
+    return B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 32 == 0 && Cout <= 256 && Cin > 0 &&
+           Cin % 64 == 0 && Cin <= 512;
 }
 
 extern "C" size_t ssl4gie_conv3x3_direct_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (!ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, Cout)) return 0;
-    int ns, per;
-    return (size_t)wgrad_grid(B, H, W, Cin, &ns, &per) * (32 * 9 * 64 + 32) * sizeof(float);
+    int ns, nc, per;
+    return (size_t)wgrad_grid(B, H, W, Cin, Cout, &ns, &nc, &per) * (32 * 9 * 64 + 32) * sizeof(float);
 }
 
 extern "C" int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float* dw2, float* dbias,
@@ -409,8 +419,8 @@ extern "C" int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float
     REQUIRE(dy && x && dw2 && workspace && ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, Cout));
     REQUIRE(workspace_bytes >= ssl4gie_conv3x3_direct_wgrad_workspace_bytes(B, H, W, Cin, Cout));
     hipStream_t st = (hipStream_t)stream;
-    int ns, per;
-    const int grid = wgrad_grid(B, H, W, Cin, &ns, &per);
+    int ns, nc, per;
+    const int grid = wgrad_grid(B, H, W, Cin, Cout, &ns, &nc, &per);
     const int tiles_x = (W + DC_TW - 1) / DC_TW, tiles_y = (H + DC_TH - 1) / DC_TH;
     const int lds = WG_XS_BYTES + WG_DY_BYTES;
     float* part_b = (float*)workspace + (size_t)grid * 32 * 9 * 64;
@@ -424,12 +434,13 @@ extern "C" int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float
         ProfScope prof(PROF_GEMM_TN, 2.0 * B * H * (double)W * Cout * 9 * Cin, st);
         hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel, dim3(grid), dim3(DC_THREADS), lds, st,
                            (const bf16_t*)dy, (const bf16_t*)x, (float*)workspace, part_b, B, H, W, Cin,
-                           relu_in, tiles_x, tiles_y, ns);
+                           Cout, relu_in, tiles_x, tiles_y, ns, nc);
         LAUNCH_CHECK();
     }
-    const int n = 32 * 9 * Cin + 32;
+    const int n = Cout * 9 * Cin + Cout;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
-                       (const float*)workspace, (const float*)part_b, dw2, dbias, Cin, ns, per, accumulate);
+                       (const float*)workspace, (const float*)part_b, dw2, dbias, Cin, Cout, ns, nc, per,
+                       accumulate);
     LAUNCH_CHECK();
     return 0;
 }

@@ -594,7 +594,7 @@ def conv3x3_direct_ok(x, n_out):
     if x.dtype != torch.bfloat16 or not x.is_contiguous():
         return False
     B, H, W, Cin = x.shape
-    return (n_out <= 64 or Cin == 32) and bool(_lib.load().ssl4gie_conv3x3_direct_ok(B, H, W, Cin, n_out))
+    return (n_out <= 128 or Cin == 32) and bool(_lib.load().ssl4gie_conv3x3_direct_ok(B, H, W, Cin, n_out))
 
 
 def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None):
@@ -617,15 +617,16 @@ def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None):
 
 
 def conv3x3_direct_wgrad_ok(x, n_out):
+    """narrow layers only (n_out <= 128): from 256 couts on the gathered TN GEMM has full tiles"""
     if x.dtype != torch.bfloat16 or not x.is_contiguous():
         return False
     B, H, W, Cin = x.shape
-    return bool(_lib.load().ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, n_out))
+    return n_out <= 128 and bool(_lib.load().ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, n_out))
 
 
 def conv3x3_direct_wgrad(dy, x, relu=False, bias_out=None):
-    """dW2 [32, 9 Cin] fp32 of the direct convolution: dy [B,H,W,32] (or [B*H*W, 32]), x [B,H,W,Cin];
-    with `bias_out` [32] fp32 the bias gradient is produced by the same kernel"""
+    """dW2 [Cout, 9 Cin] fp32 of the direct convolution: dy [B,H,W,Cout] (or [B*H*W, Cout], Cout % 32 == 0),
+    x [B,H,W,Cin]; with `bias_out` [Cout] fp32 the bias gradient is produced by the same kernel"""
     _dev(dy, x, bias_out)
     if bias_out is not None:
         assert bias_out.dtype == torch.float32 and bias_out.numel() == dy.shape[-1]

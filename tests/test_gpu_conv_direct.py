@@ -3,8 +3,8 @@ output head (reference: nn.Conv2d(128, 32, 3, 1, 1), Models/DPT_decoder.py:473-4
 gradients).  Operands are small integers, so every product and every partial sum is exact in
 bf16 / fp32 and the comparison with torch's fp64 convolution on the CPU is BIT-EXACT: a wrong
 halo offset, swizzle, tap shift, MFMA lane mapping or edge mask is an integer error.  Geometries
-cover both staged channel widths (64 and 32), one and two 32-cout blocks, maps that are not a
-multiple of the 8 x 32 tile, single-row / single-column maps, and the production 224 x 224 map."""
+cover one to six 32-channel passes, one and two 32-cout blocks per workgroup, several cout groups,
+maps that are not a multiple of the 8 x 32 tile, single-row / single-column maps, and the production 224 x 224 map."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -40,12 +40,13 @@ def w2_of(w):  # [Co,Ci,3,3] -> [Co, 9 Ci], taps row-major, channels innermost
 
 
 GEOMS = [  # B, H, W, Cin, Cout
-    (2, 16, 64, 128, 32),   # CK = 64, two channel slices, whole tiles
+    (2, 16, 64, 128, 32),   # output_conv.2: four channel passes, whole tiles
     (1, 13, 37, 64, 32),    # ragged map
-    (2, 9, 33, 32, 128),    # CK = 32, two 32-cout blocks per workgroup, two cout groups (data-gradient shape)
+    (2, 9, 33, 32, 128),    # two 32-cout blocks per workgroup, two cout groups (data-gradient shape)
     (1, 1, 5, 32, 8),       # single row, fewer couts than one block
     (1, 40, 1, 64, 24),     # single column
-    (3, 8, 32, 96, 40),     # Cin % 64 != 0 -> CK = 32 with three slices; Cout not a multiple of 32
+    (3, 8, 32, 96, 40),     # three passes; Cout not a multiple of 32
+    (1, 11, 40, 192, 128),  # output_conv.0-like: six passes, two cout groups of 64
 ]
 
 
@@ -75,11 +76,11 @@ def test_direct_conv_relu_mask_epilogue_exact(B, H, W, Ci, Co):
     assert torch.equal(y.double().cpu(), ref)
 
 
-@pytest.mark.parametrize("B,H,W,Ci", [(2, 16, 64, 128), (1, 13, 37, 64), (3, 5, 100, 192), (1, 1, 3, 64)])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 64, 128, 32), (1, 13, 37, 64, 32), (3, 5, 100, 192, 32),
+                                         (1, 1, 3, 64, 32), (2, 9, 40, 128, 128), (1, 17, 33, 64, 96)])
 @pytest.mark.parametrize("relu_in", [False, True])
-def test_direct_conv_weight_gradient_exact(B, H, W, Ci, relu_in):
+def test_direct_conv_weight_gradient_exact(B, H, W, Ci, Co, relu_in):
     from ssl4gie_amd import ops
-    Co = 32
     x = ints((B, H, W, Ci), 31)
     dy = ints((B, H, W, Co), 32, -1, 2)
     xr = x.clamp_min(0) if relu_in else x

@@ -4,7 +4,7 @@ forward, data gradient and weight gradient of output_conv.0 (256->128 @112^2) an
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ssl4gie_amd import ops
+from ssl4gie_amd import ops, _lib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 CASES = [("output_conv.0 256>128 @112", 112, 256, 128), ("output_conv.2 128>32 @224", 224, 128, 32),
@@ -39,6 +39,12 @@ for name, HW, Ci, Co in CASES:
                                                         out_dtype=torch.bfloat16).view(B, HW, HW, Ci)))
         how = "im2col"
     w = timeit(lambda: ops.conv3x3_bwd_weight(dy.view(-1, Co), x, 1, True, bias_out=bias))
+    if os.environ.get('FORCE_DIRECT'):
+        fd = timeit(lambda: ops.conv3x3_direct_fwd(x, w2, bias, relu=True))
+        print(f'{name:30s} B={B}: DIRECT(forced) fwd {fd:8.1f} us ({fl / fd / 1e6:6.1f} TF/s)', flush=True)
+    if os.environ.get('FORCE_DIRECT') and _lib.load().ssl4gie_conv3x3_direct_wgrad_ok(B, HW, HW, Ci, Co):
+        wf = timeit(lambda: ops.conv3x3_direct_wgrad(dy, x, relu=True, bias_out=bias))
+        print(f'{name:30s} B={B}: DIRECT(forced) wgrad {wf:8.1f} us ({fl / wf / 1e6:6.1f} TF/s)', flush=True)
     if ops.conv3x3_direct_ok(x, Co):
         fd = timeit(lambda: ops.conv3x3_direct_fwd(x, w2, bias, relu=True))
         dd = timeit(lambda: ops.conv3x3_direct_fwd(dy, wd, None, relu_mask=x))
