@@ -315,13 +315,18 @@ int ssl4gie_col2im3x3(const void* dcols, void* dx, int dtype, int B, int H, int 
  * of the implicit-GEMM path: taps row-major, channels innermost), y [B,H,W,Cout]:
  *     y = conv(relu_in ? relu(x) : x, w2) (+ bias[Cout] fp32)  (then y = relu_mask > 0 ? y : 0, with
  *     relu_mask [B,H,W,Cout] bf16 — the data gradient of a convolution behind a ReLU)
+ * colstats (optional, not together with relu_mask): fp32 [ssl4gie_conv3x3_direct_tiles(B,H,W)][2][Cout],
+ * per 8 x 32 pixel tile the column sums ([0]) and sums of squares ([1]) of the stored y — the
+ * partial statistics ssl4gie_bn_fwd_partials / ssl4gie_bn_stats_partials take (as
+ * ssl4gie_gemm_desc.colstats, with one partial per tile instead of per 128 rows).
  * The data gradient is the same call on dy with w2 := weight.flip(2,3) as [Cin, 9*Cout].
  * _ok(): Cin % 32 == 0 and Cout % 8 == 0 (any H, W); otherwise the calls return SSL4GIE_EARG.
  * Meant for Cout <= 128 or Cin == 32 (at 256 -> 256 it merely ties the gathered GEMM). */
 int ssl4gie_conv3x3_direct_ok(int B, int H, int W, int Cin, int Cout);
+int ssl4gie_conv3x3_direct_tiles(int B, int H, int W);
 int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const float* bias,
-                               const void* relu_mask, void* y, int B, int H, int W, int Cin,
-                               int Cout, int relu_in, void* stream);
+                               const void* relu_mask, void* y, float* colstats, int B, int H, int W,
+                               int Cin, int Cout, int relu_in, void* stream);
 /* dW2 [Cout, 9*Cin] fp32 (+)= sum over pixels of dy [B,H,W,Cout] x patch(relu_in ? relu(x) : x);
  * Cout % 32 == 0 (<= 256), Cin % 64 == 0 (<= 512); dbias [Cout] fp32 (+)= sum over pixels of dy, or NULL (it rides on a spare
  * accumulator of the same kernel).  Persistent workgroups write one fp32 partial each into the

@@ -92,7 +92,8 @@ PROTOTYPES = {
     "ssl4gie_im2col3x3": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, vp]),
     "ssl4gie_col2im3x3": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i64, vp]),
     "ssl4gie_conv3x3_direct_ok": (i32, [i32, i32, i32, i32, i32]),
-    "ssl4gie_conv3x3_direct_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_conv3x3_direct_tiles": (i32, [i32, i32, i32]),
+    "ssl4gie_conv3x3_direct_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_conv3x3_direct_wgrad_ok": (i32, [i32, i32, i32, i32, i32]),
     "ssl4gie_conv3x3_direct_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "ssl4gie_conv3x3_direct_wgrad": (i32, [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, vp]),

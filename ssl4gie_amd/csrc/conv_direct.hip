@@ -67,12 +67,13 @@ template <int CK> struct DcLay {
 };
 
 // y[b, oy, ox, co] = sum_{tap, ci} act(x)[b, oy + dy - 1, ox + dx - 1, ci] w2[co, tap * Cin + ci]
-// (+ bias[co]) (masked by relu_mask > 0).  grid = (tiles_x * tiles_y * B, ceil(Cout / (32 NCB))).
+// (+ bias[co]) (masked by relu_mask > 0); colstats [tiles][2][Cout]: per-tile sums / sums of squares
+// of y.  grid = (tiles_x * tiles_y * B, ceil(Cout / (32 NCB))).
 template <int CK, int NCB>
 __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w2, const float* __restrict__ bias,
-    const bf16_t* __restrict__ relu_mask, bf16_t* __restrict__ y, int H, int W, int Cin, int Cout,
-    int relu_in, int tiles_x, int tiles_y) {
+    const bf16_t* __restrict__ relu_mask, bf16_t* __restrict__ y, float* __restrict__ colstats, int H,
+    int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y) {
     using L = DcLay<CK>;
     constexpr int CPP = L::CPP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,29 +151,77 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
             }
         }
     }
-    // ---- epilogue: accumulator j of a lane = cout 8 (j >> 2) + 4 half + (j & 3) of pixel l31
+    // ---- epilogue.  Accumulator j of a lane = cout 8 (j >> 2) + 4 half + (j & 3) of pixel l31: 8-byte
+    // pieces 64-128 B apart.  The finished bf16 tile goes through LDS ([256 pixels][32 NCB couts],
+    // 8-byte slots XOR-ed with the pixel index against bank conflicts) and leaves as whole 16-byte
+    // chunks of consecutive pixels; the ReLU mask is read the same way.  Pixels outside the map are
+    // staged as zeros, so the BatchNorm statistics below need no mask.
+    constexpr int NC = 32 * NCB, ROWB = NC * 2, SLOTS = ROWB / 8, SM = SLOTS - 1;
+    __syncthreads();  // every wave is done with the operand images
+    char* Os = smem;
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
-        const int gy = ty0 + 2 * wave + pb, gx = tx0 + l31;
-        if (gy < H && gx < W) {
-            const size_t pix = (((size_t)b * H + gy) * W + gx) * Cout;
+        const int p = (2 * wave + pb) * DC_TW + l31;
+        const bool valid = ty0 + 2 * wave + pb < H && tx0 + l31 < W;
 #pragma unroll
-            for (int n = 0; n < NCB; ++n)
+        for (int n = 0; n < NCB; ++n)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int co = co0 + n * 32 + 8 * q + 4 * half;
-                    if (co < Cout) {
-                        f32x4 v = {acc[pb][n][4 * q], acc[pb][n][4 * q + 1], acc[pb][n][4 * q + 2],
-                                   acc[pb][n][4 * q + 3]};
-                        if (bias) v += ld4(bias + co);
-                        if (relu_mask) {
-                            const f32x4 m = ld4(relu_mask + pix + co);
+            for (int q = 0; q < 4; ++q) {
+                const int slot = n * 8 + 2 * q + half, co = co0 + slot * 4;
+                f32x4 v = {acc[pb][n][4 * q], acc[pb][n][4 * q + 1], acc[pb][n][4 * q + 2],
+                           acc[pb][n][4 * q + 3]};
+                if (bias && co < Cout) v += ld4(bias + co);
+                if (!valid || co >= Cout) v = f32x4{0, 0, 0, 0};
+                st4((bf16_t*)(Os + p * ROWB + ((slot ^ (p & SM)) << 3)), v);
+            }
+    }
+    __syncthreads();
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
-                        }
-                        st4(y + pix + co, v);
-                    }
+    for (int i = 0; i < SLOTS / 2; ++i) {
+        const int idx = tid + i * DC_THREADS, p = idx / (SLOTS / 2), j = idx % (SLOTS / 2);
+        const int sw = p & SM;
+        u32x4 v = *(const u32x4*)(Os + p * ROWB + ((j ^ (sw >> 1)) << 4));
+        if (sw & 1) v = u32x4{v[2], v[3], v[0], v[1]};  // the two slots of the chunk sit swapped
+        const int gy = ty0 + p / DC_TW, gx = tx0 + p % DC_TW, co = co0 + 8 * j;
+        if (gy < H && gx < W && co < Cout) {
+            const size_t o = (((size_t)b * H + gy) * W + gx) * Cout + co;
+            if (relu_mask) {  // keep where mask > 0: sign bit clear and not zero
+                const u32x4 m = *(const u32x4*)(relu_mask + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned lo = ((m[k] & 0x8000u) == 0 && (m[k] & 0x7fffu) != 0) ? 0xffffu : 0u;
+                    const unsigned hi = ((m[k] & 0x80000000u) == 0 && (m[k] & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                    v[k] &= lo | hi;
                 }
+            }
+            *(u32x4*)(y + o) = v;
+        }
+    }
+    if (colstats) {
+        // per-tile column sums and sums of squares of the STORED values (ssl4gie_gemm_desc.colstats
+        // semantics with one partial per tile): thread = (cout c, one of 256 / NC pixel groups)
+        constexpr int G = DC_THREADS / NC, PPG = DC_TH * DC_TW / G;
+        float* red = (float*)(smem + DC_TH * DC_TW * ROWB);  // [G][2][NC]
+        const int c = tid % NC, g = tid / NC;
+        float sum = 0.f, sq = 0.f;
+        for (int p = g * PPG; p < (g + 1) * PPG; ++p) {
+            const float v = bf2f(*(const bf16_t*)(Os + p * ROWB + (((c >> 2) ^ (p & SM)) << 3) + ((c & 3) << 1)));
+            sum += v;
+            sq += v * v;
+        }
+        red[(g * 2) * NC + c] = sum;
+        red[(g * 2 + 1) * NC + c] = sq;
+        __syncthreads();
+        if (tid < NC && co0 + tid < Cout) {
+            sum = 0.f, sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                sum += red[(k * 2) * NC + tid];
+                sq += red[(k * 2 + 1) * NC + tid];
+            }
+            float* o = colstats + (size_t)blockIdx.x * 2 * Cout + co0 + tid;
+            o[0] = sum;
+            o[Cout] = sq;
         }
     }
 }
@@ -360,10 +409,15 @@ extern "C" int ssl4gie_conv3x3_direct_ok(int B, int H, int W, int Cin, int Cout)
            (long long)B * H * W * (Cin > Cout ? Cin : Cout) * 2 < (1LL << 40);
 }
 
+extern "C" int ssl4gie_conv3x3_direct_tiles(int B, int H, int W) {
+    return ((W + DC_TW - 1) / DC_TW) * ((H + DC_TH - 1) / DC_TH) * B;
+}
+
 extern "C" int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const float* bias,
-                                          const void* relu_mask, void* y, int B, int H, int W, int Cin,
-                                          int Cout, int relu_in, void* stream) {
+                                          const void* relu_mask, void* y, float* colstats, int B, int H,
+                                          int W, int Cin, int Cout, int relu_in, void* stream) {
     REQUIRE(x && w2 && y && ssl4gie_conv3x3_direct_ok(B, H, W, Cin, Cout));
+    REQUIRE(!(colstats && relu_mask));
     int ck = 0, ncb = 0;
     direct_cfg(Cin, Cout, &ck, &ncb);
     hipStream_t st = (hipStream_t)stream;
@@ -373,15 +427,17 @@ extern "C" int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const f
 #define DC_LAUNCH(CK_, NCB_)                                                                          \
     do {                                                                                              \
         auto k = conv3x3_direct_kernel<CK_, NCB_>;                                                    \
-        const int lds = DcLay<CK_>::XS_BYTES + NCB_ * 32 * DcLay<CK_>::WROW;                          \
+        int lds = DcLay<CK_>::XS_BYTES + NCB_ * 32 * DcLay<CK_>::WROW;                                \
+        const int lds_out = DC_TH * DC_TW * NCB_ * 64 + 2 * DC_THREADS * (int)sizeof(float);          \
+        if (lds < lds_out) lds = lds_out;                                                             \
         static bool attr = false;                                                                     \
         if (!attr) {                                                                                  \
             HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
             attr = true;                                                                              \
         }                                                                                             \
         hipLaunchKernelGGL(k, grid, dim3(DC_THREADS), lds, st, (const bf16_t*)x, (const bf16_t*)w2,   \
-                           bias, (const bf16_t*)relu_mask, (bf16_t*)y, H, W, Cin, Cout, relu_in,      \
-                           tiles_x, tiles_y);                                                         \
+                           bias, (const bf16_t*)relu_mask, (bf16_t*)y, colstats, H, W, Cin, Cout,     \
+                           relu_in, tiles_x, tiles_y);                                                \
     } while (0)
     if (ncb == 2) DC_LAUNCH(32, 2);
     else DC_LAUNCH(32, 1);

@@ -111,7 +111,13 @@ class Conv3x3Fn(torch.autograd.Function):
         implicit = _IMPLICIT and ld == 9 * Cin and ops.conv3x3_implicit_ok(x, stride, Cout)
         Ho, Wo = ops.conv_out_hw(H, W, stride)
         stats = None
-        if want_stats and b is None and dt == torch.bfloat16 and Cout % 8 == 0 and ld % 64 == 0:
+        direct = _DIRECT and stride == 1 and ops.conv3x3_direct_ok(x, Cout)
+        if direct and want_stats and b is None:
+            # narrow ResNet layers (64 -> 64 @56, 128 -> 128 @28): direct kernel, statistics per tile
+            y, stats = ops.conv3x3_direct_fwd(x, w2 if ld == 9 * Cin else _w_direct(lp, weight, dt), None,
+                                              relu_in, colstats=True)
+            ctx.mark_non_differentiable(stats)
+        elif want_stats and b is None and dt == torch.bfloat16 and Cout % 8 == 0 and ld % 64 == 0:
             # the statistics only exist in the 256x256 kernel: taken whatever the tile count
             if implicit:
                 y, stats = ops.conv3x3_fwd(x, w2, None, stride, relu_in, colstats=True)
@@ -120,7 +126,7 @@ class Conv3x3Fn(torch.autograd.Function):
                                           colstats=True)
                 y = y.view(B, Ho, Wo, Cout)
             ctx.mark_non_differentiable(stats)
-        elif _DIRECT and stride == 1 and ops.conv3x3_direct_ok(x, Cout):
+        elif direct:
             # narrow layer (output_conv.2: 128 -> 32): halo-in-LDS kernel instead of a GEMM tile that
             # would be 7/8 padding
             y = ops.conv3x3_direct_fwd(x, w2 if ld == 9 * Cin else _w_direct(lp, weight, dt), b, relu_in)

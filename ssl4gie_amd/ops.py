@@ -597,9 +597,10 @@ def conv3x3_direct_ok(x, n_out):
     return (n_out <= 128 or Cin == 32) and bool(_lib.load().ssl4gie_conv3x3_direct_ok(B, H, W, Cin, n_out))
 
 
-def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None):
+def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None, colstats=False):
     """stride-1 3x3 convolution of the bf16 map x [B,H,W,Cin] with w2 [Cout, 9 Cin] on the direct
-    kernel; semantics of conv3x3_fwd (bias and relu_mask may be combined with relu here)."""
+    kernel; semantics of conv3x3_fwd (bias and relu_mask may be combined with relu here).
+    colstats: also return the BatchNorm partial statistics [tiles, 2, Cout] of y."""
     _dev(x, w2, bias, relu_mask)
     B, H, W, Cin = _nhwc(x)
     Cout, K = w2.shape
@@ -610,10 +611,14 @@ def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None):
     if relu_mask is not None:
         assert relu_mask.dtype == x.dtype and relu_mask.is_contiguous() and relu_mask.numel() == B * H * W * Cout
     y = torch.empty(B, H, W, Cout, dtype=x.dtype, device=x.device)
-    _lib.check(_lib.load().ssl4gie_conv3x3_direct_fwd(ptr(x), ptr(w2), ptr(bias), ptr(relu_mask), ptr(y),
-                                                      B, H, W, Cin, Cout, int(relu), stream()),
-               "conv3x3_direct_fwd")
-    return y
+    L = _lib.load()
+    stats = None
+    if colstats:
+        assert relu_mask is None
+        stats = torch.empty(L.ssl4gie_conv3x3_direct_tiles(B, H, W), 2, Cout, dtype=torch.float32, device=x.device)
+    _lib.check(L.ssl4gie_conv3x3_direct_fwd(ptr(x), ptr(w2), ptr(bias), ptr(relu_mask), ptr(y), ptr(stats),
+                                            B, H, W, Cin, Cout, int(relu), stream()), "conv3x3_direct_fwd")
+    return (y, stats) if colstats else y
 
 
 def conv3x3_direct_wgrad_ok(x, n_out):

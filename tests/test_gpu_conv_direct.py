@@ -64,6 +64,22 @@ def test_direct_conv_forward_exact(B, H, W, Ci, Co, relu_in):
     assert torch.equal(y.double().cpu(), ref)
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 64, 64, 64), (1, 13, 37, 64, 32), (2, 9, 33, 128, 128),
+                                         (1, 5, 40, 32, 40)])
+def test_direct_conv_batchnorm_partials_exact(B, H, W, Ci, Co):
+    """colstats: per-tile column sums / sums of squares of the stored outputs (what BatchNormFn takes
+    from the producing convolution); ragged tiles must not count their overhang"""
+    from ssl4gie_amd import _lib, ops
+    x = ints((B, H, W, Ci), 41)
+    w = ints((Co, Ci, 3, 3), 42, -1, 2)
+    ref = ref_conv(x, w, None, False)
+    y, stats = ops.conv3x3_direct_fwd(x.to(DEV, BF), w2_of(w).to(DEV, BF), None, colstats=True)
+    assert torch.equal(y.double().cpu(), ref)
+    assert stats.shape == (_lib.load().ssl4gie_conv3x3_direct_tiles(B, H, W), 2, Co)
+    tot = stats.double().sum(0).cpu()
+    assert torch.equal(tot[0], ref.sum((0, 1, 2))) and torch.equal(tot[1], (ref * ref).sum((0, 1, 2)))
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 9, 33, 32, 128), (1, 16, 64, 128, 32)])
 def test_direct_conv_relu_mask_epilogue_exact(B, H, W, Ci, Co):
     """the data gradient of a convolution whose input went through a ReLU: y = mask > 0 ? y : 0"""
