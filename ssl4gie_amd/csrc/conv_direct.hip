@@ -4,7 +4,9 @@
 // gradients.  As implicit GEMMs these have N = 32 (forward), K-per-tap = 32 (data gradient) or a
 // 32 x 1152 output (weight gradient): in the 256x256-tile GEMM kernels 7/8 of every tile is padding
 // (forward 133 TFLOP/s, weight gradient 113 TFLOP/s, and the data gradient needs a materialised
-// patch matrix — tools/dpt_head_bench.py).  Here a workgroup owns an 8 x 32 pixel tile instead:
+// patch matrix — tools/dpt_head_bench.py).  Here a workgroup owns a tile of 256 output pixels instead
+// (8 x 32 of one image; 16 x 16 for maps up to 16 wide; 8 x 8 of FOUR images for 7 x 7 maps — the
+// geometry that wastes the fewest pixels is chosen per map):
 //
 //  * conv3x3_direct_kernel (forward; the data gradient is the same kernel on dy with the flipped,
 //    transposed weight): the tile's input halo (10 x 34 pixels x CK channels) and the weight slice
@@ -29,12 +31,31 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-
-#define DC_TH 8                 // tile rows (4 waves x 2)
-#define DC_TW 32                // tile columns = one 32-pixel MFMA operand
-#define DC_HH (DC_TH + 2)
-#define DC_HW (DC_TW + 2)
 #define DC_THREADS 256
+#define DC_PIX 256  // output pixels per tile: 4 waves x 2 MFMA operands of 32 pixels
+
+// Tile geometry: TB images x TH rows x TW columns = 256 pixels, in that (row-major) order; the halo
+// is one pixel wider on every side, per image.
+template <int TB_, int TH_, int TW_> struct TileG {
+    static constexpr int TB = TB_, TH = TH_, TW = TW_, HH = TH_ + 2, HW = TW_ + 2;
+    static constexpr int NH = TB_ * HH * HW;  // halo pixels
+    static_assert(TB_ * TH_ * TW_ == DC_PIX && (TW_ == 32 || TW_ == 16 || TW_ == 8), "tile = 256 pixels");
+    static DEVI int img(int p) { return p / (TH * TW); }
+    static DEVI int row(int p) { return (p / TW) % TH; }
+    static DEVI int col(int p) { return p % TW; }
+    static DEVI int lin(int im, int hy, int hx) { return (im * HH + hy) * HW + hx; }  // halo pixel index
+};
+struct TilePos {  // which tile a workgroup owns
+    int tx0, ty0, b0;
+};
+DEVI TilePos tile_pos(int t, int tiles_x, int tiles_y, int tb, int th, int tw) {
+    TilePos q;
+    q.tx0 = (t % tiles_x) * tw;
+    t /= tiles_x;
+    q.ty0 = (t % tiles_y) * th;
+    q.b0 = (t / tiles_y) * tb;
+    return q;
+}
 
 DEVI u32x4 relu_bf16x8(u32x4 v) {  // clears every 16-bit half whose sign bit is set
     u32x4 o;
@@ -46,46 +67,38 @@ DEVI u32x4 relu_bf16x8(u32x4 v) {  // clears every 16-bit half whose sign bit is
     return o;
 }
 
-// LDS images of the forward kernel.  X: pixel-major halo, CK channels (CPP 16-byte chunks) per
-// pixel; chunk c of halo column hx sits at position c ^ f(hx), with f chosen so that the 16 pixels a
-// lane group reads (consecutive hx, one chunk index) fall into 16 different 16-byte bank slots:
-// CK = 64 (128 B / pixel): slot = 8 (hx & 1) + (c ^ ((hx >> 1) & 7)); CK = 32 (64 B / pixel):
-// slot = 4 (lin & 3) + (c ^ ((hx >> 2) & 3)).  W: one row of 9 CK values per cout, chunk cc at
-// cc ^ s(row): rows are 72 (36) slots apart = 8 (4) mod 16, so s = (row >> 1) & 7 ((row >> 2) & 3).
-template <int CK> struct DcLay {
-    static constexpr int CPP = CK / 8, PS = CK * 2;
-    static constexpr int XS_BYTES = DC_HH * DC_HW * PS;
-    static constexpr int WROW = 9 * CK * 2;
-    static DEVI int x_off(int hy, int hx, int c) {
-        const int f = CK == 64 ? ((hx >> 1) & 7) : ((hx >> 2) & 3);
-        return (hy * DC_HW + hx) * PS + ((c ^ f) << 4);
-    }
-    static DEVI int w_off(int row, int cc) {
-        const int s = CK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
-        return row * WROW + ((cc ^ s) << 4);
-    }
-};
+// LDS images of the forward kernel (32 channels = four 16-byte chunks = 64 B per pixel).
+// X: pixel-major halo; chunk c of a halo pixel sits at position c ^ f, with f chosen so that the 16
+// pixels a lane group reads with one chunk index fall into 16 different 16-byte bank slots
+// (slot = 4 (lin & 3) + (c ^ f) mod 16): TW >= 16 — the group is 16 consecutive pixels of a row —
+// f = (hx >> 2) & 3; TW = 8 — two rows of 8, ten halo pixels apart — f = ((hx >> 2) & 1) | (hy & 1) << 1.
+// W: one row of 9 x 32 values per cout, chunk cc at cc ^ ((row >> 2) & 3): rows are 36 slots
+// (4 mod 16) apart.
+#define DC_CK 32
+#define DC_CPP 4
+#define DC_PS 64
+#define DC_WROW (9 * DC_CK * 2)
+template <typename G> DEVI int dc_x_off(int lin, int hy, int hx, int c) {
+    const int f = G::TW == 8 ? (((hx >> 2) & 1) | ((hy & 1) << 1)) : ((hx >> 2) & 3);
+    return lin * DC_PS + ((c ^ f) << 4);
+}
+DEVI int dc_w_off(int row, int cc) { return row * DC_WROW + ((cc ^ ((row >> 2) & 3)) << 4); }
 
 // y[b, oy, ox, co] = sum_{tap, ci} act(x)[b, oy + dy - 1, ox + dx - 1, ci] w2[co, tap * Cin + ci]
 // (+ bias[co]) (masked by relu_mask > 0); colstats [tiles][2][Cout]: per-tile sums / sums of squares
-// of y.  grid = (tiles_x * tiles_y * B, ceil(Cout / (32 NCB))).
-template <int CK, int NCB>
+// of y.  grid = (tiles, ceil(Cout / (32 NCB))).
+template <int NCB, typename G>
 __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w2, const float* __restrict__ bias,
-    const bf16_t* __restrict__ relu_mask, bf16_t* __restrict__ y, float* __restrict__ colstats, int H,
-    int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y) {
-    using L = DcLay<CK>;
-    constexpr int CPP = L::CPP;
+    const bf16_t* __restrict__ relu_mask, bf16_t* __restrict__ y, float* __restrict__ colstats, int Bn,
+    int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y) {
+    constexpr int CPP = DC_CPP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xs = smem;
-    char* Ws = smem + L::XS_BYTES;
+    char* Ws = smem + G::NH * DC_PS;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
-    const int tx0 = (bid % tiles_x) * DC_TW;
-    bid /= tiles_x;
-    const int ty0 = (bid % tiles_y) * DC_TH;
-    const int b = bid / tiles_y;
+    const TilePos tp = tile_pos(blockIdx.x, tiles_x, tiles_y, G::TB, G::TH, G::TW);
     const int co0 = blockIdx.y * (32 * NCB);
 
     f32x16 acc[2][NCB];
@@ -96,19 +109,27 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[pb][n][j] = 0.f;
 
-    constexpr int NX = DC_HH * DC_HW * CPP, IX = (NX + DC_THREADS - 1) / DC_THREADS;
+    // this lane's two pixels (one per 32-pixel operand of the wave) in halo coordinates
+    int p_im[2], p_r[2], p_c[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const int p = (2 * wave + pb) * 32 + l31;
+        p_im[pb] = G::img(p); p_r[pb] = G::row(p); p_c[pb] = G::col(p);
+    }
+
+    constexpr int NX = G::NH * CPP, IX = (NX + DC_THREADS - 1) / DC_THREADS;
     constexpr int NW = NCB * 32 * 9 * CPP, IW = (NW + DC_THREADS - 1) / DC_THREADS;
-    for (int cin0 = 0; cin0 < Cin; cin0 += CK) {
+    for (int cin0 = 0; cin0 < Cin; cin0 += DC_CK) {
         // ---- stage the halo and the weight slice: all global loads first, then the LDS writes
         u32x4 xv[IX], wv[IW];
 #pragma unroll
         for (int i = 0; i < IX; ++i) {
             const int idx = tid + i * DC_THREADS, pi = idx / CPP, c = idx % CPP;
-            const int hy = pi / DC_HW, hx = pi % DC_HW;
-            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const int im = pi / (G::HH * G::HW), hy = (pi / G::HW) % G::HH, hx = pi % G::HW;
+            const int gy = tp.ty0 + hy - 1, gx = tp.tx0 + hx - 1, gb = tp.b0 + im;
             xv[i] = u32x4{0, 0, 0, 0};
-            if (idx < NX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                xv[i] = *(const u32x4*)(x + (((size_t)b * H + gy) * W + gx) * Cin + cin0 + c * 8);
+            if (idx < NX && gb < Bn && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                xv[i] = *(const u32x4*)(x + (((size_t)gb * H + gy) * W + gx) * Cin + cin0 + c * 8);
         }
 #pragma unroll
         for (int i = 0; i < IW; ++i) {
@@ -123,12 +144,13 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
         for (int i = 0; i < IX; ++i) {
             const int idx = tid + i * DC_THREADS, pi = idx / CPP, c = idx % CPP;
             if (idx < NX)
-                *(u32x4*)(Xs + L::x_off(pi / DC_HW, pi % DC_HW, c)) = relu_in ? relu_bf16x8(xv[i]) : xv[i];
+                *(u32x4*)(Xs + dc_x_off<G>(pi, (pi / G::HW) % G::HH, pi % G::HW, c)) =
+                    relu_in ? relu_bf16x8(xv[i]) : xv[i];
         }
 #pragma unroll
         for (int i = 0; i < IW; ++i) {
             const int idx = tid + i * DC_THREADS;
-            if (idx < NW) *(u32x4*)(Ws + L::w_off(idx / (9 * CPP), idx % (9 * CPP))) = wv[i];
+            if (idx < NW) *(u32x4*)(Ws + dc_w_off(idx / (9 * CPP), idx % (9 * CPP))) = wv[i];
         }
         __syncthreads();
         // ---- nine shifted reads of the same halo
@@ -136,15 +158,16 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-            for (int ks = 0; ks < CK / 16; ++ks) {
+            for (int ks = 0; ks < DC_CK / 16; ++ks) {
                 const int c = ks * 2 + half;
                 bf16x8 a[NCB];
 #pragma unroll
                 for (int n = 0; n < NCB; ++n)
-                    a[n] = *(const bf16x8*)(Ws + L::w_off(n * 32 + l31, tap * CPP + c));
+                    a[n] = *(const bf16x8*)(Ws + dc_w_off(n * 32 + l31, tap * CPP + c));
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb) {
-                    const bf16x8 xf = *(const bf16x8*)(Xs + L::x_off(2 * wave + pb + dy, l31 + dx, c));
+                    const int hy = p_r[pb] + dy, hx = p_c[pb] + dx;
+                    const bf16x8 xf = *(const bf16x8*)(Xs + dc_x_off<G>(G::lin(p_im[pb], hy, hx), hy, hx, c));
 #pragma unroll
                     for (int n = 0; n < NCB; ++n) acc[pb][n] = MFMA32(a[n], xf, acc[pb][n]);
                 }
@@ -161,8 +184,8 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
     char* Os = smem;
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
-        const int p = (2 * wave + pb) * DC_TW + l31;
-        const bool valid = ty0 + 2 * wave + pb < H && tx0 + l31 < W;
+        const int p = (2 * wave + pb) * 32 + l31;
+        const bool valid = tp.b0 + p_im[pb] < Bn && tp.ty0 + p_r[pb] < H && tp.tx0 + p_c[pb] < W;
 #pragma unroll
         for (int n = 0; n < NCB; ++n)
 #pragma unroll
@@ -182,9 +205,9 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
         const int sw = p & SM;
         u32x4 v = *(const u32x4*)(Os + p * ROWB + ((j ^ (sw >> 1)) << 4));
         if (sw & 1) v = u32x4{v[2], v[3], v[0], v[1]};  // the two slots of the chunk sit swapped
-        const int gy = ty0 + p / DC_TW, gx = tx0 + p % DC_TW, co = co0 + 8 * j;
-        if (gy < H && gx < W && co < Cout) {
-            const size_t o = (((size_t)b * H + gy) * W + gx) * Cout + co;
+        const int gb = tp.b0 + G::img(p), gy = tp.ty0 + G::row(p), gx = tp.tx0 + G::col(p), co = co0 + 8 * j;
+        if (gb < Bn && gy < H && gx < W && co < Cout) {
+            const size_t o = (((size_t)gb * H + gy) * W + gx) * Cout + co;
             if (relu_mask) {  // keep where mask > 0: sign bit clear and not zero
                 const u32x4 m = *(const u32x4*)(relu_mask + o);
 #pragma unroll
@@ -200,8 +223,8 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
     if (colstats) {
         // per-tile column sums and sums of squares of the STORED values (ssl4gie_gemm_desc.colstats
         // semantics with one partial per tile): thread = (cout c, one of 256 / NC pixel groups)
-        constexpr int G = DC_THREADS / NC, PPG = DC_TH * DC_TW / G;
-        float* red = (float*)(smem + DC_TH * DC_TW * ROWB);  // [G][2][NC]
+        constexpr int NG = DC_THREADS / NC, PPG = DC_PIX / NG;
+        float* red = (float*)(smem + DC_PIX * ROWB);  // [NG][2][NC]
         const int c = tid % NC, g = tid / NC;
         float sum = 0.f, sq = 0.f;
         for (int p = g * PPG; p < (g + 1) * PPG; ++p) {
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
         if (tid < NC && co0 + tid < Cout) {
             sum = 0.f, sq = 0.f;
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
+            for (int k = 0; k < NG; ++k) {
                 sum += red[(k * 2) * NC + tid];
                 sq += red[(k * 2 + 1) * NC + tid];
             }
@@ -227,21 +250,21 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
 }
 
 // ------------------------------------------------------------------ weight gradient
-// One workgroup = (channel slice of 64 input channels, a strided share of the 8 x 32 tiles).
+// One workgroup = (64 input channels, 32 couts, a strided share of the tiles).
 // Wave w: input-channel block cb = w >> 1 (32 channels), taps 0-4 (w & 1 == 0) or 5-8.
-// LDS: X halo [10][34][64 ch] (the 64-byte halves of a pixel swapped by (hx >> 1) & 1, which keeps
-// the four pixel rows of a transposed read on different banks for every tap shift) and the dy tile
-// [256 pixels][32 couts].  k-step = 16 consecutive pixels of a tile row.
-#define WG_XS_BYTES (DC_HH * DC_HW * 128)
-#define WG_DY_BYTES (DC_TH * DC_TW * 64)
-DEVI int wg_x_off(int hy, int hx, int ch) {  // byte offset of channel ch (0..63) of a halo pixel
-    return (hy * DC_HW + hx) * 128 + ((((ch >> 5) ^ (hx >> 1)) & 1) << 6) + ((ch & 31) << 1);
+// LDS: X halo [halo pixels][64 ch] (the 64-byte halves of a pixel swapped by (hx >> 1) & 1, which
+// keeps the four consecutive pixels of a transposed read on different banks for every tap shift)
+// and the dy tile [256 pixels][32 couts].  k-step = a run of 16 consecutive tile pixels: half a row
+// (TW = 32), a row (16) or two rows (8).
+#define WG_DY_BYTES (DC_PIX * 64)
+DEVI int wg_x_off(int lin, int hx, int ch) {  // byte offset of channel ch (0..63) of a halo pixel
+    return lin * 128 + ((((ch >> 5) ^ (hx >> 1)) & 1) << 6) + ((ch & 31) << 1);
 }
 // transposed 32 x 16 MFMA operand: lane (n = lane & 31, half) gets, for column n of a 32-column block,
 // the 8 k-rows (pixels) 8 half .. 8 half + 7 of a run.  Each 16-lane group transposes a 4 (k) x 16
 // (columns) block per ds_read_b64_tr_b16: lane i supplies the address of row i >> 2, columns
 // 4 (i & 3) .. + 3, and receives column i.  `p` = this lane's address in the first block (row
-// 8 half + (i >> 2)), `rs` = bytes per pixel row: the second block is 4 rows further on.
+// 8 half + (i >> 2)), `rs` = bytes per pixel: the second block is 4 pixels further on (same map row).
 DEVI bf16x8 tr_operand32(const char* p, const int rs) {
     typedef __attribute__((address_space(3))) s16x4* lp_t;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p);
@@ -250,25 +273,25 @@ DEVI bf16x8 tr_operand32(const char* p, const int rs) {
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
-// one staged tile: 16 k-steps (tile row ks >> 1, columns 16 (ks & 1) ..) x the wave's taps.  Fully
-// unrolled with compile-time taps: every LDS address is a per-lane base (dbase; xbase[dx], which
-// carries the swizzle of the lane's pixel column) plus an immediate.
+// one staged tile: 16 runs x the wave's taps.  Fully unrolled with compile-time taps: every LDS
+// address is a per-lane base (dbase; xbase[dx], which carries the lane's pixel inside a run and the
+// swizzle of its column) plus an immediate (the run's first pixel, shifted by the tap).
 // BIAS (one four-tap wave of the slice-0 workgroups): the spare fifth accumulator takes the bias
 // gradient — dy^T against a ones operand puts sum_pixels dy[p][co] into every column of row co.
-template <int TAP0, int NTAP, bool BIAS>
+template <typename G, int TAP0, int NTAP, bool BIAS>
 DEVI void wgrad_tile(f32x16 (&acc)[5], const char* dbase, const char* const (&xbase)[3]) {
     bf16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 #pragma unroll
-    for (int ks = 0; ks < DC_TH * 2; ++ks) {
-        const int r = ks >> 1, c0 = (ks & 1) * 16;
-        const bf16x8 a = tr_operand32(dbase + (r * DC_TW + c0) * 64, 64);
+    for (int u = 0; u < DC_PIX / 16; ++u) {
+        const int p0 = u * 16, im = G::img(p0), r = G::row(p0), c0 = G::col(p0);
+        const bf16x8 a = tr_operand32(dbase + p0 * 64, 64);
         if (BIAS) acc[4] = MFMA32(a, ones, acc[4]);
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
             const int tap = TAP0 + t, dyy = tap / 3, dxx = tap % 3;
-            const bf16x8 xf = tr_operand32(xbase[dxx] + ((r + dyy) * DC_HW + c0) * 128, 128);
+            const bf16x8 xf = tr_operand32(xbase[dxx] + G::lin(im, r + dyy, c0) * 128, 128);
             acc[t] = MFMA32(a, xf, acc[t]);
         }
     }
@@ -277,21 +300,21 @@ DEVI void wgrad_tile(f32x16 (&acc)[5], const char* dbase, const char* const (&xb
 // partial[wg][co 32][tap 9][ci 64] fp32, then partial_b[wg][co 32] (written by the workgroups of
 // slice 0 only); wg = blockIdx.x: combo = wg % (nslice * ngroups) = group * nslice + slice picks the
 // 64 input channels and the 32 couts, wg / ncombo the share of the tiles
+template <typename G>
 __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
     float* __restrict__ partial_b,
-    int Bn, int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y, int nslice,
-    int ncombo) {
+    int Bn, int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y, int ntiles,
+    int nslice, int ncombo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xs = smem;
-    char* Ds = smem + WG_XS_BYTES;
+    char* Ds = smem + G::NH * 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int combo = blockIdx.x % ncombo, slice = combo % nslice, cin0 = slice * 64;
     const int co0 = (combo / nslice) * 32;
-    const int wgs_per_slice = gridDim.x / ncombo, me = blockIdx.x / ncombo;
+    const int wgs_per_combo = gridDim.x / ncombo, me = blockIdx.x / ncombo;
     const int cb = wave >> 1, tap0 = (wave & 1) * 5, ntap = (wave & 1) ? 4 : 5;  // wgrad_tile<tap0, ntap>
-    const int ntiles = tiles_x * tiles_y * Bn;
 
     f32x16 acc[5];
 #pragma unroll
@@ -299,45 +322,44 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
-    // per-lane LDS bases of the transposed reads: pixel row k0 = 8 half + (i >> 2) of a 16-pixel
-    // run, columns 4 (i & 3) .. of the lane group's 16-column half (wg_x_off's swizzle depends on
-    // the pixel column only through (k0 + dx) >> 1: runs start at multiples of 16)
+    // per-lane LDS bases of the transposed reads: pixel k0 = 8 half + (i >> 2) of a 16-pixel run
+    // (TW = 8: map row k0 >> 3, column k0 & 7), columns 4 (i & 3) .. of the lane group's 16-column
+    // half.  wg_x_off's swizzle depends on the pixel column only through (kc + dx) >> 1: runs start
+    // at column 0 or 16.
     const int li = lane & 15, k0 = 8 * (lane >> 5) + (li >> 2), colb = (((lane >> 4) & 1) * 16 + 4 * (li & 3)) * 2;
+    const int kr = G::TW == 8 ? (k0 >> 3) : 0, kc = G::TW == 8 ? (k0 & 7) : k0;
     const char* dbase = Ds + k0 * 64 + colb;
-    const char* const xbase[3] = {Xs + wg_x_off(0, k0, cb * 32) + colb, Xs + wg_x_off(0, k0 + 1, cb * 32) + colb,
-                                  Xs + wg_x_off(0, k0 + 2, cb * 32) + colb};
-    constexpr int NX = DC_HH * DC_HW * 8, IX = (NX + DC_THREADS - 1) / DC_THREADS;  // 16-byte chunks
-    constexpr int ND = DC_TH * DC_TW * 4, ID = ND / DC_THREADS;
-    for (int tile = me; tile < ntiles; tile += wgs_per_slice) {
-        int t = tile;
-        const int tx0 = (t % tiles_x) * DC_TW;
-        t /= tiles_x;
-        const int ty0 = (t % tiles_y) * DC_TH;
-        const int b = t / tiles_y;
+    const char* const xbase[3] = {Xs + wg_x_off(G::lin(0, kr, kc), kc, cb * 32) + colb,
+                                  Xs + wg_x_off(G::lin(0, kr, kc + 1), kc + 1, cb * 32) + colb,
+                                  Xs + wg_x_off(G::lin(0, kr, kc + 2), kc + 2, cb * 32) + colb};
+    constexpr int NX = G::NH * 8, IX = (NX + DC_THREADS - 1) / DC_THREADS;  // 16-byte chunks
+    constexpr int ND = DC_PIX * 4, ID = ND / DC_THREADS;
+    for (int tile = me; tile < ntiles; tile += wgs_per_combo) {
+        const TilePos tp = tile_pos(tile, tiles_x, tiles_y, G::TB, G::TH, G::TW);
         u32x4 xv[IX], dv[ID];
 #pragma unroll
         for (int i = 0; i < IX; ++i) {
             const int idx = tid + i * DC_THREADS, pi = idx >> 3, c = idx & 7;
-            const int hy = pi / DC_HW, hx = pi % DC_HW;
-            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const int im = pi / (G::HH * G::HW), hy = (pi / G::HW) % G::HH, hx = pi % G::HW;
+            const int gy = tp.ty0 + hy - 1, gx = tp.tx0 + hx - 1, gb = tp.b0 + im;
             xv[i] = u32x4{0, 0, 0, 0};
-            if (idx < NX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                xv[i] = *(const u32x4*)(x + (((size_t)b * H + gy) * W + gx) * Cin + cin0 + c * 8);
+            if (idx < NX && gb < Bn && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                xv[i] = *(const u32x4*)(x + (((size_t)gb * H + gy) * W + gx) * Cin + cin0 + c * 8);
         }
 #pragma unroll
-        for (int i = 0; i < ID; ++i) {  // dy tile: pixel p = row * 32 + col, 4 chunks of 8 couts
+        for (int i = 0; i < ID; ++i) {  // dy tile in tile-pixel order, 4 chunks of 8 couts
             const int idx = tid + i * DC_THREADS, p = idx >> 2, c = idx & 3;
-            const int gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
+            const int gb = tp.b0 + G::img(p), gy = tp.ty0 + G::row(p), gx = tp.tx0 + G::col(p);
             dv[i] = u32x4{0, 0, 0, 0};
-            if (gy < H && gx < W)
-                dv[i] = *(const u32x4*)(dy + (((size_t)b * H + gy) * W + gx) * Cout + co0 + c * 8);
+            if (gb < Bn && gy < H && gx < W)
+                dv[i] = *(const u32x4*)(dy + (((size_t)gb * H + gy) * W + gx) * Cout + co0 + c * 8);
         }
         __syncthreads();  // the previous tile has been consumed
 #pragma unroll
         for (int i = 0; i < IX; ++i) {
             const int idx = tid + i * DC_THREADS, pi = idx >> 3, c = idx & 7;
             if (idx < NX)
-                *(u32x4*)(Xs + wg_x_off(pi / DC_HW, pi % DC_HW, c * 8)) = relu_in ? relu_bf16x8(xv[i]) : xv[i];
+                *(u32x4*)(Xs + wg_x_off(pi, pi % G::HW, c * 8)) = relu_in ? relu_bf16x8(xv[i]) : xv[i];
         }
 #pragma unroll
         for (int i = 0; i < ID; ++i) {
@@ -345,9 +367,9 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
             *(u32x4*)(Ds + (idx >> 2) * 64 + ((idx & 3) << 4)) = dv[i];
         }
         __syncthreads();
-        if (wave == 1 && slice == 0) wgrad_tile<5, 4, true>(acc, dbase, xbase);
-        else if (wave & 1) wgrad_tile<5, 4, false>(acc, dbase, xbase);
-        else wgrad_tile<0, 5, false>(acc, dbase, xbase);
+        if (wave == 1 && slice == 0) wgrad_tile<G, 5, 4, true>(acc, dbase, xbase);
+        else if (wave & 1) wgrad_tile<G, 5, 4, false>(acc, dbase, xbase);
+        else wgrad_tile<G, 0, 5, false>(acc, dbase, xbase);
     }
     // acc[t][j]: row (cout) = 8 (j >> 2) + 4 half + (j & 3), column (ci) = cb * 32 + (lane & 31)
     float* out = partial + (size_t)blockIdx.x * (32 * 9 * 64);
@@ -393,24 +415,57 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial,
 }
 
 // ------------------------------------------------------------------ C ABI
+typedef TileG<1, 8, 32> G32;
+typedef TileG<1, 16, 16> G16;
+typedef TileG<4, 8, 8> G8;
+struct Geom {
+    int id, tb, th, tw, tiles_x, tiles_y, tiles;
+};
+// the geometry with the fewest tiles (every tile costs the same): 8 x 32 unless the map is narrow
+static Geom pick_geom(int B, int H, int W) {
+    static const int G_[3][3] = {{1, 8, 32}, {1, 16, 16}, {4, 8, 8}};
+    Geom best = {};
+    for (int i = 0; i < 3; ++i) {
+        Geom g = {i, G_[i][0], G_[i][1], G_[i][2], 0, 0, 0};
+        g.tiles_x = (W + g.tw - 1) / g.tw;
+        g.tiles_y = (H + g.th - 1) / g.th;
+        g.tiles = g.tiles_x * g.tiles_y * ((B + g.tb - 1) / g.tb);
+        if (i == 0 || g.tiles < best.tiles) best = g;
+    }
+    return best;
+}
+
 // 32 staged channels per pass and up to 64 couts per workgroup: 58 KiB of LDS, so two to three
 // workgroups overlap their staging on a CU.  (64-channel passes with 32 couts — 80 KiB — measured
 // slower at every geometry tried: 128 -> 32 @224 746 vs 666 us, 256 -> 128 @112 1532 vs 1227 us.)
-static int direct_cfg(int Cin, int Cout, int* ck, int* ncb) {
-    if (Cin % 32 != 0) return 1;
-    *ck = 32;
-    *ncb = Cout > 32 ? 2 : 1;
-    return 0;
-}
-
 extern "C" int ssl4gie_conv3x3_direct_ok(int B, int H, int W, int Cin, int Cout) {
-    int ck, ncb;
-    return B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && !direct_cfg(Cin, Cout, &ck, &ncb) &&
+    return B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && Cin > 0 && Cin % DC_CK == 0 &&
            (long long)B * H * W * (Cin > Cout ? Cin : Cout) * 2 < (1LL << 40);
 }
 
 extern "C" int ssl4gie_conv3x3_direct_tiles(int B, int H, int W) {
-    return ((W + DC_TW - 1) / DC_TW) * ((H + DC_TH - 1) / DC_TH) * B;
+    return (B > 0 && H > 0 && W > 0) ? pick_geom(B, H, W).tiles : 0;
+}
+
+template <int NCB, typename G>
+static int launch_direct(const Geom& g, const void* x, const void* w2, const float* bias,
+                         const void* relu_mask, void* y, float* colstats, int B, int H, int W, int Cin,
+                         int Cout, int relu_in, hipStream_t st) {
+    auto k = conv3x3_direct_kernel<NCB, G>;
+    int lds = G::NH * DC_PS + NCB * 32 * DC_WROW;
+    const int lds_out = DC_PIX * NCB * 64 + 2 * DC_THREADS * (int)sizeof(float);
+    if (lds < lds_out) lds = lds_out;
+    static bool attr = false;  // one per instantiation
+    if (!attr) {
+        HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    const dim3 grid((unsigned)g.tiles, (unsigned)((Cout + 32 * NCB - 1) / (32 * NCB)));
+    hipLaunchKernelGGL(k, grid, dim3(DC_THREADS), lds, st, (const bf16_t*)x, (const bf16_t*)w2, bias,
+                       (const bf16_t*)relu_mask, (bf16_t*)y, colstats, B, H, W, Cin, Cout, relu_in,
+                       g.tiles_x, g.tiles_y);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const float* bias,
@@ -418,54 +473,57 @@ extern "C" int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const f
                                           int W, int Cin, int Cout, int relu_in, void* stream) {
     REQUIRE(x && w2 && y && ssl4gie_conv3x3_direct_ok(B, H, W, Cin, Cout));
     REQUIRE(!(colstats && relu_mask));
-    int ck = 0, ncb = 0;
-    direct_cfg(Cin, Cout, &ck, &ncb);
     hipStream_t st = (hipStream_t)stream;
-    const int tiles_x = (W + DC_TW - 1) / DC_TW, tiles_y = (H + DC_TH - 1) / DC_TH;
-    const dim3 grid((unsigned)(tiles_x * tiles_y * B), (unsigned)((Cout + 32 * ncb - 1) / (32 * ncb)));
+    const Geom g = pick_geom(B, H, W);
     ProfScope prof(PROF_GEMM_NT, 2.0 * B * H * (double)W * Cout * 9 * Cin, st);
-#define DC_LAUNCH(CK_, NCB_)                                                                          \
-    do {                                                                                              \
-        auto k = conv3x3_direct_kernel<CK_, NCB_>;                                                    \
-        int lds = DcLay<CK_>::XS_BYTES + NCB_ * 32 * DcLay<CK_>::WROW;                                \
-        const int lds_out = DC_TH * DC_TW * NCB_ * 64 + 2 * DC_THREADS * (int)sizeof(float);          \
-        if (lds < lds_out) lds = lds_out;                                                             \
-        static bool attr = false;                                                                     \
-        if (!attr) {                                                                                  \
-            HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-            attr = true;                                                                              \
-        }                                                                                             \
-        hipLaunchKernelGGL(k, grid, dim3(DC_THREADS), lds, st, (const bf16_t*)x, (const bf16_t*)w2,   \
-                           bias, (const bf16_t*)relu_mask, (bf16_t*)y, colstats, H, W, Cin, Cout,     \
-                           relu_in, tiles_x, tiles_y);                                                \
-    } while (0)
-    if (ncb == 2) DC_LAUNCH(32, 2);
-    else DC_LAUNCH(32, 1);
-#undef DC_LAUNCH
-    LAUNCH_CHECK();
-    return 0;
+#define DC_ARGS g, x, w2, bias, relu_mask, y, colstats, B, H, W, Cin, Cout, relu_in, st
+    if (Cout > 32) {
+        if (g.id == 0) return launch_direct<2, G32>(DC_ARGS);
+        if (g.id == 1) return launch_direct<2, G16>(DC_ARGS);
+        return launch_direct<2, G8>(DC_ARGS);
+    }
+    if (g.id == 0) return launch_direct<1, G32>(DC_ARGS);
+    if (g.id == 1) return launch_direct<1, G16>(DC_ARGS);
+    return launch_direct<1, G8>(DC_ARGS);
+#undef DC_ARGS
 }
 
-static int wgrad_grid(int B, int H, int W, int Cin, int Cout, int* nslice, int* ncombo, int* per_combo) {
-    const int tiles = ((W + DC_TW - 1) / DC_TW) * ((H + DC_TH - 1) / DC_TH) * B;
+static int wgrad_grid(const Geom& g, int Cin, int Cout, int* nslice, int* ncombo, int* per_combo) {
     *nslice = Cin / 64;
     *ncombo = *nslice * (Cout / 32);
     int per = (2 * ssl4gie_internal_compute_cus()) / *ncombo;  // two workgroups per CU in all
     if (per < 1) per = 1;
-    if (per > tiles) per = tiles;
+    if (per > g.tiles) per = g.tiles;
     *per_combo = per;
     return *ncombo * per;
 }
 
 extern "C" int ssl4gie_conv3x3_direct_wgrad_ok(int B, int H, int W, int Cin, int Cout) {
-    return B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 32 == 0 && Cout <= 256 && Cin > 0 &&
+    return B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 32 == 0 && Cout <= 512 && Cin > 0 &&
            Cin % 64 == 0 && Cin <= 512;
 }
 
 extern "C" size_t ssl4gie_conv3x3_direct_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (!ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, Cout)) return 0;
     int ns, nc, per;
-    return (size_t)wgrad_grid(B, H, W, Cin, Cout, &ns, &nc, &per) * (32 * 9 * 64 + 32) * sizeof(float);
+    return (size_t)wgrad_grid(pick_geom(B, H, W), Cin, Cout, &ns, &nc, &per) * (32 * 9 * 64 + 32) * sizeof(float);
+}
+
+template <typename G>
+static int launch_wgrad(const Geom& g, int grid, const void* dy, const void* x, float* part, float* part_b,
+                        int B, int H, int W, int Cin, int Cout, int relu_in, int ns, int nc,
+                        hipStream_t st) {
+    auto k = conv3x3_wgrad_direct_kernel<G>;
+    const int lds = G::NH * 128 + WG_DY_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DC_THREADS), lds, st, (const bf16_t*)dy, (const bf16_t*)x, part,
+                       part_b, B, H, W, Cin, Cout, relu_in, g.tiles_x, g.tiles_y, g.tiles, ns, nc);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float* dw2, float* dbias,
@@ -475,23 +533,19 @@ extern "C" int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float
     REQUIRE(dy && x && dw2 && workspace && ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, Cout));
     REQUIRE(workspace_bytes >= ssl4gie_conv3x3_direct_wgrad_workspace_bytes(B, H, W, Cin, Cout));
     hipStream_t st = (hipStream_t)stream;
+    const Geom g = pick_geom(B, H, W);
     int ns, nc, per;
-    const int grid = wgrad_grid(B, H, W, Cin, Cout, &ns, &nc, &per);
-    const int tiles_x = (W + DC_TW - 1) / DC_TW, tiles_y = (H + DC_TH - 1) / DC_TH;
-    const int lds = WG_XS_BYTES + WG_DY_BYTES;
+    const int grid = wgrad_grid(g, Cin, Cout, &ns, &nc, &per);
     float* part_b = (float*)workspace + (size_t)grid * 32 * 9 * 64;
-    static bool attr = false;
-    if (!attr) {
-        HIP_RET(hipFuncSetAttribute((const void*)conv3x3_wgrad_direct_kernel,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
     {
         ProfScope prof(PROF_GEMM_TN, 2.0 * B * H * (double)W * Cout * 9 * Cin, st);
-        hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel, dim3(grid), dim3(DC_THREADS), lds, st,
-                           (const bf16_t*)dy, (const bf16_t*)x, (float*)workspace, part_b, B, H, W, Cin,
-                           Cout, relu_in, tiles_x, tiles_y, ns, nc);
-        LAUNCH_CHECK();
+        int rc;
+#define WG_ARGS g, grid, dy, x, (float*)workspace, part_b, B, H, W, Cin, Cout, relu_in, ns, nc, st
+        if (g.id == 0) rc = launch_wgrad<G32>(WG_ARGS);
+        else if (g.id == 1) rc = launch_wgrad<G16>(WG_ARGS);
+        else rc = launch_wgrad<G8>(WG_ARGS);
+#undef WG_ARGS
+        if (rc) return rc;
     }
     const int n = Cout * 9 * Cin + Cout;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st,

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -588,13 +590,20 @@ def conv3x3_bwd_weight(dy2d, x, stride=1, relu=False, bias_out=None):
     return out
 
 
+_DIRECT_SMALL = os.environ.get("SSL4GIE_DIRECT_SMALL", "1") != "0"
+
+
 def conv3x3_direct_ok(x, n_out):
     """whether the direct (halo-in-LDS) kernel takes this map: narrow layers the 256-wide GEMM tiles
     would mostly pad (ssl4gie_conv3x3_direct_fwd)"""
     if x.dtype != torch.bfloat16 or not x.is_contiguous():
         return False
     B, H, W, Cin = x.shape
-    return (n_out <= 128 or Cin == 32) and bool(_lib.load().ssl4gie_conv3x3_direct_ok(B, H, W, Cin, n_out))
+    # measured (tools/conv_bench.py): ahead of the gathered GEMM wherever its 256-wide tiles are
+    # mostly padding — narrow layers — and on small maps (<= 16 wide: 256 -> 256 @14, 512 -> 512 @7),
+    # where the GEMM has too few tiles to fill the chip
+    return (n_out <= 128 or Cin == 32 or (W <= 16 and _DIRECT_SMALL)) and \
+        bool(_lib.load().ssl4gie_conv3x3_direct_ok(B, H, W, Cin, n_out))
 
 
 def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None, colstats=False):

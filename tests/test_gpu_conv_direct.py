@@ -4,7 +4,8 @@ gradients).  Operands are small integers, so every product and every partial sum
 bf16 / fp32 and the comparison with torch's fp64 convolution on the CPU is BIT-EXACT: a wrong
 halo offset, swizzle, tap shift, MFMA lane mapping or edge mask is an integer error.  Geometries
 cover one to six 32-channel passes, one and two 32-cout blocks per workgroup, several cout groups,
-maps that are not a multiple of the 8 x 32 tile, single-row / single-column maps, and the production 224 x 224 map."""
+maps that are not a multiple of the tile, all three tile geometries (8 x 32, 16 x 16, four images of 8 x 8),
+single-row / single-column maps, and the production 224 x 224 map."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -47,6 +48,10 @@ GEOMS = [  # B, H, W, Cin, Cout
     (1, 40, 1, 64, 24),     # single column
     (3, 8, 32, 96, 40),     # three passes; Cout not a multiple of 32
     (1, 11, 40, 192, 128),  # output_conv.0-like: six passes, two cout groups of 64
+    (3, 14, 14, 64, 64),    # 16 x 16 tiles (ResNet layer3 maps)
+    (2, 16, 9, 32, 40),     # 16 x 16 tiles, ragged
+    (9, 7, 7, 64, 128),     # 8 x 8 tiles of four images (layer4 maps); the last tile holds one image
+    (5, 5, 8, 32, 32),      # 8 x 8 tiles, ragged rows
 ]
 
 
@@ -65,7 +70,7 @@ def test_direct_conv_forward_exact(B, H, W, Ci, Co, relu_in):
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 64, 64, 64), (1, 13, 37, 64, 32), (2, 9, 33, 128, 128),
-                                         (1, 5, 40, 32, 40)])
+                                         (1, 5, 40, 32, 40), (3, 14, 14, 64, 64), (9, 7, 7, 64, 64)])
 def test_direct_conv_batchnorm_partials_exact(B, H, W, Ci, Co):
     """colstats: per-tile column sums / sums of squares of the stored outputs (what BatchNormFn takes
     from the producing convolution); ragged tiles must not count their overhang"""
@@ -93,7 +98,9 @@ def test_direct_conv_relu_mask_epilogue_exact(B, H, W, Ci, Co):
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 64, 128, 32), (1, 13, 37, 64, 32), (3, 5, 100, 192, 32),
-                                         (1, 1, 3, 64, 32), (2, 9, 40, 128, 128), (1, 17, 33, 64, 96)])
+                                         (1, 1, 3, 64, 32), (2, 9, 40, 128, 128), (1, 17, 33, 64, 96),
+                                         (3, 14, 14, 64, 64), (9, 7, 7, 128, 32), (5, 5, 8, 64, 64),
+                                         (2, 16, 9, 64, 32)])
 @pytest.mark.parametrize("relu_in", [False, True])
 def test_direct_conv_weight_gradient_exact(B, H, W, Ci, Co, relu_in):
     from ssl4gie_amd import ops

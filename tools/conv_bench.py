@@ -4,7 +4,7 @@ decoder / ResNet-50 geometries of the benchmark configurations.  python tools/co
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ssl4gie_amd import ops
+from ssl4gie_amd import ops, _lib
 
 CASES = [  # name, B, H, W, Cin, Cout, stride
     ("dpt refinenet 256>256 @112 b64", 64, 112, 112, 256, 256, 1),
@@ -45,7 +45,13 @@ def main():
         else:
             wi = float("nan")
         wm = timeit(lambda: ops.linear_bwd_weight(dy, ops.im2col3x3(x, s, True), bias_out=bias))
-        print(f"{name:36s} {fi:9.1f} {fm:9.1f} {fl / fi / 1e6:8.1f} | {wi:9.1f} {wm:9.1f} {fl / wi / 1e6:8.1f}")
+        fd = wd = float("nan")
+        if s == 1 and _lib.load().ssl4gie_conv3x3_direct_ok(B, H, W, Ci, Co):
+            fd = timeit(lambda: ops.conv3x3_direct_fwd(x, w2, bias, relu=True))
+        if s == 1 and _lib.load().ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Ci, Co):
+            wd = timeit(lambda: ops.conv3x3_direct_wgrad(dy.view(B, Ho, Wo, Co), x, relu=True, bias_out=bias))
+        print(f"{name:36s} {fi:9.1f} {fm:9.1f} {fl / fi / 1e6:8.1f} | {wi:9.1f} {wm:9.1f} {fl / wi / 1e6:8.1f}"
+              f" | direct fwd {fd:8.1f} ({fl / fd / 1e6:6.1f} TF/s) wgrad {wd:8.1f} ({fl / wd / 1e6:6.1f})", flush=True)
         del x, w2, dy
         torch.cuda.empty_cache()
 
