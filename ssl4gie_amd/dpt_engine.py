@@ -111,7 +111,10 @@ class Conv3x3Fn(torch.autograd.Function):
         implicit = _IMPLICIT and ld == 9 * Cin and ops.conv3x3_implicit_ok(x, stride, Cout)
         Ho, Wo = ops.conv_out_hw(H, W, stride)
         stats = None
-        direct = _DIRECT and stride == 1 and ops.conv3x3_direct_ok(x, Cout)
+        # direct kernel: where it is ahead of the gathered GEMM (ops.conv3x3_direct_ok), and instead
+        # of a materialised patch matrix where the gathered GEMM does not apply (layer1_rn: Cin = 96)
+        direct = _DIRECT and stride == 1 and (ops.conv3x3_direct_ok(x, Cout) or
+                                              (not implicit and ops.conv3x3_direct_supported(x, Cout)))
         if direct and want_stats and b is None:
             # narrow ResNet layers (64 -> 64 @56, 128 -> 128 @28): direct kernel, statistics per tile
             y, stats = ops.conv3x3_direct_fwd(x, w2 if ld == 9 * Cin else _w_direct(lp, weight, dt), None,

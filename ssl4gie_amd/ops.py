@@ -593,6 +593,14 @@ def conv3x3_bwd_weight(dy2d, x, stride=1, relu=False, bias_out=None):
 _DIRECT_SMALL = os.environ.get("SSL4GIE_DIRECT_SMALL", "1") != "0"
 
 
+def conv3x3_direct_supported(x, n_out):
+    """whether the direct kernel CAN take this stride-1 map (bf16, Cin % 32 == 0, Cout % 8 == 0)"""
+    if x.dtype != torch.bfloat16 or not x.is_contiguous():
+        return False
+    B, H, W, Cin = x.shape
+    return bool(_lib.load().ssl4gie_conv3x3_direct_ok(B, H, W, Cin, n_out))
+
+
 def conv3x3_direct_ok(x, n_out):
     """whether the direct (halo-in-LDS) kernel takes this map: narrow layers the 256-wide GEMM tiles
     would mostly pad (ssl4gie_conv3x3_direct_fwd)"""
