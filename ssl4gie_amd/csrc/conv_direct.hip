@@ -68,10 +68,10 @@ DEVI u32x4 relu_bf16x8(u32x4 v) {  // clears every 16-bit half whose sign bit is
 }
 
 // LDS images of the forward kernel (32 channels = four 16-byte chunks = 64 B per pixel).
-// X: pixel-major halo; chunk c of a halo pixel sits at position c ^ f, with f chosen so that the 16
-// pixels a lane group reads with one chunk index fall into 16 different 16-byte bank slots
-// (slot = 4 (lin & 3) + (c ^ f) mod 16): TW >= 16 — the group is 16 consecutive pixels of a row —
-// f = (hx >> 2) & 3; TW = 8 — two rows of 8, ten halo pixels apart — f = ((hx >> 2) & 1) | (hy & 1) << 1.
+// X: pixel-major halo; chunk c of a halo pixel sits at position c ^ f, with f chosen per geometry so
+// that every ds_read_b128 of the tap loop and every staging write takes its ideal 4 LDS cycles under
+// the hardware's 16-lane grouping (tools/lds_bank_sim.py, confirmed with SQ_LDS_BANK_CONFLICT = 0):
+// TW = 32: f = (hx >> 2) & 3; TW = 16: f = (hx >> 1) & 3; TW = 8: f = ((hx >> 2) & 1) | (hy & 1) << 1.
 // W: one row of 9 x 32 values per cout, chunk cc at cc ^ ((row >> 2) & 3): rows are 36 slots
 // (4 mod 16) apart.
 #define DC_CK 32
@@ -79,7 +79,7 @@ DEVI u32x4 relu_bf16x8(u32x4 v) {  // clears every 16-bit half whose sign bit is
 #define DC_PS 64
 #define DC_WROW (9 * DC_CK * 2)
 template <typename G> DEVI int dc_x_off(int lin, int hy, int hx, int c) {
-    const int f = G::TW == 8 ? (((hx >> 2) & 1) | ((hy & 1) << 1)) : ((hx >> 2) & 3);
+    const int f = G::TW == 8 ? (((hx >> 2) & 1) | ((hy & 1) << 1)) : G::TW == 16 ? ((hx >> 1) & 3) : ((hx >> 2) & 3);
     return lin * DC_PS + ((c ^ f) << 4);
 }
 DEVI int dc_w_off(int row, int cc) { return row * DC_WROW + ((cc ^ ((row >> 2) & 3)) << 4); }
@@ -88,7 +88,7 @@ DEVI int dc_w_off(int row, int cc) { return row * DC_WROW + ((cc ^ ((row >> 2) &
 // (+ bias[co]) (masked by relu_mask > 0); colstats [tiles][2][Cout]: per-tile sums / sums of squares
 // of y.  grid = (tiles, ceil(Cout / (32 NCB))).
 template <int NCB, typename G>
-__global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
+__global__ __launch_bounds__(DC_THREADS, NCB == 1 ? 3 : 2) void conv3x3_direct_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w2, const float* __restrict__ bias,
     const bf16_t* __restrict__ relu_mask, bf16_t* __restrict__ y, float* __restrict__ colstats, int Bn,
     int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
     }
     // ---- epilogue.  Accumulator j of a lane = cout 8 (j >> 2) + 4 half + (j & 3) of pixel l31: 8-byte
     // pieces 64-128 B apart.  The finished bf16 tile goes through LDS ([256 pixels][32 NCB couts],
-    // 8-byte slots XOR-ed with the pixel index against bank conflicts) and leaves as whole 16-byte
+    // 8-byte slots XOR-ed with (p ^ p >> 2): conflict-free writes and reads) and leaves as whole 16-byte
     // chunks of consecutive pixels; the ReLU mask is read the same way.  Pixels outside the map are
     // staged as zeros, so the BatchNorm statistics below need no mask.
     constexpr int NC = 32 * NCB, ROWB = NC * 2, SLOTS = ROWB / 8, SM = SLOTS - 1;
@@ -195,14 +195,14 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
                            acc[pb][n][4 * q + 3]};
                 if (bias && co < Cout) v += ld4(bias + co);
                 if (!valid || co >= Cout) v = f32x4{0, 0, 0, 0};
-                st4((bf16_t*)(Os + p * ROWB + ((slot ^ (p & SM)) << 3)), v);
+                st4((bf16_t*)(Os + p * ROWB + ((slot ^ ((p ^ (p >> 2)) & SM)) << 3)), v);
             }
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SLOTS / 2; ++i) {
         const int idx = tid + i * DC_THREADS, p = idx / (SLOTS / 2), j = idx % (SLOTS / 2);
-        const int sw = p & SM;
+        const int sw = (p ^ (p >> 2)) & SM;
         u32x4 v = *(const u32x4*)(Os + p * ROWB + ((j ^ (sw >> 1)) << 4));
         if (sw & 1) v = u32x4{v[2], v[3], v[0], v[1]};  // the two slots of the chunk sit swapped
         const int gb = tp.b0 + G::img(p), gy = tp.ty0 + G::row(p), gx = tp.tx0 + G::col(p), co = co0 + 8 * j;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_direct_kernel(
         const int c = tid % NC, g = tid / NC;
         float sum = 0.f, sq = 0.f;
         for (int p = g * PPG; p < (g + 1) * PPG; ++p) {
-            const float v = bf2f(*(const bf16_t*)(Os + p * ROWB + (((c >> 2) ^ (p & SM)) << 3) + ((c & 3) << 1)));
+            const float v = bf2f(*(const bf16_t*)(Os + p * ROWB + (((c >> 2) ^ ((p ^ (p >> 2)) & SM)) << 3) + ((c & 3) << 1)));
             sum += v;
             sq += v * v;
         }
