@@ -128,10 +128,38 @@ DEVI void stage_qkv(char* img0, char* img1, char* img2, const bf16_t* src0, cons
     }
 }
 
+// two slices (K, V) staged the same way
+template <int HD, int NPAD, int NTH>
+DEVI void stage_kv(char* img0, char* img1, const bf16_t* src0, const bf16_t* src1, long long rs, int n,
+                   int tid) {
+    constexpr int CPR = HD / 8, TOTAL = NPAD * CPR, IT = (TOTAL + NTH - 1) / NTH;
+    u32x4 v[2][IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTH, row = idx / CPR, c = idx % CPR;
+        const bool ok = idx < TOTAL && row < n;
+        const size_t off = (size_t)row * rs + c * 8;
+        v[0][i] = ok ? *(const u32x4*)(src0 + off) : u32x4{0, 0, 0, 0};
+        v[1][i] = ok ? *(const u32x4*)(src1 + off) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTH, row = idx / CPR, c = idx % CPR;
+        if (idx < TOTAL) {
+            *(u32x4*)(img0 + img_off<HD>(row, c)) = v[0][i];
+            *(u32x4*)(img1 + img_off<HD>(row, c)) = v[1][i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ forward
-// WAVES: 4, or 8 when the three operand images leave room for only one workgroup per CU (hd 64,
-// N > 128: 86 KiB) — 8 waves share that one set of images, i.e. 2 waves per SIMD instead of 1, so
-// one wave's LDS reads and softmax VALU work overlap the other's MFMAs.
+// Three images (K, V, Q) of hd 64 above N = 144 would leave room for ONE workgroup per CU, whose
+// staging round trip nothing overlaps: there (AttnFwdQG) only K and V are staged — 57 KiB, two
+// 4-wave workgroups per CU — and a wave reads its query fragments straight from global memory, one
+// query tile ahead of its use (N = 197, hd 64: 120 -> 98 us).  The same split of the BACKWARD
+// kernel into a dQ and a dK/dV launch with two images each was measured and changes nothing (304
+// vs 305 us): the backward is issue-bound, not latency-bound.
+template <int HD, int NKT> struct AttnFwdQG { static constexpr bool value = HD == 64 && NKT >= 10; };
 template <int HD, int NKT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 14 ? 3 : 2))) void attn_fwd_bf16_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H,
@@ -149,9 +177,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
     const int D = H * HD;
     const long long rs = 3LL * D;
     const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
-    // every operand is LDS-fed: no global-load latency
-    stage_qkv<HD, NPAD, 64 * WAVES>(Kimg, Vimg, Qimg, qb + D, qb + 2 * D, qb, rs, N, tid);
-    __syncthreads();                              // inside the per-tile dependency chains
+    constexpr bool QG = AttnFwdQG<HD, NKT>::value;
+    if (QG) stage_kv<HD, NPAD, 64 * WAVES>(Kimg, Vimg, qb + D, qb + 2 * D, rs, N, tid);
+    else stage_qkv<HD, NPAD, 64 * WAVES>(Kimg, Vimg, Qimg, qb + D, qb + 2 * D, qb, rs, N, tid);
+    // QG: this lane's query fragment of tile qt (rows past N repeat the last one; never stored)
+    auto load_q = [&](int qt, bf16x8 (&dst)[KS]) {
+        int row = qt * 16 + (lane & 15);
+        row = row < N ? row : N - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dst[ks] = row_frag_global(qb, rs, row, ks, lane);
+    };
+    bf16x8 qnext[KS];
+    if (QG && ((wave + bh) & (WAVES - 1)) < ((N + 15) >> 4)) load_q((wave + bh) & (WAVES - 1), qnext);
+    __syncthreads();
     const float c = scale * 1.44269504088896340736f;
     const f32x2 c2 = {c, c};
     const int nqt = (N + 15) >> 4;
@@ -160,8 +198,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
     for (int qt = (wave + bh) & (WAVES - 1); qt < nqt; qt += WAVES) {
         const int q = qt * 16 + (lane & 15);
         bf16x8 qf[KS];
+        if (QG) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag<HD>(Qimg, qt * 16, ks, lane);
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = qnext[ks];
+            if (qt + WAVES < nqt) load_q(qt + WAVES, qnext);  // in flight behind this tile's work
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag<HD>(Qimg, qt * 16, ks, lane);
+        }
         f32x4 s[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -831,8 +875,9 @@ extern "C" size_t ssl4gie_attn_workspace_bytes(int dtype, int B, int N, int H, i
 template <int HD, int NKT>
 static int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale,
                       hipStream_t st) {
-    const size_t lds = (size_t)3 * NKT * 16 * HD * 2;
-    constexpr int WAVES = (3 * NKT * 16 * HD * 2 > 80 * 1024) ? 8 : 4;
+    constexpr bool QG = AttnFwdQG<HD, NKT>::value;
+    const size_t lds = (size_t)(QG ? 2 : 3) * NKT * 16 * HD * 2;
+    constexpr int WAVES = (!QG && 3 * NKT * 16 * HD * 2 > 80 * 1024) ? 8 : 4;
     auto k = attn_fwd_bf16_kernel<HD, NKT, WAVES>;
     if (lds > 65536)
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
