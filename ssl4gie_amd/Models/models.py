@@ -150,10 +150,39 @@ class _ViTBackbone(EngineModule):
         return self._readout(x)
 
 
+_INTERP_MAT = {}
+
+
+def _interp_matrix(g, device, n=14):
+    """[g, n] matrix of the 1-D bilinear resize n -> g with align_corners=True: row y holds the two
+    weights 1 - w, w at columns i0, i0 + 1, src = y (n - 1) / (g - 1), i0 = floor(src), w = src - i0
+    (what F.interpolate computes per output element; ATen's area_pixel_compute_source_index)."""
+    key = (g, n, str(device))
+    if key not in _INTERP_MAT:
+        import numpy as np
+        A = torch.zeros(g, n, dtype=torch.float32)
+        scale = np.float32(n - 1) / np.float32(g - 1) if g > 1 else np.float32(0)  # ATen works in fp32
+        for y in range(g):
+            src = np.float32(y) * scale
+            i0 = min(int(src), n - 1)
+            i1 = min(i0 + 1, n - 1)
+            w = np.float32(src - np.float32(i0))
+            A[y, i0] += float(np.float32(1) - w)
+            A[y, i1] += float(w)
+        _INTERP_MAT[key] = A.to(device)
+    return _INTERP_MAT[key]
+
+
 def _interp_pos(pos, g, D):
-    p2 = pos[:, 1:, :].transpose(1, 2).reshape(1, D, 14, 14)
-    p2 = nn.functional.interpolate(p2, size=(g, g), mode="bilinear", align_corners=True)
-    return p2.reshape(1, D, g * g).transpose(1, 2)
+    """reference `_pos_embed_interp` (models.py:310-323): the 14 x 14 grid of the position table resized
+    to g x g, bilinear with align_corners=True -> [1, g*g, D].  The resize is separable and linear,
+    out = (A (x) A) table: two small fp32 matmuls instead of F.interpolate, whose kernel for this tiny
+    NCHW tensor takes 1.1 ms forward on the MI355X (and as long backward)."""
+    A = _interp_matrix(g, pos.device)
+    t = pos[0, 1:, :].reshape(14, 14 * D)                       # [i, (j, d)]
+    t = (A @ t).reshape(g, 14, D)                               # rows resized: [y, j, d]
+    t = torch.matmul(A, t)                                      # columns: [y, x, d] (batched over y)
+    return t.reshape(1, g * g, D)
 
 
 class PosEmbedInterpAddFn(torch.autograd.Function):
