@@ -117,6 +117,25 @@ def test_direct_conv_weight_gradient_exact(B, H, W, Ci, Co, relu_in):
     assert torch.equal(db.double().cpu(), dy.sum((0, 1, 2)))
 
 
+def test_direct_conv_wide_channels_small_maps_exact():
+    """ResNet layer4 geometry (512 -> 512 on 7 x 7 maps): sixteen channel passes, eight cout groups,
+    8 x 8 tiles of four images; weight gradient with 8 x 16 (slice, group) combinations"""
+    from ssl4gie_amd import ops
+    B, H, W, Ci, Co = 6, 7, 7, 512, 512
+    x = ints((B, H, W, Ci), 51, -1, 2)
+    w = ints((Co, Ci, 3, 3), 52, -1, 2)
+    ref = ref_conv(x, w, None, False)
+    assert ref.abs().max() < 256
+    y = ops.conv3x3_direct_fwd(x.to(DEV, BF), w2_of(w).to(DEV, BF), None)
+    assert torch.equal(y.double().cpu(), ref)
+    dy = ints((B, H, W, Co), 53, -1, 2)
+    refw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (Co, Ci, 3, 3), dy.permute(0, 3, 1, 2), padding=1)
+    db = torch.zeros(Co, device=DEV)
+    dw2 = ops.conv3x3_direct_wgrad(dy.to(DEV, BF), x.to(DEV, BF), bias_out=db)
+    assert torch.equal(dw2.double().cpu(), w2_of(refw))
+    assert torch.equal(db.double().cpu(), dy.sum((0, 1, 2)))
+
+
 def test_direct_conv_matches_the_gathered_gemm_at_the_production_head_shape():
     """output_conv.2 at the depth-finetune geometry (224 x 224, 128 -> 32), random bf16 operands:
     forward against the gathered 256x256 GEMM path (same bf16 inputs, fp32 accumulation: only the
