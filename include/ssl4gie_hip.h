@@ -172,6 +172,14 @@ int ssl4gie_attn_bwd(const void* qkv, const void* out, const void* dout, const f
 int ssl4gie_cast(const float* src, void* dst, int dst_dtype, long long n, void* stream);
 int ssl4gie_cast_transpose(const float* src, void* dst, int dst_dtype, int rows, int cols,
                            void* stream);
+/* bf16 transposed copies of S matrices of one fp32 arena in ONE launch (the per-step refresh of the
+ * pre-transposed weight operands).  Device tables: mat_off [S] int64 element offsets (the same in src
+ * and dst), mat_rows / mat_cols [S], tile_start [S+1] = running count of 64 x 64 tiles per matrix
+ * (ceil(rows/64) * ceil(cols/64)), total_tiles = tile_start[S] (passed by value: no device read).
+ * dst[off + c * rows + r] = bf16(src[off + r * cols + c]). */
+int ssl4gie_cast_transpose_batch(const float* src, void* dst, const long long* mat_off,
+                                 const int* mat_rows, const int* mat_cols, const int* tile_start,
+                                 int S, int total_tiles, void* stream);
 /* out = a + b (b may be NULL), optionally also written as an operand-type copy out_lp:
  * plumbing of the fp32 residual-gradient stream (tap gradients, models.py:450-454). n % 4 == 0 */
 int ssl4gie_add_cast(const float* a, const float* b, float* out, void* out_lp, int lp_dtype,

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "ssl4gie_attn_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "ssl4gie_cast": (i32, [vp, vp, i32, i64, vp]),
     "ssl4gie_cast_transpose": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ssl4gie_cast_transpose_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "ssl4gie_add_cast": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "ssl4gie_mask_argsort": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "ssl4gie_patch_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i32, vp]),

@@ -67,6 +67,66 @@ extern "C" int ssl4gie_cast_transpose(const float* src, void* dst, int dst_dtype
     return 0;
 }
 
+// Transposed bf16 copies of MANY matrices of one fp32 arena in one launch (the per-step refresh of the
+// pre-transposed weight operands: 83 matrices for MAE ViT-B, which as 83 launches of 5 us each cost
+// more than the bytes).  Device tables: mat_off[m] = element offset of matrix m in `src` AND in
+// `dst`, rows / cols, tile_start[m] = index of its first 64 x 64 tile (tile_start[S] = total).
+// dst[off + c * rows + r] = bf16(src[off + r * cols + c]).
+__global__ __launch_bounds__(256) void cast_transpose_batch_kernel(
+    const float* __restrict__ src, bf16_t* __restrict__ dst, const long long* __restrict__ mat_off,
+    const int* __restrict__ mat_rows, const int* __restrict__ mat_cols, const int* __restrict__ tile_start,
+    int S) {
+    __shared__ float tile[64][65];
+    const int t = blockIdx.x;
+    int lo = 0, hi = S;  // last m with tile_start[m] <= t
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int R = mat_rows[lo], Cc = mat_cols[lo], lt = t - tile_start[lo];
+    const int tiles_c = (Cc + 63) >> 6;
+    const int r0 = (lt / tiles_c) * 64, c0 = (lt % tiles_c) * 64;
+    const float* sp = src + mat_off[lo];
+    bf16_t* dp = dst + mat_off[lo];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 elements each way
+    const bool vec = (R % 4 == 0) && (Cc % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 16 * i, c = c0 + 4 * tx;
+        f32x4 v = {0, 0, 0, 0};
+        if (r < R) {
+            if (vec && c + 3 < Cc) v = ld4(sp + (size_t)r * Cc + c);
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c + j < Cc) v[j] = sp[(size_t)r * Cc + c + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[ty + 16 * i][4 * tx + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 16 * i, r = r0 + 4 * tx;
+        if (c < Cc) {
+            const f32x4 v = {tile[4 * tx][ty + 16 * i], tile[4 * tx + 1][ty + 16 * i],
+                             tile[4 * tx + 2][ty + 16 * i], tile[4 * tx + 3][ty + 16 * i]};
+            if (vec && r + 3 < R) st4(dp + (size_t)c * R + r, v);
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (r + j < R) dp[(size_t)c * R + r + j] = f2bf(v[j]);
+        }
+    }
+}
+extern "C" int ssl4gie_cast_transpose_batch(const float* src, void* dst, const long long* mat_off,
+                                            const int* mat_rows, const int* mat_cols,
+                                            const int* tile_start, int S, int total_tiles, void* stream) {
+    REQUIRE(src && dst && mat_off && mat_rows && mat_cols && tile_start && S > 0 && total_tiles > 0);
+    hipLaunchKernelGGL(cast_transpose_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0,
+                       (hipStream_t)stream, src, (bf16_t*)dst, mat_off, mat_rows, mat_cols, tile_start, S);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // out = a (+ b); optional operand-type copy (residual-gradient stream plumbing)
 template <typename T>
 __global__ void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b,

@@ -74,6 +74,45 @@ class ParamArena:
         o = self._index[id(p)]
         return self.grad[o:o + p.numel()].view(p.shape)
 
+    # -- operand-type (bf16) shadow of the whole arena, refreshed in two launches ---------------
+    def lp_views(self, p, dtype):
+        """(W [out, in], W^T [in, out]) views of the bf16 shadow arenas for parameter `p` (ndim >= 2),
+        refreshing BOTH shadows for every parameter when the weights changed since the last refresh
+        (engine.weights_epoch): one flat cast + one batched transposed cast instead of two small
+        launches per weight."""
+        assert dtype == torch.bfloat16
+        if getattr(self, "_lp_stamp", None) != weights_epoch():
+            self._refresh_lp()
+        o = self._index[id(p)]
+        rows = p.shape[0]
+        cols = p.numel() // rows
+        return (self._lp[o:o + p.numel()].view(rows, cols), self._lpt[o:o + p.numel()].view(cols, rows))
+
+    def _refresh_lp(self):
+        L = _lib.load()
+        if getattr(self, "_lp", None) is None:
+            self._lp = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device)
+            self._lpt = torch.zeros(self.numel, dtype=torch.bfloat16, device=self.device)
+            mats = [(o, p.shape[0], p.numel() // p.shape[0]) for p, o in zip(self.params, self.offsets)
+                    if p.ndim >= 2]
+            starts = [0]
+            for _, r, c in mats:
+                starts.append(starts[-1] + ((r + 63) // 64) * ((c + 63) // 64))
+            dev = self.device
+            self._lp_tab = (torch.tensor([m[0] for m in mats], dtype=torch.int64, device=dev),
+                            torch.tensor([m[1] for m in mats], dtype=torch.int32, device=dev),
+                            torch.tensor([m[2] for m in mats], dtype=torch.int32, device=dev),
+                            torch.tensor(starts, dtype=torch.int32, device=dev), len(mats), starts[-1])
+        _lib.check(L.ssl4gie_cast(ops.ptr(self.data), ops.ptr(self._lp), _lib.BF16, self.numel, ops.stream()),
+                   "cast(arena)")
+        off, rows, cols, ts, S, total = self._lp_tab
+        if S:
+            _lib.check(L.ssl4gie_cast_transpose_batch(ops.ptr(self.data), ops.ptr(self._lpt), ops.ptr(off),
+                                                      ops.ptr(rows), ops.ptr(cols), ops.ptr(ts), S, total,
+                                                      ops.stream()), "cast_transpose_batch")
+        self._lp_stamp = weights_epoch()
+        self._lp_versions = {id(p): p._version for p in self.params}
+
     def span(self, params: Sequence[nn.Parameter]):
         """[start, end) element range of the grad arena covering `params`."""
         os_ = [self._index[id(p)] for p in params]
@@ -97,12 +136,24 @@ def bump_weights_epoch():
     _WEIGHTS_EPOCH[0] += 1
 
 
+# torch's FUSED optimizers (torch.optim.AdamW(..., fused=True)) update parameters without bumping
+# Tensor._version, so version counters alone would leave every bf16 operand copy stale after the first
+# step (the linear layers would keep computing with their initial weights).  Every optimizer step —
+# any optimizer, fused or not — therefore advances the epoch.
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(lambda _opt, _args, _kwargs: bump_weights_epoch())
+except ImportError:  # torch < 2.0: callers must use ssl4gie_amd.optim or call bump_weights_epoch()
+    pass
+
+
 class LPCache:
     """bf16 copies W[out,in] and W^T[in,out] of fp32 master weights, refreshed when the parameter's
     version counter or storage changes (optimizer.step / load_state_dict bump it)."""
 
-    def __init__(self):
+    def __init__(self, arena_fn=None):
         self._c = {}
+        self._arena_fn = arena_fn  # -> ParamArena whose shadow copies serve its own parameters
 
     def get(self, p: torch.Tensor, dtype, need_t: bool = True):
         w2d = p.detach()
@@ -113,8 +164,18 @@ class LPCache:
         ver = (p._version, p.data_ptr(), dtype, weights_epoch())
         ent = self._c.get(key)
         if ent is None or ent[0] != ver or ent[3]() is not p:
-            w = ops.cast(w2d, dtype)
-            wt = ops.cast_transpose(w2d, dtype)
+            a = self._arena_fn() if self._arena_fn is not None else None
+            if a is not None and dtype == torch.bfloat16 and a.owns(p):
+                # the whole arena is refreshed at once (two launches per optimizer step); a parameter
+                # edited in place since then (its version moved, the epoch did not) is re-cast alone
+                w, wt = a.lp_views(p, dtype)
+                if a._lp_versions.get(key) != p._version:
+                    ops.cast(w2d, dtype, out=w)
+                    ops.cast_transpose(w2d, dtype, out=wt)
+                    a._lp_versions[key] = p._version
+            else:
+                w = ops.cast(w2d, dtype)
+                wt = ops.cast_transpose(w2d, dtype)
             ent = (ver, w, wt, weakref.ref(p))
             self._c[key] = ent
         return ent[1], ent[2]
@@ -649,7 +710,7 @@ class EngineModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._arena: Optional[ParamArena] = None
-        self._lp = LPCache()
+        self._lp = LPCache(self._arena_nocheck)
         self._sink = None
         object.__setattr__(self, "_root", None)  # owning EngineModule when nested (not a child link)
 
@@ -693,6 +754,10 @@ class EngineModule(nn.Module):
                     v.copy_(g)
                     p.grad = v
         return a
+
+    def _arena_nocheck(self) -> Optional[ParamArena]:
+        """the arena as validated by the last _prepare() (no parameter walk): operand-cache lookups"""
+        return self._root._arena_nocheck() if self._root is not None else self._arena
 
     def _prepare(self):
         """Call once at the top of forward(): validates the arena (cheap pointer checks)."""

@@ -148,3 +148,61 @@ def test_arena_optimizer_state_dict_round_trip():
             assert torch.equal(p1, p2), n1
         a = m1.arena()
         assert all(p.grad is None or p.grad.data_ptr() == a.grad_view(p).data_ptr() for p in m1.parameters())
+
+
+def test_bf16_operand_copies_follow_fused_and_plain_optimizer_steps():
+    """torch's fused AdamW does not bump Tensor._version: the operand caches must still see every
+    optimizer step (engine registers a global optimizer post-hook), and the arena-wide refresh (one
+    flat cast + one batched transposed cast) must equal the per-parameter casts, including after an
+    in-place edit of a single parameter."""
+    from ssl4gie_amd.Models.mae import models_mae
+    torch.manual_seed(0)
+    model = models_mae.MaskedAutoencoderViT(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2,
+                                            decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2,
+                                            mlp_ratio=3).to(DEV).set_precision("bf16")
+    imgs = torch.randn(4, 3, 32, 32, device=DEV)
+    for fused in (True, False):
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-2, fused=fused)
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss, _, _ = model(imgs, mask_ratio=0.5)
+            loss.backward()
+            opt.step()
+        loss, _, _ = model(imgs, mask_ratio=0.5)  # refreshes the caches
+        for name, p in model.named_parameters():
+            if p.ndim == 2 and "pos_embed" not in name:
+                w, wt = model.lp_cache.get(p, torch.bfloat16)
+                ref = p.detach().to(torch.bfloat16)
+                assert torch.equal(w, ref), (fused, name)
+                assert torch.equal(wt, ref.t().contiguous()), (fused, name)
+    w0 = model.blocks[0].mlp.fc1.weight
+    with torch.no_grad():
+        w0.mul_(0.5)  # version moves, epoch does not
+    w, wt = model.lp_cache.get(w0, torch.bfloat16)
+    ref = w0.detach().to(torch.bfloat16)
+    assert torch.equal(w, ref) and torch.equal(wt, ref.t().contiguous())
+
+
+def test_batched_transposed_cast_ragged_matrices():
+    """ssl4gie_cast_transpose_batch on matrices that are not multiples of its 64 x 64 tile (and not of
+    4: the scalar path), against per-matrix torch transposes; bit-exact (same RNE conversion)."""
+    from ssl4gie_amd import _lib, ops
+    shapes = [(64, 64), (192, 64), (7, 5), (130, 257), (1, 300), (100, 4), (33, 64)]
+    offs, total = [], 0
+    for r, c in shapes:
+        offs.append(total)
+        total += (r * c + 63) // 64 * 64
+    src = torch.randn(total, device=DEV)
+    dst = torch.zeros(total, dtype=torch.bfloat16, device=DEV)
+    starts = [0]
+    for r, c in shapes:
+        starts.append(starts[-1] + ((r + 63) // 64) * ((c + 63) // 64))
+    t = lambda v, dt: torch.tensor(v, dtype=dt, device=DEV)
+    off_t, r_t, c_t, s_t = t(offs, torch.int64), t([s[0] for s in shapes], torch.int32), \
+        t([s[1] for s in shapes], torch.int32), t(starts, torch.int32)
+    _lib.check(_lib.load().ssl4gie_cast_transpose_batch(ops.ptr(src), ops.ptr(dst), ops.ptr(off_t), ops.ptr(r_t),
+                                                        ops.ptr(c_t), ops.ptr(s_t), len(shapes), starts[-1],
+                                                        ops.stream()), "cast_transpose_batch")
+    for (r, c), o in zip(shapes, offs):
+        ref = src[o:o + r * c].view(r, c).to(torch.bfloat16).t().contiguous()
+        assert torch.equal(dst[o:o + r * c].view(c, r), ref), (r, c)
