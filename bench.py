@@ -194,7 +194,11 @@ def bench_depth(a):
     model = models.ViT_from_MAE(None, False, 1, False, "depth", False, None, 768, 12, 12, "cls")
     model.to(dev).set_precision(a.precision)
     ddp = parallel.DataParallel(model) if world > 1 else None
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
+    if a.optim == "arena":
+        from ssl4gie_amd.optim import ArenaAdamW
+        opt = ArenaAdamW(model, [p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    else:
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
     loss_fn = ScaleAndShiftInvariantLoss(alpha=0.1)
     g = torch.Generator("cpu").manual_seed(rank)
     imgs = torch.randn(B, 3, 224, 224, generator=g).to(dev)
@@ -304,7 +308,11 @@ def bench_vit(a):
     model = models.ViT_from_MAE(None, True, 6, False, None, False, None, 768, 12, 12, "cls")
     model.to(dev).set_precision(a.precision)
     ddp = parallel.DataParallel(model) if world > 1 else None
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
+    if a.optim == "arena":
+        from ssl4gie_amd.optim import ArenaAdamW
+        opt = ArenaAdamW(model, [p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    else:
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
     g = torch.Generator("cpu").manual_seed(rank)
     imgs = torch.randn(B, 3, 224, 224, generator=g).to(dev)
     labels = torch.randint(0, 6, (B,), generator=g).to(dev)
@@ -352,7 +360,11 @@ def bench_det(a):
     model = models.VisionTransformer_from_Any(False, 0, False, None, True, 1024, 768, 12, 12, "cls")
     model.to(dev).set_precision(a.precision)
     ddp = parallel.DataParallel(model) if world > 1 else None
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
+    if a.optim == "arena":
+        from ssl4gie_amd.optim import ArenaAdamW
+        opt = ArenaAdamW(model, [p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    else:
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
     g = torch.Generator("cpu").manual_seed(rank)
     imgs = torch.randn(B, 3, 1024, 1024, generator=g).to(dev)
 
@@ -459,9 +471,12 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--optim", default="torch", choices=["torch", "arena"],
-                    help="torch: torch.optim fused / foreach steps (what the north_star prescribes); arena: "
-                         "the same updates as kernels over the parameter arena (ssl4gie_amd.optim)")
+    ap.add_argument("--optim", default="arena", choices=["torch", "arena"],
+                    help="arena: the optimizer update as kernels over the parameter arena (ssl4gie_amd.optim: "
+                         "torch.optim.AdamW's / the reference LARS's arithmetic, tests/test_gpu_optim.py; "
+                         "AdamW also emits the bf16 operand copies) — measured faster than torch's fused "
+                         "step once that refreshes the operand copies too; torch: torch.optim fused / "
+                         "foreach steps")
     ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco", "bt", "det", "vit"],
                     help="mae = BASELINE.json configs[1] (the headline metric); depth = configs[3] "
                          "(ViT-B + DPT depth finetune step, bs 128/GPU) as an extra measurement")
@@ -582,7 +597,8 @@ def main():
                                    "mask 0.75) fwd+bwd+grad-allreduce+AdamW, 224x224 synthetic "
                                    "N(0,1) images resident in HBM",
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "optimizer": "AdamW(0.9,0.95) wd 0.05"},
+                       "parallelism": f"dp{world}",
+                       "optimizer": "AdamW(0.9,0.95) wd 0.05 (" + ("ssl4gie_amd.optim.ArenaAdamW" if a.optim == "arena" else "torch.optim.AdamW fused") + ")"},
             "images_per_sec_per_gpu": round(ips / world, 1),
             "model_mfma_frac": round(ips / world * GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS, 4),
             "final_loss": round(final_loss, 5),

@@ -448,6 +448,12 @@ int ssl4gie_avgpool_bwd(const float* dy, void* dx, int dtype, int B, int HW, int
 int ssl4gie_adamw_arena(float* p, const float* g, float* m, float* v, const long long* seg_start,
                         const float* seg_lr, const float* seg_wd, int S, float beta1, float beta2,
                         float eps, int step, long long n, void* stream);
+/* the same step, also writing the bf16 operand copy of every UPDATED element into lp_bf16 [n] (the
+ * flat shadow arena the GEMM operands are views of; skipped segments are left as they are) — saves
+ * the separate cast pass over the arena.  lp_bf16 = NULL: as ssl4gie_adamw_arena. */
+int ssl4gie_adamw_arena_lp(float* p, const float* g, float* m, float* v, const long long* seg_start,
+                           const float* seg_lr, const float* seg_wd, int S, float beta1, float beta2,
+                           float eps, int step, long long n, void* lp_bf16, void* stream);
 size_t ssl4gie_lars_workspace_bytes(int S);
 int ssl4gie_lars_arena(float* p, const float* g, float* mu, const long long* seg_start,
                        const float* seg_lr, const float* seg_wd, const float* seg_mat, int S,

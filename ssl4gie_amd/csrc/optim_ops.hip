@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void adamw_arena_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
     const long long* __restrict__ seg_start, const float* __restrict__ seg_lr,
     const float* __restrict__ seg_wd, int S, float b1, float b2, float eps, float bc1, float rsqrt_bc2,
-    long long n) {
+    long long n, bf16_t* __restrict__ lp) {
     const long long first = (long long)blockIdx.x * blockDim.x * 4;
     const long long i = first + threadIdx.x * 4;
     const int s = block_seg(seg_start, S, i < n ? i : n - 4, first);  // slices are 64-element aligned
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void adamw_arena_kernel(
     st4(p + i, pp);
     st4(m + i, mm);
     st4(v + i, vv);
+    if (lp) st4(lp + i, pp);  // the bf16 operand copy of the updated weights, while they are in registers
 }
 
 // LARS stage 1: partial[(s * parts + part) * 2 + {0, 1}] = sum p^2, sum (g + wd p)^2 over the part
@@ -136,18 +137,25 @@ __global__ __launch_bounds__(256) void lars_apply_kernel(
     st4(mu + i, mm);
 }
 
-extern "C" int ssl4gie_adamw_arena(float* p, const float* g, float* m, float* v,
-                                   const long long* seg_start, const float* seg_lr,
-                                   const float* seg_wd, int S, float beta1, float beta2, float eps,
-                                   int step, long long n, void* stream) {
+extern "C" int ssl4gie_adamw_arena_lp(float* p, const float* g, float* m, float* v,
+                                      const long long* seg_start, const float* seg_lr,
+                                      const float* seg_wd, int S, float beta1, float beta2, float eps,
+                                      int step, long long n, void* lp_bf16, void* stream) {
     REQUIRE(p && g && m && v && seg_start && seg_lr && seg_wd && S > 0 && step > 0 && n >= 0 && n % 4 == 0);
     if (n == 0) return 0;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_arena_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, p, g, m, v, seg_start, seg_lr, seg_wd, S, beta1, beta2, eps,
-                       bc1, 1.f / sqrtf(bc2), n);
+                       bc1, 1.f / sqrtf(bc2), n, (bf16_t*)lp_bf16);
     LAUNCH_CHECK();
     return 0;
+}
+extern "C" int ssl4gie_adamw_arena(float* p, const float* g, float* m, float* v,
+                                   const long long* seg_start, const float* seg_lr,
+                                   const float* seg_wd, int S, float beta1, float beta2, float eps,
+                                   int step, long long n, void* stream) {
+    return ssl4gie_adamw_arena_lp(p, g, m, v, seg_start, seg_lr, seg_wd, S, beta1, beta2, eps, step, n,
+                                  nullptr, stream);
 }
 extern "C" size_t ssl4gie_lars_workspace_bytes(int S) {
     return ((size_t)S * LARS_PARTS * 2 + S) * sizeof(float);

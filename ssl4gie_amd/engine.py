@@ -88,6 +88,17 @@ class ParamArena:
         cols = p.numel() // rows
         return (self._lp[o:o + p.numel()].view(rows, cols), self._lpt[o:o + p.numel()].view(cols, rows))
 
+    def lp_flat_for_update(self):
+        """the flat bf16 shadow, for an optimizer kernel that writes the updated elements into it
+        (optim.ArenaAdamW); brought up to date first, so that segments the kernel skips stay valid"""
+        if getattr(self, "_lp_stamp", None) != weights_epoch():
+            self._refresh_lp()
+        return self._lp
+
+    def lp_flat_is_current(self):
+        """called after bump_weights_epoch() by an optimizer that wrote the flat shadow itself"""
+        self._lp_flat_stamp = weights_epoch()
+
     def _refresh_lp(self):
         L = _lib.load()
         if getattr(self, "_lp", None) is None:
@@ -103,8 +114,9 @@ class ParamArena:
                             torch.tensor([m[1] for m in mats], dtype=torch.int32, device=dev),
                             torch.tensor([m[2] for m in mats], dtype=torch.int32, device=dev),
                             torch.tensor(starts, dtype=torch.int32, device=dev), len(mats), starts[-1])
-        _lib.check(L.ssl4gie_cast(ops.ptr(self.data), ops.ptr(self._lp), _lib.BF16, self.numel, ops.stream()),
-                   "cast(arena)")
+        if getattr(self, "_lp_flat_stamp", None) != weights_epoch():
+            _lib.check(L.ssl4gie_cast(ops.ptr(self.data), ops.ptr(self._lp), _lib.BF16, self.numel,
+                                      ops.stream()), "cast(arena)")
         off, rows, cols, ts, S, total = self._lp_tab
         if S:
             _lib.check(L.ssl4gie_cast_transpose_batch(ops.ptr(self.data), ops.ptr(self._lpt), ops.ptr(off),

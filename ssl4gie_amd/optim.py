@@ -145,11 +145,17 @@ class ArenaAdamW(_ArenaOptimizer):
             self.exp_avg_sq = torch.zeros_like(a.data)
         start, lr, wd, _, S = self._build_tables(a)
         self.step_count += 1
-        _lib.check(_lib.load().ssl4gie_adamw_arena(ptr(a.data), ptr(a.grad), ptr(self.exp_avg),
-                                                   ptr(self.exp_avg_sq), ptr(start), ptr(lr), ptr(wd), S,
-                                                   self.betas[0], self.betas[1], self.eps, self.step_count,
-                                                   a.numel, stream()), "adamw_arena")
+        # the kernel also writes the bf16 operand copy of what it updates into the arena's flat shadow
+        # (engine.ParamArena.lp_views): the next forward then only needs the batched transposes
+        lp = a.lp_flat_for_update() if a.data.is_cuda else None
+        _lib.check(_lib.load().ssl4gie_adamw_arena_lp(ptr(a.data), ptr(a.grad), ptr(self.exp_avg),
+                                                      ptr(self.exp_avg_sq), ptr(start), ptr(lr), ptr(wd), S,
+                                                      self.betas[0], self.betas[1], self.eps,
+                                                      self.step_count, a.numel, ptr(lp), stream()),
+                   "adamw_arena")
         bump_weights_epoch()
+        if lp is not None:
+            a.lp_flat_is_current()
 
 
 class ArenaLARS(_ArenaOptimizer):
