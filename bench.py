@@ -507,7 +507,8 @@ def main():
     ddp = parallel.DataParallel(model) if world > 1 else None
     if a.optim == "arena":  # the same update as one kernel over the parameter arena
         from ssl4gie_amd.optim import ArenaAdamW
-        opt = ArenaAdamW(model, param_groups(model), lr=1.5e-4, betas=(0.9, 0.95))
+        opt = ArenaAdamW(model, param_groups(model), lr=1.5e-4, betas=(0.9, 0.95),
+                         overlap_backward=os.environ.get("SSL4GIE_OPT_OVERLAP", "0") == "1")  # measured: no gain
     else:
         try:
             opt = torch.optim.AdamW(param_groups(model), lr=1.5e-4, betas=(0.9, 0.95), fused=True)

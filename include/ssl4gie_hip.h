@@ -454,6 +454,14 @@ int ssl4gie_adamw_arena(float* p, const float* g, float* m, float* v, const long
 int ssl4gie_adamw_arena_lp(float* p, const float* g, float* m, float* v, const long long* seg_start,
                            const float* seg_lr, const float* seg_wd, int S, float beta1, float beta2,
                            float eps, int step, long long n, void* lp_bf16, void* stream);
+/* the same step restricted to the arena elements [lo, hi) (multiples of 4; whole segments in
+ * practice): lets the update of a transformer block's parameters be enqueued on a side stream as
+ * soon as that block's backward is, behind the rest of the backward pass (optim.ArenaAdamW,
+ * overlap_backward).  The union of the ranges of one step must cover [0, n) exactly once. */
+int ssl4gie_adamw_arena_range(float* p, const float* g, float* m, float* v, const long long* seg_start,
+                              const float* seg_lr, const float* seg_wd, int S, float beta1, float beta2,
+                              float eps, int step, long long lo, long long hi, void* lp_bf16,
+                              void* stream);
 size_t ssl4gie_lars_workspace_bytes(int S);
 int ssl4gie_lars_arena(float* p, const float* g, float* mu, const long long* seg_start,
                        const float* seg_lr, const float* seg_wd, const float* seg_mat, int S,

@@ -126,6 +126,7 @@ PROTOTYPES = {
     "ssl4gie_bn_stats_partials": (i32, [vp, i32, vp, vp, vp, i64, i32, vp]),
     "ssl4gie_adamw_arena": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, i64, vp]),
     "ssl4gie_adamw_arena_lp": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, i64, vp, vp]),
+    "ssl4gie_adamw_arena_range": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, i64, i64, vp, vp]),
     "ssl4gie_lars_workspace_bytes": (sz, [i32]),
     "ssl4gie_lars_arena": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, i64, vp]),
     "ssl4gie_normalize_u8": (i32, [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, i32, i32, vp]),

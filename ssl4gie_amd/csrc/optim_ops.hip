@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void adamw_arena_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
     const long long* __restrict__ seg_start, const float* __restrict__ seg_lr,
     const float* __restrict__ seg_wd, int S, float b1, float b2, float eps, float bc1, float rsqrt_bc2,
-    long long n, bf16_t* __restrict__ lp) {
-    const long long first = (long long)blockIdx.x * blockDim.x * 4;
+    long long n, bf16_t* __restrict__ lp, long long lo) {
+    const long long first = lo + (long long)blockIdx.x * blockDim.x * 4;  // elements [lo, n)
     const long long i = first + threadIdx.x * 4;
     const int s = block_seg(seg_start, S, i < n ? i : n - 4, first);  // slices are 64-element aligned
     if (i >= n) return;
@@ -137,18 +137,28 @@ __global__ __launch_bounds__(256) void lars_apply_kernel(
     st4(mu + i, mm);
 }
 
+extern "C" int ssl4gie_adamw_arena_range(float* p, const float* g, float* m, float* v,
+                                         const long long* seg_start, const float* seg_lr,
+                                         const float* seg_wd, int S, float beta1, float beta2, float eps,
+                                         int step, long long lo, long long hi, void* lp_bf16,
+                                         void* stream) {
+    REQUIRE(p && g && m && v && seg_start && seg_lr && seg_wd && S > 0 && step > 0 && lo >= 0 && hi >= lo &&
+            lo % 4 == 0 && hi % 4 == 0);
+    if (hi == lo) return 0;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_arena_kernel, dim3((unsigned)(((hi - lo) / 4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, p, g, m, v, seg_start, seg_lr, seg_wd, S, beta1, beta2, eps,
+                       bc1, 1.f / sqrtf(bc2), hi, (bf16_t*)lp_bf16, lo);
+    LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int ssl4gie_adamw_arena_lp(float* p, const float* g, float* m, float* v,
                                       const long long* seg_start, const float* seg_lr,
                                       const float* seg_wd, int S, float beta1, float beta2, float eps,
                                       int step, long long n, void* lp_bf16, void* stream) {
-    REQUIRE(p && g && m && v && seg_start && seg_lr && seg_wd && S > 0 && step > 0 && n >= 0 && n % 4 == 0);
-    if (n == 0) return 0;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_arena_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, p, g, m, v, seg_start, seg_lr, seg_wd, S, beta1, beta2, eps,
-                       bc1, 1.f / sqrtf(bc2), n, (bf16_t*)lp_bf16);
-    LAUNCH_CHECK();
-    return 0;
+    REQUIRE(n >= 0);
+    return ssl4gie_adamw_arena_range(p, g, m, v, seg_start, seg_lr, seg_wd, S, beta1, beta2, eps, step, 0, n,
+                                     lp_bf16, stream);
 }
 extern "C" int ssl4gie_adamw_arena(float* p, const float* g, float* m, float* v,
                                    const long long* seg_start, const float* seg_lr,

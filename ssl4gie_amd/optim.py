@@ -127,15 +127,102 @@ class _ArenaOptimizer:
 
 
 class ArenaAdamW(_ArenaOptimizer):
-    """`ArenaAdamW(model, params_or_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)`"""
+    """`ArenaAdamW(model, params_or_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+    overlap_backward=False)`
 
-    def __init__(self, model, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    overlap_backward: the update of a transformer block's parameters is enqueued on a side stream as
+    soon as that block's backward kernels are (engine.GradSink.tracker), so it runs behind the rest of
+    the backward pass in the CUs the data-gradient chain leaves idle; `step()` then updates whatever is
+    left and joins the streams.  Same arithmetic, same result.  It engages from the second step on
+    (the first one learns which parameters get gradients), only while every parameter is used ONCE per
+    backward pass (two-view models accumulate over uses), never with gradient accumulation over
+    several backward passes, and not under parallel.DataParallel (which owns the tracker: its
+    gradient all-reduce has to come first).  Measured on the MAE ViT-B step it does NOT pay (24.1 vs
+    23.9-24.0 ms, same box): the HBM-bound update competes with the backward GEMMs' operand traffic for
+    about what it hides.  Kept, off by default, because the result is bitwise the plain step's
+    (tests/test_gpu_optim.py) and a model with more idle CUs in its backward may differ."""
+
+    def __init__(self, model, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 overlap_backward=False):
         super().__init__(model, params, dict(lr=lr, weight_decay=weight_decay))
         self.betas, self.eps = betas, eps
         self.exp_avg = self.exp_avg_sq = None
+        self._overlap = bool(overlap_backward)
+        self._stream = None        # side stream of the in-backward updates
+        self._done = []            # [lo, hi) ranges already updated in the current step
+        self._tables = None        # device tables of the current step (built at its first use)
+        self._seen = {}            # id(p) -> tracker calls in the current pass
+        self._hooked = False
+        self._lp = None
 
     def _state_buffers(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+
+    # ------------------------------------------------------------------ in-backward updates
+    def _hook(self):
+        if self._overlap and not self._hooked:
+            sink = self.model.sink()
+            if sink.tracker is None:
+                sink.tracker = self._on_use_done
+                self._hooked = True
+            else:
+                self._overlap = False  # somebody else (DataParallel) owns the engine's call-back
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none)
+        self._hook()
+        self._done, self._seen, self._tables = [], {}, None
+
+    def _launch(self, a, lo, hi, st):
+        start, lr, wd, _, S = self._tables
+        _lib.check(_lib.load().ssl4gie_adamw_arena_range(
+            ptr(a.data), ptr(a.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(start), ptr(lr), ptr(wd), S,
+            self.betas[0], self.betas[1], self.eps, self.step_count + 1, lo, hi, ptr(self._lp), st),
+            "adamw_arena_range")
+
+    @torch.no_grad()
+    def _on_use_done(self, params):
+        if not self._overlap or self.exp_avg is None or self._tables_key is None:
+            return  # first step: plain update in step()
+        for p in params:
+            n = self._seen.get(id(p), 0) + 1
+            self._seen[id(p)] = n
+            if n > 1:  # a second use in one pass: gradients still accumulating — not this model
+                self._overlap = False
+                return
+        a = self.model.arena()
+        lo, hi = a.span(params)
+        inside = [q for q, o in zip(a.params, a.offsets) if lo <= o < hi]
+        ids = {id(p) for p in params}
+        if any(id(q) not in ids for q in inside) or any(lo < h and l < hi for l, h in self._done):
+            return  # not a contiguous run of exactly these parameters: left to step()
+        if self._tables is None:
+            self._lp = a.lp_flat_for_update()
+            self._tables = self._build_tables_cached(a)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=a.data.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(a.data.device))  # the block's backward, incl. its dW join
+        self._stream.wait_event(ev)
+        self._launch(a, lo, hi, self._stream.cuda_stream)
+        self._done.append((lo, hi))
+
+    def _build_tables_cached(self, a):
+        """tables with the ACTIVE mask of the previous step (gradients do not exist yet while the
+        backward pass is running); only the lr / wd values are refreshed"""
+        saved = self._tables_key
+        n = len(a.params)
+        group_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+        hyper = tuple((g["lr"], g["weight_decay"]) for g in self.param_groups)
+        if hyper != self._hyper:
+            lr_h, wd_h = self._host
+            lr_h.copy_(torch.tensor([hyper[gi][0] if gi >= 0 else -1.0 for gi in self._gidx]))
+            wd_h.copy_(torch.tensor([hyper[gi][1] if gi >= 0 else 0.0 for gi in self._gidx]))
+            self._dev[1].copy_(lr_h, non_blocking=True)
+            self._dev[2].copy_(wd_h, non_blocking=True)
+            self._hyper = hyper
+        assert self._tables_key == saved and group_of is not None
+        return tuple(self._dev) + (n,)
 
     @torch.no_grad()
     def step(self):
@@ -143,18 +230,27 @@ class ArenaAdamW(_ArenaOptimizer):
         if self.exp_avg is None or self.exp_avg.numel() != a.numel:
             self.exp_avg = torch.zeros_like(a.data)
             self.exp_avg_sq = torch.zeros_like(a.data)
-        start, lr, wd, _, S = self._build_tables(a)
-        self.step_count += 1
-        # the kernel also writes the bf16 operand copy of what it updates into the arena's flat shadow
+        key_before = self._tables_key
+        tables = self._build_tables(a)
+        if self._done and self._tables_key != key_before:
+            raise RuntimeError("ArenaAdamW(overlap_backward=True): the set of parameters with gradients "
+                               "changed between steps after part of this step was already applied")
+        self._tables = tables
+        # the kernels also write the bf16 operand copy of what they update into the arena's flat shadow
         # (engine.ParamArena.lp_views): the next forward then only needs the batched transposes
-        lp = a.lp_flat_for_update() if a.data.is_cuda else None
-        _lib.check(_lib.load().ssl4gie_adamw_arena_lp(ptr(a.data), ptr(a.grad), ptr(self.exp_avg),
-                                                      ptr(self.exp_avg_sq), ptr(start), ptr(lr), ptr(wd), S,
-                                                      self.betas[0], self.betas[1], self.eps,
-                                                      self.step_count, a.numel, ptr(lp), stream()),
-                   "adamw_arena")
+        self._lp = a.lp_flat_for_update() if a.data.is_cuda else None
+        st = stream()
+        pos = 0
+        for lo, hi in sorted(self._done) + [(a.numel, a.numel)]:  # the complement of the ranges done
+            if lo > pos:
+                self._launch(a, pos, lo, st)
+            pos = max(pos, hi)
+        if self._done:
+            torch.cuda.current_stream(a.data.device).wait_stream(self._stream)
+        self.step_count += 1
+        self._done, self._seen, self._tables = [], {}, None
         bump_weights_epoch()
-        if lp is not None:
+        if self._lp is not None:
             a.lp_flat_is_current()
 
 

@@ -206,3 +206,47 @@ def test_batched_transposed_cast_ragged_matrices():
     for (r, c), o in zip(shapes, offs):
         ref = src[o:o + r * c].view(r, c).to(torch.bfloat16).t().contiguous()
         assert torch.equal(dst[o:o + r * c].view(c, r), ref), (r, c)
+
+
+def test_arena_adamw_in_backward_updates_match_the_plain_step():
+    """overlap_backward=True enqueues each block's update behind that block's backward on a side
+    stream; the arithmetic is the same, so parameters, moments and the bf16 operand copies must be
+    bitwise those of the plain step — over several steps, with a learning-rate change in between"""
+    from ssl4gie_amd.Models.mae import models_mae
+    from ssl4gie_amd.optim import ArenaAdamW
+
+    def run(overlap):
+        torch.manual_seed(0)
+        model = models_mae.MaskedAutoencoderViT(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=2,
+                                                decoder_embed_dim=64, decoder_depth=2, decoder_num_heads=2,
+                                                mlp_ratio=4).to(DEV).set_precision("bf16")
+        decay = [p for p in model.parameters() if p.requires_grad and p.ndim > 1]
+        rest = [p for p in model.parameters() if p.requires_grad and p.ndim <= 1]
+        opt = ArenaAdamW(model, [{"params": decay, "weight_decay": 0.05}, {"params": rest, "weight_decay": 0.0}],
+                         lr=1e-2, betas=(0.9, 0.95), overlap_backward=overlap)
+        imgs = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(DEV)
+        noise = torch.rand(8, 16, generator=torch.Generator().manual_seed(4)).to(DEV)
+        for it in range(5):
+            if it == 3:
+                for g in opt.param_groups:
+                    g["lr"] = 3e-3
+            opt.zero_grad(set_to_none=True)
+            loss, _, _ = model(imgs, mask_ratio=0.5, noise=noise)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        used = len(opt._done) == 0 and opt._overlap
+        return model, opt, float(loss), used
+
+    torch.manual_seed(1)
+    m0, o0, l0, _ = run(False)
+    m1, o1, l1, active = run(True)
+    assert active, "the overlapped mode fell back to the plain step"
+    assert l0 == l1
+    for (n0, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(p0, p1), n0
+    assert torch.equal(o0.exp_avg, o1.exp_avg) and torch.equal(o0.exp_avg_sq, o1.exp_avg_sq)
+    w = m1.blocks[1].mlp.fc2.weight
+    lp, lpt = m1.lp_cache.get(w, torch.bfloat16)
+    ref = w.detach().to(torch.bfloat16)
+    assert torch.equal(lp, ref) and torch.equal(lpt, ref.t().contiguous())
