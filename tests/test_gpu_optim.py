@@ -250,3 +250,29 @@ def test_arena_adamw_in_backward_updates_match_the_plain_step():
     lp, lpt = m1.lp_cache.get(w, torch.bfloat16)
     ref = w.detach().to(torch.bfloat16)
     assert torch.equal(lp, ref) and torch.equal(lpt, ref.t().contiguous())
+
+
+def test_bf16_training_curve_is_the_same_under_fused_and_foreach_adamw():
+    """guards the whole chain optimizer step -> operand-copy refresh -> next forward: with stale bf16
+    weights (what torch's fused AdamW used to cause) the two curves part after the first step"""
+    from ssl4gie_amd.Models.mae import models_mae
+    curves = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        model = models_mae.MaskedAutoencoderViT(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2,
+                                                decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2,
+                                                mlp_ratio=4).to(DEV).set_precision("bf16")
+        opt = torch.optim.AdamW(model.parameters(), lr=3e-3, betas=(0.9, 0.95), fused=fused)
+        imgs = torch.randn(16, 3, 32, 32, generator=torch.Generator().manual_seed(7)).to(DEV)
+        noise = torch.rand(16, 16, generator=torch.Generator().manual_seed(8)).to(DEV)
+        losses = []
+        for _ in range(12):
+            opt.zero_grad(set_to_none=True)
+            loss, _, _ = model(imgs, mask_ratio=0.5, noise=noise)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        curves.append(losses)
+    a, b = curves
+    assert a[-1] < 0.8 * a[0], a  # it trains
+    assert max(abs(x - y) for x, y in zip(a, b)) < 2e-2 * a[0], (a, b)
