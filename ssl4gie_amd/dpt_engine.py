@@ -120,6 +120,7 @@ class Conv3x3Fn(torch.autograd.Function):
             y, stats = ops.conv3x3_direct_fwd(x, w2 if ld == 9 * Cin else _w_direct(lp, weight, dt), None,
                                               relu_in, colstats=True)
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)  # no zero tensor for the statistics' (absent) gradient
         elif want_stats and b is None and dt == torch.bfloat16 and Cout % 8 == 0 and ld % 64 == 0:
             # the statistics only exist in the 256x256 kernel: taken whatever the tile count
             if implicit:
@@ -129,6 +130,7 @@ class Conv3x3Fn(torch.autograd.Function):
                                           colstats=True)
                 y = y.view(B, Ho, Wo, Cout)
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)  # no zero tensor for the statistics' (absent) gradient
         elif direct:
             # narrow layer (output_conv.2: 128 -> 32): halo-in-LDS kernel instead of a GEMM tile that
             # would be 7/8 padding

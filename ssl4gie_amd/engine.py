@@ -563,6 +563,7 @@ class LinearFn(torch.autograd.Function):
             if bias is None and out_dtype == dtype and ops.colstats_ok(x2.shape[0], w.shape[0], w.shape[1], dtype):
                 y, stats = ops.linear_fwd(x2, w, None, out_dtype=out_dtype, colstats=True)
                 ctx.mark_non_differentiable(stats)
+                ctx.set_materialize_grads(False)  # no zero tensor for the statistics' (absent) gradient
             else:
                 y = ops.linear_fwd(x2, w, bias.detach() if bias is not None else None, out_dtype=out_dtype)
             return y.view(*shp[:-1], w.shape[0]), stats

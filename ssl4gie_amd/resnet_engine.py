@@ -64,6 +64,7 @@ class StemConvFn(torch.autograd.Function):
         if want_stats and ops.colstats_ok(cols.shape[0], Cout, ld, dtype):
             y, stats = ops.linear_fwd(cols, w2, None, out_dtype=dtype, colstats=True)
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)  # no zero tensor for the statistics' (absent) gradient
         else:
             y = ops.linear_fwd(cols, w2, None, out_dtype=dtype)
         y = y.view(B, Ho, Wo, Cout)
