@@ -111,7 +111,11 @@ def test_moco_resnet_step_vs_oracle():
             assert p.grad is None
         else:
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
-    assert int(m.base_encoder.bn1.num_batches_tracked) == 2 and int(m.momentum_encoder.bn1.num_batches_tracked) == 2
+    # the counts live on the host between steps and reach the buffers with state_dict()
+    sd_now = m.state_dict()
+    assert int(sd_now["base_encoder.bn1.num_batches_tracked"]) == 2
+    assert int(sd_now["momentum_encoder.bn1.num_batches_tracked"]) == 2
+    assert int(m.base_encoder.bn1.num_batches_tracked) == 2  # flushed by the state_dict call
 
 
 def test_momentum_encoder_uses_updated_weights_after_ema():

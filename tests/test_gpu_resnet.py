@@ -67,7 +67,7 @@ def test_batchnorm_fwd_bwd_fp32(relu, with_res):
         assert rel_err(nchw(rd.grad.cpu()), rr.grad) < 1e-5
     assert rel_err(bn.running_mean.cpu(), bn_ref.running_mean) < 1e-5
     assert rel_err(bn.running_var.cpu(), bn_ref.running_var) < 1e-5
-    assert int(bn.num_batches_tracked) == 1
+    assert int(bn.state_dict()["num_batches_tracked"]) == 1  # host-side count, written at state_dict()
 
 
 def test_maxpool_avgpool_subsample():
