@@ -139,6 +139,12 @@ def test_lds_swizzles_are_conflict_free():
                    for c0 in range(0, nch, 4) for r0 in (0, 16, 208))
         assert all(sim.tr_b16_cycles(sim.attn_tr_read_addrs(rb, swz, k0, d0, s)) == 2
                    for k0 in (0, 32, 192) for d0 in range(0, nch * 8, 16) for s in (False, True))
+    # direct 3x3 convolution: every tap read of the three tile geometries, the weight reads and the
+    # staged output tile take their ideal cycle counts (confirmed on the GPU: SQ_LDS_BANK_CONFLICT = 0)
+    for geom in ((1, 8, 32), (1, 16, 16), (4, 8, 8)):
+        assert sim.direct_x_read_cycles(*geom) == 4, geom
+    assert sim.direct_w_read_cycles(2) == 4
+    assert sim.direct_out_cycles(1) == (2, 4) and sim.direct_out_cycles(2) == (2, 4)
 
 
 def test_checkpoint_wrappers_round_trip():
@@ -243,3 +249,25 @@ def test_augreg_npz_loader_round_trip(tmp_path, monkeypatch):
     monkeypatch.delenv("SSL4GIE_AUGREG_NPZ")
     with pytest.raises(RuntimeError, match="no network"):
         models.VisionTransformer_from_Any(False, 0, False, None, False, None, 768, 12, 12, "cls", ImageNet_weights=True)
+
+
+def test_position_table_resize_matches_f_interpolate():
+    """Models/models.py `_interp_pos` (two small matmuls with the separable align_corners=True
+    weights) against the reference's formulation (models.py:310-323: F.interpolate, bilinear,
+    align_corners=True) on the CPU, values and the table gradient."""
+    import torch
+    import torch.nn.functional as F
+    from ssl4gie_amd.Models.models import _interp_pos
+    D = 12
+    g0 = torch.Generator().manual_seed(3)
+    for g in (14, 16, 37, 64, 7):
+        pos = torch.randn(1, 197, D, generator=g0, requires_grad=True)
+        ref = F.interpolate(pos[:, 1:, :].transpose(1, 2).reshape(1, D, 14, 14), size=(g, g), mode="bilinear",
+                            align_corners=True).reshape(1, D, g * g).transpose(1, 2)
+        got = _interp_pos(pos, g, D)
+        assert (got - ref).abs().max() < 2e-6
+        w = torch.randn(1, g * g, D, generator=g0)
+        (gr,) = torch.autograd.grad(ref, pos, w, retain_graph=True)
+        (gg,) = torch.autograd.grad(got, pos, w)
+        assert (gr - gg).abs().max() < 2e-5 * max(1.0, float(gr.abs().max()))
+        assert gg[0, 0].abs().max() == 0  # the cls row gets no gradient

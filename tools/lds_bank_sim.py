@@ -81,3 +81,74 @@ if __name__ == "__main__":
     tn = lambda k: ((k & 3) | ((k >> 1) & 4)) << 1
     print("TN 256B rows, tr:", [tr_b16_cycles(tr_read_addrs(256, tn, k0, x0, s))
                                 for k0 in (0, 32) for x0 in (0, 16, 112) for s in (False, True)])
+
+
+# ---- direct 3x3 convolution (csrc/conv_direct.hip): halo reads of the tap loop, weight reads, the
+# staged output tile.  Geometry = (TB, TH, TW) with TB * TH * TW = 256; formulas mirror the kernel.
+def direct_x_swizzle(tw, hy, hx):
+    if tw == 8:
+        return ((hx >> 2) & 1) | ((hy & 1) << 1)
+    return ((hx >> 1) & 3) if tw == 16 else ((hx >> 2) & 3)
+
+
+def direct_x_read_cycles(tb, th, tw):
+    """worst ds_read_b128 cycles (ideal 4) of the forward kernel's halo reads over all waves, taps,
+    operand halves and k-steps"""
+    hh, hw = th + 2, tw + 2
+    worst = 0
+    for wave in range(4):
+        for pb in range(2):
+            for tap in range(9):
+                dy, dx = divmod(tap, 3)
+                for ks in range(2):
+                    addrs = []
+                    for lane in range(64):
+                        p = (2 * wave + pb) * 32 + (lane & 31)
+                        im, r, c = p // (th * tw), (p // tw) % th, p % tw
+                        hy, hx = r + dy, c + dx
+                        lin = (im * hh + hy) * hw + hx
+                        addrs.append(lin * 64 + (((ks * 2 + (lane >> 5)) ^ direct_x_swizzle(tw, hy, hx)) << 4))
+                    worst = max(worst, b128_cycles(addrs))
+    return worst
+
+
+def direct_w_read_cycles(ncb=2):
+    worst = 0
+    for n in range(ncb):
+        for tap in range(9):
+            for ks in range(2):
+                addrs = []
+                for lane in range(64):
+                    row = n * 32 + (lane & 31)
+                    cc = tap * 4 + ks * 2 + (lane >> 5)
+                    addrs.append(row * 576 + ((cc ^ ((row >> 2) & 3)) << 4))
+                worst = max(worst, b128_cycles(addrs))
+    return worst
+
+
+def direct_out_cycles(ncb):
+    """(worst ds_write_b64 cycles, ideal 2; worst ds_read_b128 cycles, ideal 4) of the staged output"""
+    rowb = ncb * 64
+    slots = rowb // 8
+    sm = slots - 1
+    sw = lambda p: (p ^ (p >> 2)) & sm
+    ww = wr = 0
+    for wave in range(4):
+        for pb in range(2):
+            for n in range(ncb):
+                for q in range(4):
+                    addrs = []
+                    for lane in range(64):
+                        p = (2 * wave + pb) * 32 + (lane & 31)
+                        slot = n * 8 + 2 * q + (lane >> 5)
+                        addrs.append(p * rowb + ((slot ^ sw(p)) << 3))
+                    ww = max(ww, b64_cycles(addrs))
+    for i in range(slots // 2):
+        for w in range(4):
+            addrs = []
+            for lane in range(64):
+                idx = w * 64 + lane + i * 256
+                p, j = idx // (slots // 2), idx % (slots // 2)
+                addrs.append(p * rowb + ((j ^ (sw(p) >> 1)) << 4))
+            wr = max(wr, b128_cycles(addrs))
+    return ww, wr
