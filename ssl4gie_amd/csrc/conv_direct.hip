@@ -86,20 +86,24 @@ DEVI int dc_w_off(int row, int cc) { return row * DC_WROW + ((cc ^ ((row >> 2) &
 
 // y[b, oy, ox, co] = sum_{tap, ci} act(x)[b, oy + dy - 1, ox + dx - 1, ci] w2[co, tap * Cin + ci]
 // (+ bias[co]) (masked by relu_mask > 0); colstats [tiles][2][Cout]: per-tile sums / sums of squares
-// of y.  grid = (tiles, ceil(Cout / (32 NCB))).
+// of y.  grid = tiles * ngroups, ngroups = ceil(Cout / (32 NCB)).
 template <int NCB, typename G>
 __global__ __launch_bounds__(DC_THREADS, NCB == 1 ? 3 : 2) void conv3x3_direct_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w2, const float* __restrict__ bias,
     const bf16_t* __restrict__ relu_mask, bf16_t* __restrict__ y, float* __restrict__ colstats, int Bn,
-    int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y) {
+    int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y, int ngroups) {
     constexpr int CPP = DC_CPP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xs = smem;
     char* Ws = smem + G::NH * DC_PS;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TilePos tp = tile_pos(blockIdx.x, tiles_x, tiles_y, G::TB, G::TH, G::TW);
-    const int co0 = blockIdx.y * (32 * NCB);
+    // the cout groups of a tile are neighbours in an XCD's share of the grid (common.h xcd_remap), so
+    // that the halo they all read is fetched into that XCD's L2 once
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_id = lid / ngroups;
+    const TilePos tp = tile_pos(tile_id, tiles_x, tiles_y, G::TB, G::TH, G::TW);
+    const int co0 = (lid % ngroups) * (32 * NCB);
 
     f32x16 acc[2][NCB];
 #pragma unroll
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(DC_THREADS, NCB == 1 ? 3 : 2) void conv3x3_direct_k
                 sum += red[(k * 2) * NC + tid];
                 sq += red[(k * 2 + 1) * NC + tid];
             }
-            float* o = colstats + (size_t)blockIdx.x * 2 * Cout + co0 + tid;
+            float* o = colstats + (size_t)tile_id * 2 * Cout + co0 + tid;
             o[0] = sum;
             o[Cout] = sq;
         }
@@ -298,7 +302,7 @@ DEVI void wgrad_tile(f32x16 (&acc)[5], const char* dbase, const char* const (&xb
 }
 
 // partial[wg][co 32][tap 9][ci 64] fp32, then partial_b[wg][co 32] (written by the workgroups of
-// slice 0 only); wg = blockIdx.x: combo = wg % (nslice * ngroups) = group * nslice + slice picks the
+// slice 0 only); wg = the workgroup's logical id (xcd_remap of blockIdx.x): combo = wg % (nslice * ngroups) = group * nslice + slice picks the
 // 64 input channels and the 32 couts, wg / ncombo the share of the tiles
 template <typename G>
 __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
@@ -311,9 +315,12 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
     char* Ds = smem + G::NH * 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int combo = blockIdx.x % ncombo, slice = combo % nslice, cin0 = slice * 64;
+    // the (slice, group) combinations that walk the same tiles are neighbours in an XCD's share of
+    // the grid: the x halo slice is shared by the cout groups, the dy tile by the channel slices
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int combo = wg % ncombo, slice = combo % nslice, cin0 = slice * 64;
     const int co0 = (combo / nslice) * 32;
-    const int wgs_per_combo = gridDim.x / ncombo, me = blockIdx.x / ncombo;
+    const int wgs_per_combo = gridDim.x / ncombo, me = wg / ncombo;
     const int cb = wave >> 1, tap0 = (wave & 1) * 5, ntap = (wave & 1) ? 4 : 5;  // wgrad_tile<tap0, ntap>
 
     f32x16 acc[5];
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
         else wgrad_tile<G, 0, 5, false>(acc, dbase, xbase);
     }
     // acc[t][j]: row (cout) = 8 (j >> 2) + 4 half + (j & 3), column (ci) = cb * 32 + (lane & 31)
-    float* out = partial + (size_t)blockIdx.x * (32 * 9 * 64);
+    float* out = partial + (size_t)wg * (32 * 9 * 64);
     const int half = lane >> 5, ci = cb * 32 + (lane & 31);
 #pragma unroll
     for (int t = 0; t < 5; ++t)
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
             }
     if (wave == 1 && slice == 0 && (lane & 31) == 0)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) partial_b[blockIdx.x * 32 + 8 * (j >> 2) + 4 * half + (j & 3)] = acc[4][j];
+        for (int j = 0; j < 16; ++j) partial_b[wg * 32 + 8 * (j >> 2) + 4 * half + (j & 3)] = acc[4][j];
 }
 
 // dW2[co, tap * Cin + ci] (+)= sum over the workgroups of (co's group, ci's slice), in workgroup
@@ -460,10 +467,11 @@ static int launch_direct(const Geom& g, const void* x, const void* w2, const flo
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    const dim3 grid((unsigned)g.tiles, (unsigned)((Cout + 32 * NCB - 1) / (32 * NCB)));
-    hipLaunchKernelGGL(k, grid, dim3(DC_THREADS), lds, st, (const bf16_t*)x, (const bf16_t*)w2, bias,
-                       (const bf16_t*)relu_mask, (bf16_t*)y, colstats, B, H, W, Cin, Cout, relu_in,
-                       g.tiles_x, g.tiles_y);
+    const int ngroups = (Cout + 32 * NCB - 1) / (32 * NCB);
+    REQUIRE((long long)g.tiles * ngroups < (1LL << 31));
+    hipLaunchKernelGGL(k, dim3((unsigned)(g.tiles * ngroups)), dim3(DC_THREADS), lds, st, (const bf16_t*)x,
+                       (const bf16_t*)w2, bias, (const bf16_t*)relu_mask, (bf16_t*)y, colstats, B, H, W, Cin,
+                       Cout, relu_in, g.tiles_x, g.tiles_y, ngroups);
     LAUNCH_CHECK();
     return 0;
 }
