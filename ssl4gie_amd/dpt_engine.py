@@ -143,6 +143,8 @@ class Conv3x3Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *unused):
+        if dy is None:  # the map itself was not used downstream (gradients are not materialised)
+            return (None,) * 8
         x, weight, bias = ctx.saved_tensors
         stride, relu_in, sink, lp, ld = ctx.cfg
         B, H, W, Cin = x.shape

@@ -572,6 +572,8 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *unused):
+        if dy is None:  # the map itself was not used downstream (gradients are not materialised)
+            return (None,) * 9
         x2, weight, bias = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
         if dy2.dtype != ctx.dtype:  # fp32 output (decoder_pred): operand copy for the GEMMs

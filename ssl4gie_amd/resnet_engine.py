@@ -72,6 +72,8 @@ class StemConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *unused):
+        if dy is None:  # the map itself was not used downstream (gradients are not materialised)
+            return (None,) * 6
         imgs, weight = ctx.saved_tensors
         dtype, sink = ctx.cfg
         Cout = weight.shape[0]
