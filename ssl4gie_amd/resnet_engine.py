@@ -22,7 +22,7 @@ class _StemCols:
     """The stem patch matrices of the last two image batches (1.2 GB each at 256 x 224 x 224 — small
     change against 288 GB of HBM).  MoCo feeds the same two views to the base and the momentum
     encoder (moco/builder.py:127-135) and the weight gradient needs the matrix again: one im2col
-    per view and step instead of three.  Entries are tied to the image tensor OBJECT (weak
+    per view and step instead of three (the entry is dropped once its weight gradient is taken).  Entries are tied to the image tensor OBJECT (weak
     reference + version counter), never to its address, so a recycled allocation cannot hit."""
 
     def __init__(self, keep=2):
@@ -37,6 +37,12 @@ class _StemCols:
         self.items.append((weakref.ref(imgs), imgs._version, dtype, val))
         del self.items[:-self.keep]
         return val
+
+    def drop(self, imgs):
+        """forget this batch's matrix: its weight gradient has been taken, the training step that
+        produced it is over — a later forward on the SAME tensor object (a benchmark loop on a fixed
+        synthetic batch) must pay for its own im2col, as a step on fresh images does"""
+        self.items = [it for it in self.items if it[0]() is not imgs]
 
     def clear(self):
         self.items.clear()
@@ -82,6 +88,7 @@ class StemConvFn(torch.autograd.Function):
             cols, _, _ = STEM_COLS.get(imgs, dtype)  # cached for the last two batches, else recomputed
             dw2 = ops.linear_bwd_weight(dy.contiguous().view(-1, Cout), cols)
             _write_grad(tw, dw2[:, :147].view(Cout, 7, 7, 3).permute(0, 3, 1, 2), acc)
+        STEM_COLS.drop(imgs)
         return None, rets[0], None, None, None, None
 
 
