@@ -344,6 +344,25 @@ size_t ssl4gie_conv3x3_direct_wgrad_workspace_bytes(int B, int H, int W, int Cin
 int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float* dw2, float* dbias,
                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin,
                                  int Cout, int relu_in, int accumulate, void* stream);
+/* torchvision ResNet.conv1 = nn.Conv2d(3, 64, 7, stride 2, pad 3, bias=False) (reference
+ * Models/models.py:63-69) WITHOUT a patch matrix (ssl4gie_stem_im2col7x7 + GEMM remain for fp32).
+ *   pack:  img fp32 [B,3,H,W] -> packed bf16 [B, 2 Ho + 6, 2 Wo + 6, 4] (three channels + a zero,
+ *          three pixels / rows of zero padding in front), Ho = (H-1)/2 + 1, Wo likewise; once per
+ *          batch, shared by every forward on it and by the weight gradient.
+ *   fwd:   y [B,Ho,Wo,64] bf16 = conv(packed, w2s), w2s bf16 [64][8][8][4] = weight[co][c][ky][kx]
+ *          at [co][ky][kx][c], zero where ky = 7, kx = 7 or c = 3.  colstats (optional): fp32
+ *          [ssl4gie_stem7x7_tiles(B,H,W)][2][64] per-tile BatchNorm partial statistics of y.
+ *   wgrad: dw2s fp32 [64][7][8][4] (+)= sum over output pixels of dy [B,Ho,Wo,64] x patch; the
+ *          kx = 7 and c = 3 entries are arithmetic by-products, not gradients (their weights do
+ *          not exist).  Deterministic: per-workgroup partials + fixed-order reduction. */
+size_t ssl4gie_stem7x7_packed_bytes(int B, int H, int W);
+int ssl4gie_stem7x7_pack(const float* img, void* packed, int B, int H, int W, void* stream);
+int ssl4gie_stem7x7_tiles(int B, int H, int W);
+int ssl4gie_stem7x7_fwd(const void* packed, const void* w2s, void* y, float* colstats, int B, int H,
+                        int W, void* stream);
+size_t ssl4gie_stem7x7_wgrad_workspace_bytes(int B, int H, int W);
+int ssl4gie_stem7x7_wgrad(const void* dy, const void* packed, float* dw2s, void* workspace,
+                          size_t workspace_bytes, int B, int H, int W, int accumulate, void* stream);
 /* F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) (:293-295, Interpolate :69-104)
  * x [B,H,W,C] -> y [B,2H,2W,C]; backward in gather form (no atomics) */
 int ssl4gie_bilinear2x_fwd(const void* x, void* y, int dtype, int B, int H, int W, int C,

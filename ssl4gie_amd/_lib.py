@@ -98,6 +98,12 @@ PROTOTYPES = {
     "ssl4gie_conv3x3_direct_wgrad_ok": (i32, [i32, i32, i32, i32, i32]),
     "ssl4gie_conv3x3_direct_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "ssl4gie_conv3x3_direct_wgrad": (i32, [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_stem7x7_packed_bytes": (sz, [i32, i32, i32]),
+    "ssl4gie_stem7x7_pack": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ssl4gie_stem7x7_tiles": (i32, [i32, i32, i32]),
+    "ssl4gie_stem7x7_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ssl4gie_stem7x7_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
+    "ssl4gie_stem7x7_wgrad": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
     "ssl4gie_bilinear2x_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_bilinear2x_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_pixel_shuffle": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -84,6 +84,95 @@ template <typename G> DEVI int dc_x_off(int lin, int hy, int hx, int c) {
 }
 DEVI int dc_w_off(int row, int cc) { return row * DC_WROW + ((cc ^ ((row >> 2) & 3)) << 4); }
 
+// ---- epilogue of the forward kernels (contains workgroup barriers: call uniformly) -------------
+template <int NCB, typename G>
+DEVI void dc_epilogue(f32x16 (&acc)[2][NCB], char* smem, const TilePos tp, const int co0, const int tile_id,
+                      const float* __restrict__ bias, const bf16_t* __restrict__ relu_mask,
+                      bf16_t* __restrict__ y, float* __restrict__ colstats, const int Bn, const int H,
+                      const int W, const int Cout) {
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int p_im[2], p_r[2], p_c[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const int p = (2 * wave + pb) * 32 + l31;
+        p_im[pb] = G::img(p); p_r[pb] = G::row(p); p_c[pb] = G::col(p);
+    }
+    // ---- epilogue.  Accumulator j of a lane = cout 8 (j >> 2) + 4 half + (j & 3) of pixel l31: 8-byte
+    // pieces 64-128 B apart.  The finished bf16 tile goes through LDS ([256 pixels][32 NCB couts],
+    // 8-byte slots XOR-ed with (p ^ p >> 2): conflict-free writes and reads) and leaves as whole 16-byte
+    // chunks of consecutive pixels; the ReLU mask is read the same way.  Pixels outside the map are
+    // staged as zeros, so the BatchNorm statistics below need no mask.
+    constexpr int NC = 32 * NCB, ROWB = NC * 2, SLOTS = ROWB / 8, SM = SLOTS - 1;
+    __syncthreads();  // every wave is done with the operand images
+    char* Os = smem;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const int p = (2 * wave + pb) * 32 + l31;
+        const bool valid = tp.b0 + p_im[pb] < Bn && tp.ty0 + p_r[pb] < H && tp.tx0 + p_c[pb] < W;
+#pragma unroll
+        for (int n = 0; n < NCB; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int slot = n * 8 + 2 * q + half, co = co0 + slot * 4;
+                f32x4 v = {acc[pb][n][4 * q], acc[pb][n][4 * q + 1], acc[pb][n][4 * q + 2],
+                           acc[pb][n][4 * q + 3]};
+                if (bias && co < Cout) v += ld4(bias + co);
+                if (!valid || co >= Cout) v = f32x4{0, 0, 0, 0};
+                st4((bf16_t*)(Os + p * ROWB + ((slot ^ ((p ^ (p >> 2)) & SM)) << 3)), v);
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SLOTS / 2; ++i) {
+        const int idx = tid + i * DC_THREADS, p = idx / (SLOTS / 2), j = idx % (SLOTS / 2);
+        const int sw = (p ^ (p >> 2)) & SM;
+        u32x4 v = *(const u32x4*)(Os + p * ROWB + ((j ^ (sw >> 1)) << 4));
+        if (sw & 1) v = u32x4{v[2], v[3], v[0], v[1]};  // the two slots of the chunk sit swapped
+        const int gb = tp.b0 + G::img(p), gy = tp.ty0 + G::row(p), gx = tp.tx0 + G::col(p), co = co0 + 8 * j;
+        if (gb < Bn && gy < H && gx < W && co < Cout) {
+            const size_t o = (((size_t)gb * H + gy) * W + gx) * Cout + co;
+            if (relu_mask) {  // keep where mask > 0: sign bit clear and not zero
+                const u32x4 m = *(const u32x4*)(relu_mask + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned lo = ((m[k] & 0x8000u) == 0 && (m[k] & 0x7fffu) != 0) ? 0xffffu : 0u;
+                    const unsigned hi = ((m[k] & 0x80000000u) == 0 && (m[k] & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                    v[k] &= lo | hi;
+                }
+            }
+            *(u32x4*)(y + o) = v;
+        }
+    }
+    if (colstats) {
+        // per-tile column sums and sums of squares of the STORED values (ssl4gie_gemm_desc.colstats
+        // semantics with one partial per tile): thread = (cout c, one of 256 / NC pixel groups)
+        constexpr int NG = DC_THREADS / NC, PPG = DC_PIX / NG;
+        float* red = (float*)(smem + DC_PIX * ROWB);  // [NG][2][NC]
+        const int c = tid % NC, g = tid / NC;
+        float sum = 0.f, sq = 0.f;
+        for (int p = g * PPG; p < (g + 1) * PPG; ++p) {
+            const float v = bf2f(*(const bf16_t*)(Os + p * ROWB + (((c >> 2) ^ ((p ^ (p >> 2)) & SM)) << 3) + ((c & 3) << 1)));
+            sum += v;
+            sq += v * v;
+        }
+        red[(g * 2) * NC + c] = sum;
+        red[(g * 2 + 1) * NC + c] = sq;
+        __syncthreads();
+        if (tid < NC && co0 + tid < Cout) {
+            sum = 0.f, sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                sum += red[(k * 2) * NC + tid];
+                sq += red[(k * 2 + 1) * NC + tid];
+            }
+            float* o = colstats + (size_t)tile_id * 2 * Cout + co0 + tid;
+            o[0] = sum;
+            o[Cout] = sq;
+        }
+    }
+}
+
 // y[b, oy, ox, co] = sum_{tap, ci} act(x)[b, oy + dy - 1, ox + dx - 1, ci] w2[co, tap * Cin + ci]
 // (+ bias[co]) (masked by relu_mask > 0); colstats [tiles][2][Cout]: per-tile sums / sums of squares
 // of y.  grid = tiles * ngroups, ngroups = ceil(Cout / (32 NCB)).
@@ -178,79 +267,7 @@ __global__ __launch_bounds__(DC_THREADS, NCB == 1 ? 3 : 2) void conv3x3_direct_k
             }
         }
     }
-    // ---- epilogue.  Accumulator j of a lane = cout 8 (j >> 2) + 4 half + (j & 3) of pixel l31: 8-byte
-    // pieces 64-128 B apart.  The finished bf16 tile goes through LDS ([256 pixels][32 NCB couts],
-    // 8-byte slots XOR-ed with (p ^ p >> 2): conflict-free writes and reads) and leaves as whole 16-byte
-    // chunks of consecutive pixels; the ReLU mask is read the same way.  Pixels outside the map are
-    // staged as zeros, so the BatchNorm statistics below need no mask.
-    constexpr int NC = 32 * NCB, ROWB = NC * 2, SLOTS = ROWB / 8, SM = SLOTS - 1;
-    __syncthreads();  // every wave is done with the operand images
-    char* Os = smem;
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-        const int p = (2 * wave + pb) * 32 + l31;
-        const bool valid = tp.b0 + p_im[pb] < Bn && tp.ty0 + p_r[pb] < H && tp.tx0 + p_c[pb] < W;
-#pragma unroll
-        for (int n = 0; n < NCB; ++n)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int slot = n * 8 + 2 * q + half, co = co0 + slot * 4;
-                f32x4 v = {acc[pb][n][4 * q], acc[pb][n][4 * q + 1], acc[pb][n][4 * q + 2],
-                           acc[pb][n][4 * q + 3]};
-                if (bias && co < Cout) v += ld4(bias + co);
-                if (!valid || co >= Cout) v = f32x4{0, 0, 0, 0};
-                st4((bf16_t*)(Os + p * ROWB + ((slot ^ ((p ^ (p >> 2)) & SM)) << 3)), v);
-            }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < SLOTS / 2; ++i) {
-        const int idx = tid + i * DC_THREADS, p = idx / (SLOTS / 2), j = idx % (SLOTS / 2);
-        const int sw = (p ^ (p >> 2)) & SM;
-        u32x4 v = *(const u32x4*)(Os + p * ROWB + ((j ^ (sw >> 1)) << 4));
-        if (sw & 1) v = u32x4{v[2], v[3], v[0], v[1]};  // the two slots of the chunk sit swapped
-        const int gb = tp.b0 + G::img(p), gy = tp.ty0 + G::row(p), gx = tp.tx0 + G::col(p), co = co0 + 8 * j;
-        if (gb < Bn && gy < H && gx < W && co < Cout) {
-            const size_t o = (((size_t)gb * H + gy) * W + gx) * Cout + co;
-            if (relu_mask) {  // keep where mask > 0: sign bit clear and not zero
-                const u32x4 m = *(const u32x4*)(relu_mask + o);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned lo = ((m[k] & 0x8000u) == 0 && (m[k] & 0x7fffu) != 0) ? 0xffffu : 0u;
-                    const unsigned hi = ((m[k] & 0x80000000u) == 0 && (m[k] & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
-                    v[k] &= lo | hi;
-                }
-            }
-            *(u32x4*)(y + o) = v;
-        }
-    }
-    if (colstats) {
-        // per-tile column sums and sums of squares of the STORED values (ssl4gie_gemm_desc.colstats
-        // semantics with one partial per tile): thread = (cout c, one of 256 / NC pixel groups)
-        constexpr int NG = DC_THREADS / NC, PPG = DC_PIX / NG;
-        float* red = (float*)(smem + DC_PIX * ROWB);  // [NG][2][NC]
-        const int c = tid % NC, g = tid / NC;
-        float sum = 0.f, sq = 0.f;
-        for (int p = g * PPG; p < (g + 1) * PPG; ++p) {
-            const float v = bf2f(*(const bf16_t*)(Os + p * ROWB + (((c >> 2) ^ ((p ^ (p >> 2)) & SM)) << 3) + ((c & 3) << 1)));
-            sum += v;
-            sq += v * v;
-        }
-        red[(g * 2) * NC + c] = sum;
-        red[(g * 2 + 1) * NC + c] = sq;
-        __syncthreads();
-        if (tid < NC && co0 + tid < Cout) {
-            sum = 0.f, sq = 0.f;
-#pragma unroll
-            for (int k = 0; k < NG; ++k) {
-                sum += red[(k * 2) * NC + tid];
-                sq += red[(k * 2 + 1) * NC + tid];
-            }
-            float* o = colstats + (size_t)tile_id * 2 * Cout + co0 + tid;
-            o[0] = sum;
-            o[Cout] = sq;
-        }
-    }
+    dc_epilogue<NCB, G>(acc, smem, tp, co0, tile_id, bias, relu_mask, y, colstats, Bn, H, W, Cout);
 }
 
 // ------------------------------------------------------------------ weight gradient
@@ -421,6 +438,176 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial,
     *o = accumulate ? *o + s : s;
 }
 
+// ------------------------------------------------------------------ 7x7 stride-2 stem
+// torchvision ResNet.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False) (reference Models/models.py:63-69)
+// without a patch matrix.  The fp32 NCHW image is packed ONCE per step into bf16 [B, Hp, Wp, 4]
+// (three channels + a zero, three pixels / rows of zero padding in front, Hp = 2 Ho + 6,
+// Wp = 2 Wo + 6): an output pixel's patch is then 7 image rows x 8 pixels x 4 channels, every MFMA
+// k-chunk (2 pixels) a 16-byte read at a 16-byte-aligned address (the window starts at the even
+// column 2 ox), and 32 consecutive output pixels read 512 contiguous bytes: no swizzle needed.
+// Weights [64][8][8][4] bf16 (row 7, pixel 7, channel 3 zero).  Same tiles, MFMA shape and epilogue
+// (incl. the BatchNorm partial statistics) as conv3x3_direct_kernel<2, G>.
+#define ST_WROW 512
+template <typename G> struct StemG {
+    static constexpr int RH = 2 * G::TH + 6, RW = 2 * G::TW + 6, XS_BYTES = RH * RW * 8;
+    static_assert(G::TB == 1, "one image per tile");
+};
+__global__ void stem7x7_pack_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int H, int W,
+                                    int Hp, int Wp, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % Wp), yy = (int)((idx / Wp) % Hp);
+    const long long b = idx / ((long long)Wp * Hp);
+    const int iy = yy - 3, ix = x - 3;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const float* p = img + ((size_t)b * 3 * H + iy) * W + ix;
+        c0 = p[0]; c1 = p[(size_t)H * W]; c2 = p[(size_t)2 * H * W];
+    }
+    u32x2 v;
+    v[0] = pack_bf2(c0, c1);
+    v[1] = pack_bf2(c2, 0.f);
+    *(u32x2*)(out + idx * 4) = v;
+}
+template <typename G>
+DEVI void stem_stage_x(char* Xs, const bf16_t* __restrict__ P, const TilePos tp, int Hp, int Wp, int tid) {
+    using S = StemG<G>;
+    constexpr int NC = S::RH * S::RW / 2, IT = (NC + DC_THREADS - 1) / DC_THREADS;  // 16-byte chunks = 2 pixels
+    u32x4 v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * DC_THREADS, hy = idx / (S::RW / 2), hx = 2 * (idx % (S::RW / 2));
+        const int gy = 2 * tp.ty0 + hy, gx = 2 * tp.tx0 + hx;
+        v[i] = u32x4{0, 0, 0, 0};
+        if (idx < NC && gy < Hp && gx < Wp) v[i] = *(const u32x4*)(P + (((size_t)tp.b0 * Hp + gy) * Wp + gx) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * DC_THREADS;
+        if (idx < NC) *(u32x4*)(Xs + (size_t)idx * 16) = v[i];
+    }
+}
+template <typename G>
+__global__ __launch_bounds__(DC_THREADS, 2) void stem7x7_direct_kernel(
+    const bf16_t* __restrict__ P, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+    float* __restrict__ colstats, int Bn, int Ho, int Wo, int Hp, int Wp, int tiles_x, int tiles_y) {
+    using S = StemG<G>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xs = smem;
+    char* Ws = smem + S::XS_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
+    const TilePos tp = tile_pos(tile_id, tiles_x, tiles_y, 1, G::TH, G::TW);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[pb][n][j] = 0.f;
+    {
+        u32x4 wv[8];  // 64 rows x 32 chunks
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wv[i] = *(const u32x4*)(w + (size_t)(tid + i * DC_THREADS) * 8);
+        stem_stage_x<G>(Xs, P, tp, Hp, Wp, tid);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * DC_THREADS, row = idx >> 5, cc = idx & 31;
+            *(u32x4*)(Ws + row * ST_WROW + ((cc ^ (row & 15)) << 4)) = wv[i];
+        }
+    }
+    __syncthreads();
+    int xo[2];  // this lane's two output pixels: byte offset of their window's first pixel
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const int p = (2 * wave + pb) * 32 + l31;
+        xo[pb] = (2 * G::row(p) * S::RW + 2 * G::col(p) + 2 * half) * 8;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int cc = dy * 4 + ks * 2 + half;
+            bf16x8 a[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                a[n] = *(const bf16x8*)(Ws + (n * 32 + l31) * ST_WROW + ((cc ^ (l31 & 15)) << 4));
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const bf16x8 xf = *(const bf16x8*)(Xs + xo[pb] + (dy * S::RW + 4 * ks) * 8);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[pb][n] = MFMA32(a[n], xf, acc[pb][n]);
+            }
+        }
+    dc_epilogue<2, G>(acc, smem, tp, 0, tile_id, nullptr, nullptr, y, colstats, Bn, Ho, Wo, 64);
+}
+// dW[co][dy][px * 4 + c] = sum over output pixels of dy_out[p][co] P[2 oy + dy][2 ox + px][c]; wave w:
+// cout block w & 1, image rows dy = (w >> 1) + 2 t.  partial[wg][64][7][32] fp32.
+template <typename G>
+__global__ __launch_bounds__(DC_THREADS, 2) void stem7x7_wgrad_kernel(
+    const bf16_t* __restrict__ dyo, const bf16_t* __restrict__ P, float* __restrict__ partial, int Bn,
+    int Ho, int Wo, int Hp, int Wp, int tiles_x, int tiles_y, int ntiles) {
+    using S = StemG<G>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xs = smem;
+    char* Ds = smem + S::XS_BYTES;  // two images [256 pixels][32 couts]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int cbk = wave & 1, dy0 = wave >> 1, nrow = dy0 ? 3 : 4;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    const int li = lane & 15, k0 = 8 * (lane >> 5) + (li >> 2), colb = (((lane >> 4) & 1) * 16 + 4 * (li & 3)) * 2;
+    const char* dbase = Ds + cbk * WG_DY_BYTES + k0 * 64 + colb;
+    const char* xbase = Xs + 2 * k0 * 8 + colb;
+    constexpr int ND = DC_PIX * 8, ID = ND / DC_THREADS;
+    for (int tile = wg; tile < ntiles; tile += gridDim.x) {
+        const TilePos tp = tile_pos(tile, tiles_x, tiles_y, 1, G::TH, G::TW);
+        u32x4 dv[ID];
+#pragma unroll
+        for (int i = 0; i < ID; ++i) {
+            const int idx = tid + i * DC_THREADS, p = idx >> 3, c = idx & 7;
+            const int gy = tp.ty0 + G::row(p), gx = tp.tx0 + G::col(p);
+            dv[i] = u32x4{0, 0, 0, 0};
+            if (gy < Ho && gx < Wo) dv[i] = *(const u32x4*)(dyo + (((size_t)tp.b0 * Ho + gy) * Wo + gx) * 64 + c * 8);
+        }
+        __syncthreads();  // the previous tile has been consumed
+        stem_stage_x<G>(Xs, P, tp, Hp, Wp, tid);
+#pragma unroll
+        for (int i = 0; i < ID; ++i) {
+            const int idx = tid + i * DC_THREADS, p = idx >> 3, c = idx & 7;
+            *(u32x4*)(Ds + (c >> 2) * WG_DY_BYTES + p * 64 + ((c & 3) << 4)) = dv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < DC_PIX / 16; ++u) {
+            const int p0 = u * 16, r = G::row(p0), c0 = G::col(p0);
+            const bf16x8 a = tr_operand32(dbase + p0 * 64, 64);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < nrow) {
+                    const int dyy = dy0 + 2 * t;  // wave-uniform
+                    const bf16x8 xf = tr_operand32(xbase + ((2 * r + dyy) * S::RW + 2 * c0) * 8, 16);
+                    acc[t] = MFMA32(a, xf, acc[t]);
+                }
+        }
+    }
+    float* out = partial + (size_t)wg * (64 * 7 * 32);
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (t < nrow)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int co = cbk * 32 + 8 * (j >> 2) + 4 * half + (j & 3);
+                out[(co * 7 + dy0 + 2 * t) * 32 + col] = acc[t][j];
+            }
+}
+
 // ------------------------------------------------------------------ C ABI
 typedef TileG<1, 8, 32> G32;
 typedef TileG<1, 16, 16> G16;
@@ -561,4 +748,94 @@ extern "C" int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float
                        accumulate);
     LAUNCH_CHECK();
     return 0;
+}
+
+// ---- stem
+static Geom stem_geom(int B, int Ho, int Wo) {
+    Geom g = pick_geom(B, Ho, Wo);
+    if (g.id == 2) {  // the four-image geometry does not exist for the stem: 16 x 16 instead
+        g = Geom{1, 1, 16, 16, (Wo + 15) / 16, (Ho + 15) / 16, 0};
+        g.tiles = g.tiles_x * g.tiles_y * B;
+    }
+    return g;
+}
+static bool stem_ok(int B, int H, int W) {
+    return B > 0 && H >= 7 && W >= 7 && (long long)B * H * W < (1LL << 31);
+}
+extern "C" size_t ssl4gie_stem7x7_packed_bytes(int B, int H, int W) {
+    if (!stem_ok(B, H, W)) return 0;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    return (size_t)B * (2 * Ho + 6) * (2 * Wo + 6) * 4 * sizeof(bf16_t);
+}
+extern "C" int ssl4gie_stem7x7_pack(const float* img, void* packed, int B, int H, int W, void* stream) {
+    REQUIRE(img && packed && stem_ok(B, H, W));
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Hp = 2 * Ho + 6, Wp = 2 * Wo + 6;
+    const long long total = (long long)B * Hp * Wp;
+    hipLaunchKernelGGL(stem7x7_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, img, (bf16_t*)packed, H, W, Hp, Wp, total);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ssl4gie_stem7x7_tiles(int B, int H, int W) {
+    if (!stem_ok(B, H, W)) return 0;
+    return stem_geom(B, (H - 1) / 2 + 1, (W - 1) / 2 + 1).tiles;
+}
+template <typename G>
+static int launch_stem_fwd(const Geom& g, const void* packed, const void* w, void* y, float* colstats, int B,
+                           int Ho, int Wo, hipStream_t st) {
+    auto k = stem7x7_direct_kernel<G>;
+    int lds = StemG<G>::XS_BYTES + 64 * ST_WROW;
+    const int lds_out = DC_PIX * 128 + 2 * DC_THREADS * (int)sizeof(float);
+    if (lds < lds_out) lds = lds_out;
+    hipLaunchKernelGGL(k, dim3((unsigned)g.tiles), dim3(DC_THREADS), lds, st, (const bf16_t*)packed,
+                       (const bf16_t*)w, (bf16_t*)y, colstats, B, Ho, Wo, 2 * Ho + 6, 2 * Wo + 6, g.tiles_x,
+                       g.tiles_y);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ssl4gie_stem7x7_fwd(const void* packed, const void* w2s, void* y, float* colstats, int B,
+                                   int H, int W, void* stream) {
+    REQUIRE(packed && w2s && y && stem_ok(B, H, W));
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const Geom g = stem_geom(B, Ho, Wo);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_GEMM_NT, 2.0 * B * Ho * (double)Wo * 64 * 147, st);
+    if (g.id == 0) return launch_stem_fwd<G32>(g, packed, w2s, y, colstats, B, Ho, Wo, st);
+    return launch_stem_fwd<G16>(g, packed, w2s, y, colstats, B, Ho, Wo, st);
+}
+static int stem_wgrad_grid(const Geom& g) {
+    int n = 2 * ssl4gie_internal_compute_cus();
+    return n < g.tiles ? n : g.tiles;
+}
+extern "C" size_t ssl4gie_stem7x7_wgrad_workspace_bytes(int B, int H, int W) {
+    if (!stem_ok(B, H, W)) return 0;
+    return (size_t)stem_wgrad_grid(stem_geom(B, (H - 1) / 2 + 1, (W - 1) / 2 + 1)) * 64 * 7 * 32 * sizeof(float);
+}
+template <typename G>
+static int launch_stem_wgrad(const Geom& g, int grid, const void* dy, const void* packed, float* part, int B,
+                             int Ho, int Wo, hipStream_t st) {
+    auto k = stem7x7_wgrad_kernel<G>;
+    const int lds = StemG<G>::XS_BYTES + 2 * WG_DY_BYTES;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DC_THREADS), lds, st, (const bf16_t*)dy, (const bf16_t*)packed, part,
+                       B, Ho, Wo, 2 * Ho + 6, 2 * Wo + 6, g.tiles_x, g.tiles_y, g.tiles);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ssl4gie_stem7x7_wgrad(const void* dy, const void* packed, float* dw2s, void* workspace,
+                                     size_t workspace_bytes, int B, int H, int W, int accumulate,
+                                     void* stream) {
+    REQUIRE(dy && packed && dw2s && workspace && stem_ok(B, H, W));
+    REQUIRE(workspace_bytes >= ssl4gie_stem7x7_wgrad_workspace_bytes(B, H, W));
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const Geom g = stem_geom(B, Ho, Wo);
+    const int grid = stem_wgrad_grid(g);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        ProfScope prof(PROF_GEMM_TN, 2.0 * B * Ho * (double)Wo * 64 * 147, st);
+        int rc = g.id == 0 ? launch_stem_wgrad<G32>(g, grid, dy, packed, (float*)workspace, B, Ho, Wo, st)
+                           : launch_stem_wgrad<G16>(g, grid, dy, packed, (float*)workspace, B, Ho, Wo, st);
+        if (rc) return rc;
+    }
+    return ssl4gie_internal_reduce_partials((const float*)workspace, dw2s, grid, 64 * 7 * 32, (size_t)64 * 7 * 32,
+                                            accumulate, st);
 }

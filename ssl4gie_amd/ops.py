@@ -665,6 +665,53 @@ def conv3x3_direct_wgrad(dy, x, relu=False, bias_out=None):
     return out
 
 
+def stem7x7_pack(imgs):
+    """fp32 NCHW [B,3,H,W] -> the padded 4-channel bf16 image the direct stem kernels read"""
+    _dev(imgs)
+    _f32(imgs)
+    B, Cc, H, W = imgs.shape
+    assert Cc == 3 and imgs.is_contiguous()
+    L = _lib.load()
+    nb = L.ssl4gie_stem7x7_packed_bytes(B, H, W)
+    assert nb > 0, "stem7x7: unsupported image size"
+    out = torch.empty(nb // 2, dtype=torch.bfloat16, device=imgs.device)
+    _lib.check(L.ssl4gie_stem7x7_pack(ptr(imgs), ptr(out), B, H, W, stream()), "stem7x7_pack")
+    return out
+
+
+def stem7x7_weight(weight):
+    """[64, 3, 7, 7] fp32 -> [64, 256] in the kernels' layout [co][ky (8)][kx (8)][c (4)], zeros in the padding"""
+    w = torch.zeros(weight.shape[0], 8, 8, 4, dtype=weight.dtype, device=weight.device)
+    w[:, :7, :7, :3] = weight.permute(0, 2, 3, 1)
+    return w.reshape(weight.shape[0], 256)
+
+
+def stem7x7_fwd(packed, w2s, B, H, W, colstats=False):
+    """y [B,Ho,Wo,64] bf16 (+ BatchNorm partial statistics [tiles, 2, 64])"""
+    _dev(packed, w2s)
+    assert w2s.shape == (64, 256) and w2s.dtype == torch.bfloat16 and w2s.is_contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    L = _lib.load()
+    y = torch.empty(B, Ho, Wo, 64, dtype=torch.bfloat16, device=packed.device)
+    stats = torch.empty(L.ssl4gie_stem7x7_tiles(B, H, W), 2, 64, dtype=torch.float32, device=packed.device) \
+        if colstats else None
+    _lib.check(L.ssl4gie_stem7x7_fwd(ptr(packed), ptr(w2s), ptr(y), ptr(stats), B, H, W, stream()), "stem7x7_fwd")
+    return (y, stats) if colstats else y
+
+
+def stem7x7_wgrad(dy, packed, B, H, W):
+    """weight gradient [64, 3, 7, 7] fp32 of the stem from dy [B,Ho,Wo,64] bf16 and the packed image"""
+    _dev(dy, packed)
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and dy.shape[-1] == 64
+    L = _lib.load()
+    nb = L.ssl4gie_stem7x7_wgrad_workspace_bytes(B, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+    out = torch.empty(64, 7, 8, 4, dtype=torch.float32, device=dy.device)
+    _lib.check(L.ssl4gie_stem7x7_wgrad(ptr(dy), ptr(packed), ptr(out), ptr(ws), nb, B, H, W, 0, stream()),
+               "stem7x7_wgrad")
+    return out[:, :, :7, :3].permute(0, 3, 1, 2)  # [co, c, ky, kx]
+
+
 def col2im3x3(dcols, B, H, W, C, stride):
     _dev(dcols)
     dx = torch.empty(B, H, W, C, dtype=dcols.dtype, device=dcols.device)

@@ -19,7 +19,7 @@ from .engine import GradSink, LPCache
 
 
 class _StemCols:
-    """The stem patch matrices of the last two image batches (1.2 GB each at 256 x 224 x 224 — small
+    """The stem operands (bf16: the packed image, 0.1 GB; fp32: the patch matrix) of the last two image batches (1.2 GB each at 256 x 224 x 224 — small
     change against 288 GB of HBM).  MoCo feeds the same two views to the base and the momentum
     encoder (moco/builder.py:127-135) and the weight gradient needs the matrix again: one im2col
     per view and step instead of three (the entry is dropped once its weight gradient is taken).  Entries are tied to the image tensor OBJECT (weak
@@ -28,13 +28,16 @@ class _StemCols:
     def __init__(self, keep=2):
         self.keep, self.items = keep, []
 
-    def get(self, imgs, dtype):
+    def get(self, imgs, dtype, make=None):
+        """`make` (default: the patch matrix) builds the cached value; entries are keyed on it too"""
+        make = make or ops.stem_im2col7x7
+        key = (dtype, getattr(make, "__name__", "make"))
         for i, (ref, ver, dt, val) in enumerate(self.items):
-            if ref() is imgs and ver == imgs._version and dt == dtype:
+            if ref() is imgs and ver == imgs._version and dt == key:
                 self.items.append(self.items.pop(i))
                 return val
-        val = ops.stem_im2col7x7(imgs, dtype)
-        self.items.append((weakref.ref(imgs), imgs._version, dtype, val))
+        val = make(imgs, dtype) if make is ops.stem_im2col7x7 else make(imgs)
+        self.items.append((weakref.ref(imgs), imgs._version, key, val))
         del self.items[:-self.keep]
         return val
 
@@ -49,6 +52,8 @@ class _StemCols:
 
 
 STEM_COLS = _StemCols()
+# SSL4GIE_STEM_DIRECT=0: the bf16 stem through the patch matrix again (A/B)
+_STEM_DIRECT = __import__("os").environ.get("SSL4GIE_STEM_DIRECT", "1") != "0"
 
 
 class StemConvFn(torch.autograd.Function):
@@ -59,9 +64,25 @@ class StemConvFn(torch.autograd.Function):
         """want_stats: also return the BatchNorm partial statistics of the map (or None)"""
         imgs = imgs.contiguous().float()
         B = imgs.shape[0]
+        Cout = weight.shape[0]
+        if _STEM_DIRECT and dtype == torch.bfloat16 and Cout == 64 and imgs.shape[1] == 3:
+            # bf16: no patch matrix — the image is packed once per batch (bf16, 4 channels, padded) and
+            # read by the direct stem kernels (csrc/conv_direct.hip): 43 + 179 us instead of 740 + 454
+            H, W = imgs.shape[2:]
+            packed = STEM_COLS.get(imgs, dtype, ops.stem7x7_pack)
+            w2s = _derived(lp, weight, "stem7", dtype, ops.stem7x7_weight)
+            ctx.save_for_backward(imgs, weight)
+            ctx.cfg = (dtype, sink)
+            ctx.direct = True
+            if want_stats:
+                y, stats = ops.stem7x7_fwd(packed, w2s, B, H, W, colstats=True)
+                ctx.mark_non_differentiable(stats)
+                ctx.set_materialize_grads(False)
+                return y, stats
+            return ops.stem7x7_fwd(packed, w2s, B, H, W)
+        ctx.direct = False
         cols, Ho, Wo = STEM_COLS.get(imgs, dtype)
         ld = cols.shape[1]
-        Cout = weight.shape[0]
         w2 = _derived(lp, weight, f"stem:{ld}", dtype,
                       lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 147), ld))
         ctx.save_for_backward(imgs, weight)
@@ -84,7 +105,11 @@ class StemConvFn(torch.autograd.Function):
         dtype, sink = ctx.cfg
         Cout = weight.shape[0]
         (tw,), acc, rets = sink.plan([weight])
-        if tw is not None:
+        if tw is not None and ctx.direct:
+            B, _, H, W = imgs.shape
+            packed = STEM_COLS.get(imgs, dtype, ops.stem7x7_pack)  # cached for the last two batches
+            _write_grad(tw, ops.stem7x7_wgrad(dy.contiguous(), packed, B, H, W), acc)
+        elif tw is not None:
             cols, _, _ = STEM_COLS.get(imgs, dtype)  # cached for the last two batches, else recomputed
             dw2 = ops.linear_bwd_weight(dy.contiguous().view(-1, Cout), cols)
             _write_grad(tw, dw2[:, :147].view(Cout, 7, 7, 3).permute(0, 3, 1, 2), acc)

@@ -164,3 +164,27 @@ def test_direct_conv_matches_the_gathered_gemm_at_the_production_head_shape():
                                             out_dtype=BF).view(B, H, W, Ci))
     assert ((dx.float() - dx_ref.float()).norm() / dx_ref.float().norm()) < 3e-3
     assert torch.equal(dx == 0, dx_ref == 0) or ((dx == 0) != (dx_ref == 0)).float().mean() < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 64), (3, 37, 45), (1, 7, 9), (2, 224, 224), (5, 33, 32)])
+def test_direct_stem_forward_and_weight_gradient_exact(B, H, W):
+    """7x7 stride-2 pad-3 stem (torchvision conv1) on the direct kernels: packed image, forward with
+    BatchNorm partial statistics, weight gradient — integers, exact against torch fp64"""
+    from ssl4gie_amd import _lib, ops
+    x = ints((B, 3, H, W), 61)
+    w = ints((64, 3, 7, 7), 62, -1, 2)
+    ref = F.conv2d(x, w, None, stride=2, padding=3).permute(0, 2, 3, 1).contiguous()
+    Ho, Wo = ref.shape[1:3]
+    assert ref.abs().max() < 256
+    packed = ops.stem7x7_pack(x.float().to(DEV))
+    w2s = ops.stem7x7_weight(w.float().to(DEV)).to(BF)
+    y, stats = ops.stem7x7_fwd(packed, w2s, B, H, W, colstats=True)
+    assert y.shape == (B, Ho, Wo, 64)
+    assert torch.equal(y.double().cpu(), ref)
+    tot = stats.double().sum(0).cpu()
+    assert torch.equal(tot[0], ref.sum((0, 1, 2))) and torch.equal(tot[1], (ref * ref).sum((0, 1, 2)))
+    dy = ints((B, Ho, Wo, 64), 63, -1, 2)
+    refw = torch.nn.grad.conv2d_weight(x, (64, 3, 7, 7), dy.permute(0, 3, 1, 2), stride=2, padding=3)
+    dw = ops.stem7x7_wgrad(dy.to(DEV, BF), packed, B, H, W)
+    assert refw.abs().max() < 2 ** 24
+    assert torch.equal(dw.double().cpu(), refw)
