@@ -209,8 +209,17 @@ class ConvTransposeFn(torch.autograd.Function):
     def forward(ctx, x2, weight, bias, B, H, W, sink: GradSink, lp: LPCache):
         Cin, Cout, k, _ = weight.shape
         dt = x2.dtype
-        w2 = _derived(lp, weight, "ct", dt, lambda w: w.permute(2, 3, 1, 0).reshape(k * k * Cout, Cin))
-        g = ops.linear_fwd(x2, w2, None, out_dtype=dt)
+        ld = ops.k_pad(Cin, dt)
+        if ld != Cin:
+            # Cin = 96 (act_postprocess1) is not a whole number of the bf16 GEMM's 64-deep K-tiles: with
+            # zero-padded operand copies (6 MB) the product runs on the MFMA bf16 kernel instead of the
+            # generic fp32 one (164 -> ~20 us)
+            w2 = _derived(lp, weight, f"ct:{ld}", dt,
+                          lambda w: _pad_cols(w.permute(2, 3, 1, 0).reshape(k * k * Cout, Cin), ld))
+            g = ops.linear_fwd(_pad_cols(x2, ld), w2, None, out_dtype=dt)
+        else:
+            w2 = _derived(lp, weight, "ct", dt, lambda w: w.permute(2, 3, 1, 0).reshape(k * k * Cout, Cin))
+            g = ops.linear_fwd(x2, w2, None, out_dtype=dt)
         y = ops.pixel_shuffle(g, bias.detach(), B, H, W, k, Cout)
         ctx.save_for_backward(x2, weight, bias)
         ctx.cfg = (B, H, W, sink, lp)
