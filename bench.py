@@ -42,15 +42,46 @@ PEAK_HBM_GBS = 8000.0
 
 
 def dp_info(ddp, steps_run):
-    """data-parallel bookkeeping for the N > 1 lines: gradient collectives per step (how many left
-    during backward is visible from the count: 1 = everything at finish()), parameters that had to
-    be reduced late, SyncBatchNorm collectives per step"""
+    """data-parallel bookkeeping for the N > 1 lines: gradient collectives per step and how many of
+    them left while backward was still running, parameters that had to be reduced on their own,
+    what carried the slices (rccl / direct / gloo in rehearsals), SyncBatchNorm exchanges per step"""
     if ddp is None:
         return {}
     from ssl4gie_amd import resnet_engine
-    return {"dp": {"grad_collectives_per_step": round(ddp.n_collectives / max(steps_run, 1), 2),
-                   "late_params": ddp.n_late, "transport": "direct" if ddp._direct is not None else "rccl",
-                   "syncbn_collectives_per_step": round(resnet_engine.SYNC_BN_COLLECTIVES[0] / max(steps_run, 1), 1)}}
+    n = max(steps_run, 1)
+    return {"dp": {"grad_collectives_per_step": round(ddp.n_collectives / n, 2),
+                   "overlapped_with_backward_per_step": round(ddp.n_overlapped / n, 2),
+                   "late_params": ddp.n_late, "transport": ddp.transport,
+                   "passes_closed_in_backward": ddp.n_passes,
+                   "syncbn_collectives_per_step": round(resnet_engine.SYNC_BN_COLLECTIVES[0] / n, 1)}}
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves,
+    BEFORE anything in this process touches the GPU (a process that has initialised HIP must never be
+    exec-replaced, and the parent stays a plain supervisor), as children of
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; rank 0's
+    JSON line goes to our stdout, the exit code is the launcher's (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    n = None
+    for i, t in enumerate(argv):
+        if t == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif t.startswith("--gpus="):
+            n = int(t.split("=", 1)[1])
+    if not n or n <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def param_groups(model, wd=0.05):
@@ -208,9 +239,7 @@ def bench_depth(a):
     def step():
         opt.zero_grad(set_to_none=True)
         loss = loss_fn((ddp or model)(imgs), tgt)
-        loss.backward()
-        if ddp is not None:
-            ddp.finish()
+        loss.backward()   # under DataParallel the gradient exchange completes in here
         opt.step()
         return loss
 
@@ -268,9 +297,7 @@ def bench_moco(a):
     def step():
         opt.zero_grad(set_to_none=True)
         loss = (ddp or model)(x1, x2, 0.99)
-        loss.backward()
-        if ddp is not None:
-            ddp.finish()
+        loss.backward()   # under DataParallel the gradient exchange completes in here
         opt.step()
         return loss
 
@@ -320,9 +347,7 @@ def bench_vit(a):
     def step():
         opt.zero_grad(set_to_none=True)
         loss = torch.nn.functional.cross_entropy((ddp or model)(imgs), labels)
-        loss.backward()
-        if ddp is not None:
-            ddp.finish()
+        loss.backward()   # under DataParallel the gradient exchange completes in here
         opt.step()
         return loss
 
@@ -372,9 +397,7 @@ def bench_det(a):
         opt.zero_grad(set_to_none=True)
         out = (ddp or model)(imgs)
         loss = sum((v * v).mean() for v in out.values())
-        loss.backward()
-        if ddp is not None:
-            ddp.finish()
+        loss.backward()   # under DataParallel the gradient exchange completes in here
         opt.step()
         return loss
 
@@ -435,9 +458,7 @@ def bench_bt(a):
     def step():
         opt.zero_grad(set_to_none=True)
         loss = (ddp or model)(y1, y2)
-        loss.backward()
-        if ddp is not None:
-            ddp.finish()
+        loss.backward()   # under DataParallel the gradient exchange completes in here
         opt.step()
         return loss
 
@@ -480,7 +501,23 @@ def main():
     ap.add_argument("--workload", default="mae", choices=["mae", "depth", "moco", "bt", "det", "vit"],
                     help="mae = BASELINE.json configs[1] (the headline metric); depth = configs[3] "
                          "(ViT-B + DPT depth finetune step, bs 128/GPU) as an extra measurement")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch check without a GPU: the ranks meet (gloo), sum their ranks and rank 0 "
+                         "prints one JSON line — what tests/test_abi_and_host.py runs through the self-launcher")
     a = ap.parse_args()
+    if a.rendezvous_only:
+        import torch.distributed as dist
+        from ssl4gie_amd import parallel
+        rank, local, world = parallel.init_from_env("gloo")
+        assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+        t = torch.tensor([float(rank)])
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous": world, "rank_sum": float(t)}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if a.workload == "depth":
         return bench_depth(a)
     if a.workload == "bt":
@@ -524,9 +561,7 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         loss, _, _ = (ddp or model)(imgs, mask_ratio=0.75)
-        loss.backward()
-        if ddp is not None:
-            ddp.finish()
+        loss.backward()   # under DataParallel the gradient exchange completes in here
         opt.step()
         return loss
 
@@ -615,4 +650,7 @@ def main():
 
 
 if __name__ == "__main__":
+    rc = self_launch(sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     main()

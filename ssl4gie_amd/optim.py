@@ -42,6 +42,10 @@ class _ArenaOptimizer:
 
     # ------------------------------------------------------------------ segment tables
     def _arena(self):
+        # torch optimizers get this through the global pre-step hook parallel.py registers: close any
+        # data-parallel pass still open and wait for the comm stream before gradients are read
+        from .parallel import before_optimizer_step
+        before_optimizer_step()
         a = self.model.arena()
         own = [p for g in self.param_groups for p in g["params"]]
         assert all(a.owns(p) for p in own), "every optimised parameter must live in the model's arena"

@@ -24,6 +24,7 @@ Design (MI355X-first, not torch DDP's reducer):
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional
 
 import torch
@@ -31,41 +32,83 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
-class DataParallel:
-    """Wraps an EngineModule-like model (anything exposing `.arena()` -> ParamArena-like object with
-    `.data`, `.grad`, `.params`, `.span(params)`, `.grad_view(p)`).
+_LIVE = weakref.WeakSet()  # wrappers whose communication an optimizer step must wait for
+
+
+def before_optimizer_step():
+    """Second line of defence behind the end-of-backward call-back: every optimizer step (torch
+    optimizers through a global pre-step hook, ssl4gie_amd.optim through a direct call) first closes
+    any pass a wrapper still has open and makes the compute stream wait for the comm stream — an
+    optimizer can never step on un-reduced gradients, whatever the training loop looks like."""
+    for dp in list(_LIVE):
+        dp._before_step()
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_pre_hook as _reg_pre_hook
+    _reg_pre_hook(lambda _opt, _args, _kwargs: before_optimizer_step())
+except ImportError:  # torch < 2.0: ssl4gie_amd.optim still calls before_optimizer_step() itself
+    pass
+
+
+class DataParallel(nn.Module):
+    """Drop-in for `torch.nn.parallel.DistributedDataParallel` on an EngineModule-like model (anything
+    exposing `.arena()` -> ParamArena-like object with `.data`, `.grad`, `.params`, `.span(params)`,
+    `.grad_view(p)`): replace the class name in the reference's train loop, nothing else.
+
+        model = DataParallel(model, device_ids=[gpu], find_unused_parameters=True)  # train_depth.py:226-229
+        model.train(); ...; loss.backward(); optimizer.step()                        # :35-48, unchanged
+
+    It is an `nn.Module` holding the model as `self.module`: `train()` / `eval()` / `load_state_dict()` /
+    `named_parameters()` work on the wrapper, `state_dict()` carries the `module.` prefix the reference's
+    MoCo checkpoints have (`main_moco.py:313`, consumed by `convert_to_deit.py:24-32`), and
+    `model.module.state_dict()` is the un-prefixed dict `train_depth.py:357` saves.  The gradient
+    exchange finishes INSIDE `backward()` (an autograd-engine call-back queued by the first hook of a
+    pass, as torch DDP's reducer does), so `scaler.scale(loss).backward()` is followed directly by
+    `scaler.step(optimizer)`; `finish()` remains as an idempotent no-op for older callers.
 
     Readiness is per PARAMETER and comes from autograd itself: a post-accumulate-grad hook on every
     trainable parameter fires once per backward, after the LAST node that uses the parameter has
     enqueued its kernels (autograd runs a leaf's AccumulateGrad only when every use has delivered
     its contribution) — so a parameter used twice in one step (both views of MoCo / Barlow Twins),
     a parameter of an adopted child module, a convolution or BatchNorm parameter are all handled by
-    the same rule, with no call-backs from the engine.  The arena is walked from its end: the
-    "frontier" is the lowest offset above which every trainable parameter is final (or is known
-    never to receive a gradient: learnt during the first step, the reference's
-    `find_unused_parameters=True`); whenever `bucket_bytes` of final gradients have accumulated above
-    the frontier, that contiguous slice is all-reduced on the comm stream.  Runs of frozen
-    parameters (MoCo's momentum encoder: half the arena) split the arena into segments and are never
-    communicated.  A parameter that turns up after its slice went out (graph changed) is reduced on
-    its own; anything not covered by hooks is covered by finish()."""
+    the same rule.  The arena is walked from its end: the "frontier" is the lowest offset above which
+    every trainable parameter is final (or is known never to receive a gradient: learnt during the
+    first pass and agreed between the ranks, the reference's `find_unused_parameters=True`); whenever
+    `bucket_bytes` of final gradients have accumulated above the frontier, that contiguous slice is
+    all-reduced on the comm stream.  Slices never contain a parameter learnt as unused (so one that
+    turns up later — the graph changed — has nothing in flight over its slice and is reduced on its
+    own), and runs of frozen parameters (MoCo's momentum encoder: half the arena) split the arena
+    into segments that are never communicated."""
 
     FROZEN_GAP_ELEMS = 1 << 18  # a frozen run >= 1 MiB ends a segment (not worth carrying along)
 
-    def __init__(self, model, process_group=None, bucket_bytes: int = 64 << 20,
-                 overlap: bool = True, broadcast_parameters: bool = True):
+    def __init__(self, module, device_ids=None, output_device=None, find_unused_parameters=True,
+                 process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True,
+                 broadcast_parameters: bool = True, broadcast_buffers: bool = True, **_ddp_kwargs):
+        """`device_ids`, `output_device`, `find_unused_parameters`, `broadcast_buffers` and further
+        keyword arguments of torch's DDP are accepted so that the reference's constructor calls
+        (`main_pretrain.py:175`, `train_depth.py:226-229`, `main_moco.py:208`) stay as they are:
+        one process drives one device (the module's), unused parameters are always tolerated."""
+        super().__init__()
         assert dist.is_initialized(), "init_process_group first (one process per GPU)"
-        self.module = model
+        self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = overlap
+        self.require_backward_grad_sync = True   # torch DDP's name; False inside no_sync()
         self._arena = None
         self._hooks: List = []
         self._handles: List = []
         self._step = 0
+        self._armed = False      # the end-of-backward call-back of the current pass is queued
         self.n_collectives = 0
-        self.n_late = 0  # parameters reduced on their own after their slice had gone out
-        self._bind(model.arena())
+        self.n_late = 0  # parameters reduced on their own (learnt as unused, then used after all)
+        self.n_passes = 0        # backward passes closed (from inside backward or by finish())
+        self.n_overlapped = 0    # collectives that left while backward was still running
+        self._n_at_pass_start = 0
+        self._bind(module.arena())
         self._is_cuda = self._arena.grad.is_cuda
         self._comm_stream = torch.cuda.Stream() if self._is_cuda else None
         self._avg_op = self._pick_avg_op()
@@ -85,7 +128,7 @@ class DataParallel:
         if broadcast_parameters and self.world > 1:
             dist.broadcast(self._arena.data, src=0, group=process_group)
             # DDP also broadcasts buffers (BatchNorm running statistics) from rank 0
-            for b in (model.buffers() if hasattr(model, "buffers") else ()):
+            for b in (module.buffers() if (broadcast_buffers and hasattr(module, "buffers")) else ()):
                 if b.numel():
                     dist.broadcast(b, src=0, group=process_group)
             try:  # the flat buffer was written, not the parameter views: refresh operand caches
@@ -93,6 +136,19 @@ class DataParallel:
                 bump_weights_epoch()
             except ImportError:  # toy models of the CPU tests do not load the engine
                 pass
+        _LIVE.add(self)
+
+    @property
+    def transport(self) -> str:
+        """what carries the gradient slices: "direct" (csrc/allreduce.hip), else the
+        torch.distributed backend's name ("nccl" is RCCL on ROCm; "gloo" in CPU tests / rehearsals)"""
+        if self._direct is not None:
+            return "direct"
+        try:
+            b = str(dist.get_backend(self.pg))
+        except Exception:
+            b = "unknown"
+        return "rccl" if b == "nccl" else b
 
     # ---------------------------------------------------------------- arena index
     def _bind(self, arena):
@@ -121,7 +177,7 @@ class DataParallel:
             self._items.append((lo, hi, p, seg))
         self._index = {id(p): i for i, (_, _, p, _) in enumerate(self._items)}
         n = len(self._items)
-        self._stamp = [0] * n        # step in which the parameter's hook last fired
+        self._stamp = [0] * n        # pass in which the parameter's hook last fired
         self._unused = [False] * n   # learnt: never receives a gradient
         self._learnt = False
         self._uses = [0] * n         # uses reported by the engine (GradSink.tracker) in this pass
@@ -130,29 +186,51 @@ class DataParallel:
         if callable(sink) and self.overlap and self.world > 1:
             sink().tracker = self._on_use_done
         self._reset_pass()
-        if self.overlap and self.world > 1:
+        if self.world > 1:
             for _, _, p, _ in self._items:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_param))
 
     def _reset_pass(self):
         self._k = 0                  # items [0, k) are final
-        self._sent = 0               # items [0, sent) have been handed to a collective
+        self._sent = 0               # items [0, sent) have been handed to a collective (or skipped: unused)
         self._fired = self._late = 0
         self._uses = [0] * len(self._items) if hasattr(self, "_items") else []
+        self._armed = False
         self._step += 1
 
-    # the model is used exactly like the wrapped module
-    def __call__(self, *a, **k):
+    # the wrapper is used exactly like the wrapped module
+    def forward(self, *a, **k):
         arena = self.module.arena()
         if arena is not self._arena:  # .to() / a new parameter rebuilt the arena
+            self._drain()
             self._bind(arena)
+        elif self._armed or self._fired:
+            # a backward pass that raised half-way never reached its call-back: start afresh
+            self._drain()
+            self._reset_pass()
         return self.module(*a, **k)
 
-    def parameters(self):
-        return self.module.parameters()
+    def arena(self):
+        return self.module.arena()
 
-    def state_dict(self, *a, **k):
-        return self.module.state_dict(*a, **k)
+    def sink(self):
+        return self.module.sink()
+
+    class _NoSync:
+        def __init__(self, dp):
+            self.dp = dp
+
+        def __enter__(self):
+            self.prev = self.dp.require_backward_grad_sync
+            self.dp.require_backward_grad_sync = False
+
+        def __exit__(self, *exc):
+            self.dp.require_backward_grad_sync = self.prev
+
+    def no_sync(self):
+        """torch DDP's gradient-accumulation context: backward passes inside it add into the arena
+        without communicating; the first pass outside it averages the accumulated gradients"""
+        return DataParallel._NoSync(self)
 
     def _pick_avg_op(self):
         try:
@@ -204,45 +282,86 @@ class DataParallel:
             p.grad = v
 
     def _send(self, upto: int, force: bool = False):
-        """hand items [sent, upto) to collectives: one slice per segment, a slice goes out when it
-        has reached bucket size, when its segment is complete, or when `force`"""
-        items = self._items
+        """hand items [sent, upto) to collectives.  A slice is a run of consecutive final items of one
+        segment without a learnt-unused parameter in it; it goes out when it has reached bucket size,
+        when it cannot grow any more (segment end, or an unused parameter follows), or when `force`."""
+        items, unused = self._items, self._unused
         while self._sent < upto:
             i = self._sent
+            if unused[i]:
+                # left out of every slice, so nothing is ever in flight over it: if it received a
+                # gradient after all (the graph changed) it is reduced on its own
+                if self._stamp[i] == self._step:
+                    self.n_late += 1
+                    self._late += 1
+                    self._reduce_slice(items[i][0], items[i][1])
+                self._sent = i + 1
+                continue
             seg = items[i][3]
             j = i
-            while j < upto and items[j][3] == seg:
+            while j < upto and items[j][3] == seg and not unused[j]:
                 j += 1
-            seg_done = j == len(items) or items[j][3] != seg
-            hi = self._seg_hi[seg] if (i == 0 or items[i - 1][3] != seg) else items[i - 1][0]
+            closed = j == len(items) or items[j][3] != seg or unused[j]
+            first = i == 0 or items[i - 1][3] != seg
+            hi = self._seg_hi[seg] if first else items[i - 1][0]
             lo = items[j - 1][0]
-            if not (force or seg_done or hi - lo >= self.bucket_elems):
+            if not (force or closed or hi - lo >= self.bucket_elems):
                 return
             self._reduce_slice(lo, hi)
             self._sent = j
+
+    def _arm(self):
+        """queue the end-of-backward call-back (once per pass; only possible from inside backward)"""
+        if not self._armed:
+            self._armed = True
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(self._finalize)
 
     def _on_use_done(self, params):
         """engine call-back (GradSink.tracker): the kernels of one use of `params` are enqueued.  A
         parameter whose learnt number of uses per pass has been reached is final NOW — before
         autograd gets round to its AccumulateGrad, which for a block stack (one autograd node for
         8-12 blocks) is only after the whole stack."""
+        if not self.require_backward_grad_sync:
+            return
         for p in params:
             i = self._index.get(id(p))
             if i is None:
                 continue
             self._uses[i] += 1
-            if self._learnt and self._expected[i] and self._uses[i] == self._expected[i]:
-                self._on_param(p, early=True)
+            if self._learnt and self._expected[i]:
+                if self._uses[i] == self._expected[i]:
+                    self._on_param(p, early=True)
+                elif self._uses[i] > self._expected[i]:
+                    raise RuntimeError(
+                        "ssl4gie_amd.parallel.DataParallel: a parameter is used more often in this backward "
+                        "pass than in the pass the communication schedule was learnt from (its gradient slice "
+                        "may already be in flight); call ddp.relearn() after changing the graph")
+
+    def relearn(self):
+        """forget the learnt schedule (unused set, uses per pass): the next pass communicates at its
+        end and learns again — call after changing which parameters take part in the graph"""
+        self._drain()
+        n = len(self._items)
+        self._unused, self._expected, self._learnt = [False] * n, [0] * n, False
+        self._reset_pass()
 
     def _on_param(self, p, early=False):
         i = self._index.get(id(p))
         if i is None or self._stamp[i] == self._step:
             return
+        self._arm()
+        if not self.require_backward_grad_sync:
+            return
         if not early:
             self._adopt(p)
         self._stamp[i] = self._step
         self._fired += 1
-        if i < self._sent:  # its slice has already gone out (a parameter we had learnt as unused)
+        if not self.overlap:
+            return
+        if i < self._sent:
+            # only a parameter learnt as unused can be behind the frontier, and _send() left its slice
+            # out of every collective: nothing is in flight over it, it is reduced on its own
             self.n_late += 1
             self._late += 1
             self._reduce_slice(self._items[i][0], self._items[i][1])
@@ -261,19 +380,38 @@ class DataParallel:
             if p.requires_grad:
                 self._on_param(p)
 
-    def finish(self):
-        """Call after loss.backward() and before optimizer.step(): sends whatever has not gone out
-        yet and makes the compute stream wait for all communication."""
-        if self.world > 1:
+    def _agree_unused(self, used: List[bool]) -> List[bool]:
+        """ranks agree on the unused set (a parameter used on ANY rank is waited for on all): the
+        slices every rank cuts out of its arena are then the same, whatever a rank's own graph did"""
+        t = torch.tensor([1.0 if u else 0.0 for u in used], dtype=torch.float32, device=self._arena.grad.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        return [v == 0.0 for v in t.tolist()]
+
+    def _finalize(self):
+        """End of a backward pass (autograd-engine call-back; also reachable through finish() and the
+        optimizer pre-step hook): send whatever has not gone out, then make the caller's stream wait
+        for all communication.  The engine runs final call-backs on the stream that was current around
+        `backward()`, after syncing it with the leaf streams."""
+        self.n_overlapped += self.n_collectives - self._n_at_pass_start
+        if self.world > 1 and self.require_backward_grad_sync:
             for _, _, p, _ in self._items[self._sent:]:
                 self._adopt(p)
-            if (not self._learnt or self._late) and self._fired:
-                # first step (or the graph changed): parameters whose hook did not fire do not
-                # take part in this graph
-                self._unused = [s != self._step for s in self._stamp]
-                self._expected = list(self._uses)
-                self._learnt = True
+            # the forced send covers items whose hook did not fire as well (zeros, or gradients of an
+            # earlier pass that were never cleared: every rank sends the same slices either way);
+            # the slices of THIS pass are cut with the unused set learnt so far
             self._send(len(self._items), force=True)
+            if (not self._learnt or self._late) and self._fired:
+                # first pass (or the graph changed): parameters whose hook did not fire on any rank do
+                # not take part in this graph
+                self._unused = self._agree_unused([s == self._step for s in self._stamp])
+                self._expected, self._learnt = list(self._uses), True
+        self._drain()
+        self.n_passes += 1
+        self._n_at_pass_start = self.n_collectives
+        self._reset_pass()
+
+    def _drain(self):
+        """wait for every collective in flight (host-side for gloo, stream-side for RCCL / direct)"""
         for h, g in self._handles:
             h.wait()
             if self._avg_op is None and self.world > 1:
@@ -281,7 +419,20 @@ class DataParallel:
         self._handles.clear()
         if self._is_cuda:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
-        self._reset_pass()
+            if self._direct is not None:
+                self._direct.raise_if_failed()
+
+    def _before_step(self):
+        if self.world > 1 and (self._armed or self._fired or self._handles):
+            self._finalize()
+        elif self._is_cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def finish(self):
+        """No longer needed: the pass is closed from inside `backward()`.  Kept as an idempotent call
+        for loops written against the round-2 interface — it closes a pass only if one is open."""
+        if self.world > 1 and (self._armed or self._fired or self._handles):
+            self._finalize()
 
     # ---------------------------------------------------------------- small collectives
     def all_reduce_mean(self, t: torch.Tensor) -> torch.Tensor:
@@ -326,6 +477,17 @@ class DirectAllReduce:
             self._check(self.L.ssl4gie_allreduce_direct_enqueue(self.h, t.data_ptr() + 4 * off, m, float(scale), st),
                         "allreduce_direct_enqueue")
             off += m
+
+    def raise_if_failed(self):
+        """a peer that never signalled (poll time-out inside a kernel) leaves a sticky error word in
+        the handle; enqueue returns it from then on and DataParallel raises instead of stepping on
+        stale sums"""
+        err = getattr(self.L, "ssl4gie_allreduce_direct_error", None)
+        if err is not None and self.h:
+            rc = err(self.h)
+            if rc:
+                raise RuntimeError(f"ssl4gie direct all-reduce: a peer did not arrive in time (error word {rc}); "
+                                   "gradients of this step are not reduced")
 
     def close(self):
         if self.h:

@@ -271,3 +271,23 @@ def test_position_table_resize_matches_f_interpolate():
         (gg,) = torch.autograd.grad(got, pos, w)
         assert (gr - gg).abs().max() < 2e-5 * max(1.0, float(gr.abs().max()))
         assert gg[0, 0].abs().max() == 0  # the cls row gets no gradient
+
+
+@pytest.mark.timeout(180)
+def test_bench_self_launches_its_ranks_when_invoked_plainly():
+    """`python bench.py --gpus 2 ...` with no torchrun environment (how the driver invokes N = 1) must
+    start its own ranks: the parent spawns `torch.distributed.run` children before touching the GPU,
+    relays rank 0's line and exits with the launcher's code (it used to die on an assert)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0]) == {"rendezvous": 2, "rank_sum": 1.0}
+    # a failing rank is reported through the exit code
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only",
+                        "--no-such-flag"], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode != 0

@@ -118,8 +118,7 @@ def _dp_worker(rank, world, port, q, transport):
     for step in range(3):
         for p in m.parameters():
             p.grad = None
-        ddp(x).backward()
-        ddp.finish()
+        ddp(x).backward()   # the exchange completes inside backward()
         torch.cuda.synchronize()
         out.append(torch.cat([p.grad.flatten() for p in m.parameters()]).cpu().numpy())  # by value
     q.put((rank, transport, out, ddp.n_collectives))
@@ -130,7 +129,7 @@ def _dp_worker(rank, world, port, q, transport):
 
 @pytest.mark.timeout(300)
 def test_data_parallel_direct_transport_equals_default():
-    """same toy, same data: gradients after DataParallel.finish() with the direct transport == with
+    """same toy, same data: gradients after backward() under DataParallel with the direct transport == with
     torch.distributed's all-reduce (gloo here), bucket slices going out during backward"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

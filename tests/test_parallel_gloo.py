@@ -134,21 +134,22 @@ def _worker(rank, world, port, q, two_view, frozen, bucket_bytes):
     m = _Toy(frozen=frozen)
     torch.manual_seed(1234)
     ref_init = _Toy(frozen=frozen)  # rank 0's initial weights
-    ddp = DataParallel(m, bucket_bytes=bucket_bytes, overlap=True)
+    # the reference's constructor call, class name replaced (train_depth.py:226-229)
+    model = DataParallel(m, device_ids=[0], find_unused_parameters=True, bucket_bytes=bucket_bytes)
     a = m.arena()
     same_weights = all(torch.equal(p, r) for p, r in zip(m.parameters(), ref_init.parameters()))
-    batches = _batches(world, two_view)
+    batches = _batches(world, two_view)  # DIFFERENT data per rank
     expect = _single_process_grads(1234, batches, frozen=frozen)
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.0)
     res = []
     for step in range(3):  # step 0 learns the unused set; steps 1, 2 overlap fully
-        for p in m.parameters():
-            p.grad = None
-        before = ddp.n_collectives
-        loss = ddp(*batches[rank])
-        loss.backward()
-        during = ddp.n_collectives - before
-        ddp.finish()
-        ok = True
+        model.train()
+        opt.zero_grad(set_to_none=True)
+        before, before_ov = model.n_collectives, model.n_overlapped
+        loss = model(*batches[rank])
+        loss.backward()             # the exchange finishes in here: no finish() anywhere
+        during = model.n_overlapped - before_ov
+        ok = model.n_passes == step + 1
         for k, p in m.named_parameters():
             e = expect[k]
             if e is None:
@@ -156,17 +157,23 @@ def _worker(rank, world, port, q, two_view, frozen, bucket_bytes):
             else:
                 ok &= p.grad is not None and torch.allclose(p.grad, e, rtol=1e-5, atol=1e-7)
                 ok &= p.grad.data_ptr() == a.grad_view(p).data_ptr()  # incl. the adopted torch-op gradient
-        res.append((bool(ok), during, ddp.n_collectives - before, ddp.n_late))
-    loss_mean = ddp.all_reduce_mean(torch.tensor([float(rank + 1)]))
-    q.put((rank, same_weights, res, float(loss_mean)))
+        opt.step()
+        model.finish()              # idempotent: nothing left to do
+        ok &= model.n_passes == step + 1
+        res.append((bool(ok), during, model.n_collectives - before, model.n_late))
+    loss_mean = model.all_reduce_mean(torch.tensor([float(rank + 1)]))
+    keys_ok = all(k.startswith("module.") for k in model.state_dict()) and \
+        set(model.module.state_dict()) == {k[len("module."):] for k in model.state_dict()}
+    q.put((rank, same_weights and keys_ok, res, float(loss_mean)))
     dist.destroy_process_group()
 
 
-def _run(two_view, frozen, bucket_bytes):
+def _run(two_view, frozen, bucket_bytes, target=None, extra=()):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, two_view, frozen, bucket_bytes)) for r in range(2)]
+    procs = [ctx.Process(target=target or _worker, args=(r, 2, port, q) + ((two_view, frozen, bucket_bytes) if target is None else tuple(extra)))
+             for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=100) for _ in procs]
@@ -179,31 +186,130 @@ def _run(two_view, frozen, bucket_bytes):
 @pytest.mark.timeout(120)
 @pytest.mark.parametrize("two_view", [False, True])
 def test_bucketed_allreduce_world2(two_view):
-    """gradient mean over 2 ranks == single-process gradient of the mean loss, with buckets going out
-    DURING backward — also when every parameter is used twice per step (the slice of a parameter
-    must not go out before its second use has accumulated into it), for the adopted child's and
-    the torch-op-produced gradients, and around a parameter that never receives a gradient"""
+    """gradient mean over 2 ranks (different data per rank) == single-process gradient of the mean
+    loss, with NO finish() call: the pass is closed from inside backward(), buckets go out DURING
+    backward — also when every parameter is used twice per step (the slice of a parameter must not
+    go out before its second use has accumulated into it), for the adopted child's and the
+    torch-op-produced gradients, and around a parameter that never receives a gradient"""
     for rank, same_w, steps, lm in _run(two_view, 0, 4 * 2000):
-        assert same_w, "rank-0 parameter broadcast"
+        assert same_w, "rank-0 parameter broadcast / module.-prefixed state_dict"
         for ok, during, total, late in steps:
             assert ok, "gradient average"
             assert late == 0
-        # step 0: the never-used parameter sits above the blocks and holds the frontier until
-        # finish(); afterwards it is known and most slices leave while backward is still running
+        # step 0: the never-used parameter sits above the blocks and holds the frontier until the
+        # end of backward; afterwards it is known and most slices leave while backward is still running
         assert steps[1][1] >= 2 and steps[2][1] >= 2, steps
-        assert steps[1][2] <= steps[1][1] + 1
+        assert steps[1][2] <= steps[1][1] + 2
         assert abs(lm - 1.5) < 1e-6
 
 
 @pytest.mark.timeout(120)
 def test_frozen_run_is_not_communicated_world2():
     """a large frozen block in the middle of the arena (MoCo's momentum encoder) splits it into
-    segments: trainable slices either side are averaged, the frozen run is never sent"""
+    segments: trainable slices either side are averaged, the frozen run is never sent (the learnt-unused
+    parameter sits at the end of its segment: leaving it out does not split a slice)"""
     for rank, same_w, steps, lm in _run(True, 600, 1 << 30):
         assert same_w
         for ok, during, total, late in steps:
             assert ok and late == 0
             assert total == 2, "one slice per trainable segment (bucket larger than either)"
+
+
+def _loop_worker(rank, world, port, q):
+    """gradient accumulation under no_sync(), a parameter that turns up after it was learnt as unused,
+    a backward pass that raises half-way, a module.-prefixed checkpoint round trip"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssl4gie_amd import checkpoints
+    from ssl4gie_amd.parallel import DataParallel
+    torch.manual_seed(7)
+    m = _Toy()
+    model = DataParallel(m, bucket_bytes=4 * 2000)
+    a = m.arena()
+    batches = _batches(world, True)
+    ok = True
+    # --- accumulation: two micro-batches, the first without communication
+    for p in m.parameters():
+        p.grad = None
+    x1, x2 = batches[rank]
+    n0 = model.n_collectives
+    with model.no_sync():
+        model(x1).backward()
+    ok &= model.n_collectives == n0
+    model(x2).backward()
+    exp = None
+    for b in batches:
+        g = _single_process_grads(7, [[b[0]]])
+        g2 = _single_process_grads(7, [[b[1]]])
+        tot = {k: (None if g[k] is None else (g[k] + g2[k]) / world) for k in g}
+        exp = tot if exp is None else {k: (None if tot[k] is None else exp[k] + tot[k]) for k in tot}
+    for k, p in m.named_parameters():
+        if exp[k] is not None:
+            ok &= torch.allclose(p.grad, exp[k], rtol=1e-5, atol=1e-7)
+    # --- a parameter learnt as unused receives a gradient after all (the graph changed)
+    for p in m.parameters():
+        p.grad = None
+    model(x1).backward()          # a plain pass: `unused` is known to be unused by now
+    late0 = model.n_late
+    for p in m.parameters():
+        p.grad = None
+    loss = model(x1) + (m.unused.weight ** 2).sum() * (rank + 1.0)
+    loss.backward()
+    ok &= model.n_late == late0 + 1
+    ok &= torch.allclose(m.unused.weight.grad, 2 * m.unused.weight.detach() * 1.5, rtol=1e-6)
+    ok &= m.unused.weight.grad.data_ptr() == a.grad_view(m.unused.weight).data_ptr()
+    for p in m.parameters():
+        p.grad = None
+    n_before = model.n_collectives
+    (model(x1) + (m.unused.weight ** 2).sum()).backward()   # re-learnt: part of the slices now
+    ok &= model.n_late == late0 + 1 and model.n_collectives > n_before
+    # --- a backward that raises leaves no stale pass behind
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+        @staticmethod
+        def backward(ctx, g):
+            raise ValueError("boom")
+    for p in m.parameters():
+        p.grad = None
+    try:
+        Boom.apply(model(x1)).backward()
+        ok = False
+    except ValueError:
+        pass
+    for p in m.parameters():
+        p.grad = None
+    model.relearn()
+    passes = model.n_passes
+    model(x1).backward()
+    ok &= model.n_passes == passes + 1
+    # --- module.-prefixed file (main_moco.py:313) -> plain names (convert_to_deit.py:24-32)
+    import io
+    buf = io.BytesIO()
+    torch.save({"state_dict": model.state_dict(), "epoch": 3}, buf)
+    buf.seek(0)
+    sd = torch.load(buf)["state_dict"]
+    plain = checkpoints.ddp_unwrap(sd)
+    torch.manual_seed(99)
+    fresh = _Toy()
+    fresh.load_state_dict(plain, strict=True)
+    ok &= all(torch.equal(x, y) for x, y in zip(fresh.parameters(), m.parameters()))
+    wrapped = DataParallel(_Toy(), broadcast_parameters=False)
+    wrapped.load_state_dict(sd, strict=True)        # main_moco.py:246 loads INTO the wrapper
+    ok &= all(torch.equal(x, y) for x, y in zip(wrapped.module.parameters(), m.parameters()))
+    model.eval()
+    ok &= not m.training
+    model.train()
+    ok &= m.training
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_reference_loop_features_world2():
+    res = _run(None, None, None, target=_loop_worker)
+    assert all(ok for _, ok in res), res
 
 
 def _syncbn_worker(rank, world, port, q):
