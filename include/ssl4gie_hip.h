@@ -31,6 +31,7 @@ extern "C" {
 #define SSL4GIE_F32 0
 #define SSL4GIE_BF16 1
 #define SSL4GIE_EARG 1000
+#define SSL4GIE_EPEER 1001 /* direct all-reduce: a peer did not arrive in time (sticky, see _error) */
 
 int ssl4gie_abi_version(void);
 
@@ -554,7 +555,14 @@ int ssl4gie_dice_loss(const float* logits, const float* target, float* loss, flo
  *   enqueue  grad[0 .. n_elems) <- scale * sum over ranks, in place, on `stream` (5 launches, no host
  *            synchronisation).  Every rank must enqueue the same sequence of sizes; sums run in rank
  *            order on every rank, so all ranks end with bitwise identical values;
- *   destroy  unmaps / frees (after the streams that used the handle have drained). */
+ *   error    the handle's sticky error word: 0, or (sequence number << 8 | 1 + peer rank) of the first
+ *            bucket in which a waiting kernel gave up on a peer (bounded poll: ~30 s, SSL4GIE_AR_TIMEOUT_S
+ *            or set_timeout).  Such a kernel writes NaN instead of stale sums; from then on enqueue
+ *            returns SSL4GIE_EPEER (1001) and ssl4gie_amd.parallel.DataParallel raises.  Read without
+ *            synchronising (mapped host memory);
+ *   destroy  unmaps / frees (after the streams that used the handle have drained).
+ * init fails (hipError_t) when fine-grained device memory is not available: peer stores and in-kernel
+ * flag polls are not coherent on coarse-grained memory, so there is no fallback to it. */
 typedef struct ssl4gie_ar_handle ssl4gie_ar_handle;
 size_t ssl4gie_allreduce_direct_blob_bytes(void);
 int ssl4gie_allreduce_direct_init(int rank, int world, size_t max_elems, void* export_blob,
@@ -562,6 +570,8 @@ int ssl4gie_allreduce_direct_init(int rank, int world, size_t max_elems, void* e
 int ssl4gie_allreduce_direct_connect(ssl4gie_ar_handle* h, const void* all_blobs);
 int ssl4gie_allreduce_direct_enqueue(ssl4gie_ar_handle* h, float* grad, size_t n_elems, float scale,
                                      void* stream);
+unsigned ssl4gie_allreduce_direct_error(const ssl4gie_ar_handle* h);
+int ssl4gie_allreduce_direct_set_timeout(ssl4gie_ar_handle* h, double seconds);
 int ssl4gie_allreduce_direct_destroy(ssl4gie_ar_handle* h);
 
 #ifdef __cplusplus

@@ -160,6 +160,8 @@ PROTOTYPES = {
     "ssl4gie_allreduce_direct_init": (i32, [i32, i32, sz, vp, C.POINTER(vp)]),
     "ssl4gie_allreduce_direct_connect": (i32, [vp, vp]),
     "ssl4gie_allreduce_direct_enqueue": (i32, [vp, vp, sz, f32, vp]),
+    "ssl4gie_allreduce_direct_error": (C.c_uint, [vp]),
+    "ssl4gie_allreduce_direct_set_timeout": (i32, [vp, C.c_double]),
     "ssl4gie_allreduce_direct_destroy": (i32, [vp]),
     "ssl4gie_prof_begin": (i32, [i32]),
     "ssl4gie_prof_collect": (i32, [vp, vp, vp]),
@@ -205,5 +207,6 @@ def load():
 
 def check(rc: int, what: str):
     if rc != 0:
-        kind = "invalid argument" if rc == 1000 else f"hipError_t {rc}"
+        kind = {1000: "invalid argument",
+                1001: "a peer of the direct all-reduce did not arrive in time (sticky)"}.get(rc, f"hipError_t {rc}")
         raise RuntimeError(f"libssl4gie_hip: {what} failed ({kind})")

@@ -27,20 +27,51 @@ from __future__ import annotations
 from collections import OrderedDict
 
 
-def load_file(path, map_location="cpu"):
-    """`torch.load` for checkpoint files written by the reference's scripts.  Those hold more than
-    tensors — MAE saves `'args': argparse.Namespace` (`Models/mae/util/misc.py:301-307`), the finetune
-    apps save Python / NumPy RNG states (`train_depth.py:355-366`) — which torch >= 2.6's default
-    `weights_only=True` rejects.  First try the restricted unpickler with `argparse.Namespace`
-    allow-listed; a file that still needs more (RNG state tuples, numpy arrays) is loaded the way the
-    reference's torch did, unrestricted: these are the user's own training checkpoints."""
+def _reference_payload_globals():
+    """what the reference's own checkpoint files hold besides tensors and builtins: MAE's
+    `'args': argparse.Namespace` (`Models/mae/util/misc.py:301-307`), the finetune apps' NumPy RNG
+    state and NumPy scalars (`train_depth.py:355-366`: `np.random.get_state()`, `loss` / `val_perf`)
+    — under the module paths NumPy 1.x and 2.x pickle them with"""
     import argparse
+    import numpy as np
+    try:
+        from numpy._core import multiarray as ma
+    except ImportError:  # NumPy 1.x
+        from numpy.core import multiarray as ma
+    out = [argparse.Namespace, np.ndarray, np.dtype]
+    for name in ("_reconstruct", "scalar"):
+        fn = getattr(ma, name)
+        out += [fn, (fn, f"numpy.core.multiarray.{name}"), (fn, f"numpy._core.multiarray.{name}")]
+    for t in (np.uint8, np.uint32, np.uint64, np.int32, np.int64, np.float16, np.float32, np.float64, np.bool_):
+        out.append(type(np.dtype(t)))
+    return out
+
+
+def load_file(path, map_location="cpu", trusted=None):
+    """`torch.load` for checkpoint files written by the reference's scripts.  Those hold more than
+    tensors — MAE saves `'args': argparse.Namespace`, the finetune apps save Python / NumPy RNG states —
+    which torch >= 2.6's default `weights_only=True` rejects.  The restricted unpickler is kept and
+    exactly those types are allow-listed (`_reference_payload_globals`); nothing else is ever executed.
+    A file that needs more is REFUSED unless the caller opts in with `trusted=True` (or
+    `SSL4GIE_TRUSTED_CHECKPOINTS=1`): a downloaded "pretrained weights" file must not be able to run
+    code just because the safe loader rejected it."""
+    import os
     import pickle
+    import warnings
     import torch
     try:
-        with torch.serialization.safe_globals([argparse.Namespace]):
+        with torch.serialization.safe_globals(_reference_payload_globals()):
             return torch.load(path, map_location=map_location, weights_only=True)
-    except (pickle.UnpicklingError, RuntimeError):
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        if trusted is None:
+            trusted = os.environ.get("SSL4GIE_TRUSTED_CHECKPOINTS", "0") == "1"
+        if not trusted:
+            raise RuntimeError(
+                f"{path}: holds objects outside tensors and the reference's known checkpoint payload "
+                f"(argparse.Namespace, NumPy arrays / scalars): {e}\nIf this file is your own, load it with "
+                "checkpoints.load_file(path, trusted=True) or set SSL4GIE_TRUSTED_CHECKPOINTS=1 "
+                "(full unpickling can execute code).") from e
+        warnings.warn(f"{path}: unpickling without restrictions (trusted=True)")
         return torch.load(path, map_location=map_location, weights_only=False)
 
 

@@ -48,6 +48,11 @@ struct ssl4gie_ar_handle {
     char* region[AR_MAX_WORLD];  // [rank] = own allocation, others = IPC mappings
     unsigned seq;
     bool connected;
+    // sticky error word in mapped host memory: a waiting kernel that gives up on a peer stores
+    // (seq << 8 | 1 + peer) here with a system-scope store; the host reads it without synchronising
+    unsigned* err_host;
+    unsigned* err_dev;
+    long long max_spins;    // bound of one flag poll (s_sleep(8) per spin, ~0.3 us)
 };
 
 struct ArLayout {
@@ -95,26 +100,41 @@ __global__ void ar_signal_kernel(ArPeers peers, size_t flag_off, int me, int W, 
     }
 }
 
-// every workgroup polls the W flags itself (W loads): no grid-wide dependency
-DEVI void ar_wait(const unsigned* flags, int W, unsigned seq) {
+// every workgroup polls the W flags itself (W loads): no grid-wide dependency.  Returns false when a
+// peer did not arrive within the bound: the poll must be bounded (a peer that died must not leave
+// waves spinning on the device for ever), but a kernel that gave up must not pass stale sums on
+// silently either — it records (seq, peer) in the handle's sticky error word, which every later
+// enqueue returns and ssl4gie_amd.parallel raises on, and the callers below poison what they write
+// with NaN, so the step that used the bucket is visibly broken (non-finite loss / GradScaler skip).
+DEVI bool ar_wait(const unsigned* flags, int W, unsigned seq, long long max_spins, unsigned* err) {
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
+    __syncthreads();
     if (threadIdx.x < (unsigned)W) {
-        // sequence numbers only grow; the difference is taken modulo 2^32.  The poll is bounded
-        // (~10 s): a peer that died must not leave waves spinning on the device for ever — the
-        // kernel then finishes with stale data and the caller's next collective / check fails
+        // sequence numbers only grow; the difference is taken modulo 2^32
         long long spins = 0;
-        while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0 &&
-               ++spins < (1ll << 25))
+        bool late = false;
+        while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (++spins >= max_spins) { late = true; break; }
             __builtin_amdgcn_s_sleep(8);
+        }
+        if (late) {
+            timed_out = 1;
+            __hip_atomic_store(err, (seq << 8) | (1u + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     __syncthreads();
     __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system-scope acquire: peers' data stores are visible
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    return timed_out == 0;
 }
 
 __global__ void ar_reduce_kernel(float* __restrict__ grad, size_t n, int me, int W, ArPeers peers,
                                  size_t slots_off, size_t result_off, size_t flag_off,
-                                 size_t chunk_cap, float scale, unsigned seq) {
-    ar_wait((const unsigned*)(peers.region[me] + flag_off), W, seq);
+                                 size_t chunk_cap, float scale, unsigned seq, long long max_spins,
+                                 unsigned* err) {
+    if (!ar_wait((const unsigned*)(peers.region[me] + flag_off), W, seq, max_spins, err))
+        scale = __builtin_nanf("");  // a slot was never filled: what leaves here must not look like a sum
     const size_t per = ar_per(n, W);
     const size_t lo = (size_t)me * per;
     if (lo >= n) return;
@@ -135,8 +155,9 @@ __global__ void ar_reduce_kernel(float* __restrict__ grad, size_t n, int me, int
 }
 
 __global__ void ar_gather_kernel(float* __restrict__ grad, size_t n, int me, int W, ArPeers peers,
-                                 size_t result_off, size_t flag_off, size_t chunk_cap, unsigned seq) {
-    ar_wait((const unsigned*)(peers.region[me] + flag_off), W, seq);
+                                 size_t result_off, size_t flag_off, size_t chunk_cap, unsigned seq,
+                                 long long max_spins, unsigned* err) {
+    const bool ok = ar_wait((const unsigned*)(peers.region[me] + flag_off), W, seq, max_spins, err);
     const int w = blockIdx.y;
     if (w == me) return;
     const size_t per = ar_per(n, W);
@@ -146,9 +167,10 @@ __global__ void ar_gather_kernel(float* __restrict__ grad, size_t n, int me, int
     const float* src = (const float*)(peers.region[me] + result_off) + (size_t)w * chunk_cap;
     float* dst = grad + lo;
     const size_t n4 = len / 4;
+    const float poison = ok ? 0.f : __builtin_nanf("");  // an owner never delivered: NaN, not stale values
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
-        ((f32x4*)dst)[i] = ((const f32x4*)src)[i];
-    if (blockIdx.x == 0 && threadIdx.x < (len & 3)) dst[n4 * 4 + threadIdx.x] = src[n4 * 4 + threadIdx.x];
+        ((f32x4*)dst)[i] = ((const f32x4*)src)[i] + poison;
+    if (blockIdx.x == 0 && threadIdx.x < (len & 3)) dst[n4 * 4 + threadIdx.x] = src[n4 * 4 + threadIdx.x] + poison;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -167,17 +189,30 @@ extern "C" int ssl4gie_allreduce_direct_init(int rank, int world, size_t max_ele
     h->region_bytes = L.total;
     // fine-grained device memory: peers' system-scope stores / loads of flags and data are coherent
     // with this device's caches without waiting for a kernel boundary (what RCCL's p2p buffers use)
+    // No fallback to coarse-grained hipMalloc: peer stores and in-kernel flag polls are not coherent
+    // there (a poll could spin on a line held in L2) — the caller gets the error and keeps RCCL.
     void* p = nullptr;
     hipError_t e = hipExtMallocWithFlags(&p, L.total, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, L.total); }
-    if (e != hipSuccess) { free(h); return (int)e; }
+    if (e != hipSuccess) { (void)hipGetLastError(); free(h); return (int)e; }
+    // ~30 s by default (SSL4GIE_AR_TIMEOUT_S): long enough for a rank that writes a checkpoint or
+    // evaluates between two steps, short enough not to look like a hung device
+    {
+        const char* ev = getenv("SSL4GIE_AR_TIMEOUT_S");
+        double secs = ev ? atof(ev) : 30.0;
+        if (!(secs > 0)) secs = 30.0;
+        h->max_spins = (long long)(secs * 3.0e6);
+        if (h->max_spins < 1) h->max_spins = 1;
+    }
+    e = hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped);
+    if (e == hipSuccess) { *h->err_host = 0; e = hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0); }
+    if (e != hipSuccess) { if (h->err_host) (void)hipHostFree(h->err_host); (void)hipFree(p); free(h); return (int)e; }
     e = hipMemset(p, 0, L.total);
     if (e == hipSuccess) e = hipDeviceSynchronize();  // zeroed flags are visible before anyone maps them
-    if (e != hipSuccess) { (void)hipFree(p); free(h); return (int)e; }
+    if (e != hipSuccess) { (void)hipHostFree(h->err_host); (void)hipFree(p); free(h); return (int)e; }
     h->region[rank] = (char*)p;
     hipIpcMemHandle_t ipc;
     e = hipIpcGetMemHandle(&ipc, p);
-    if (e != hipSuccess) { (void)hipFree(p); free(h); return (int)e; }
+    if (e != hipSuccess) { (void)hipHostFree(h->err_host); (void)hipFree(p); free(h); return (int)e; }
     memset(export_blob, 0, ssl4gie_allreduce_direct_blob_bytes());
     memcpy(export_blob, &ipc, sizeof(ipc));
     unsigned long long meta[2] = {(unsigned long long)h->chunk_cap, (unsigned long long)world};
@@ -208,6 +243,7 @@ extern "C" int ssl4gie_allreduce_direct_connect(ssl4gie_ar_handle* h, const void
 extern "C" int ssl4gie_allreduce_direct_enqueue(ssl4gie_ar_handle* h, float* grad, size_t n_elems,
                                                 float scale, void* stream) {
     REQUIRE(h && h->connected && grad);
+    if (*(volatile unsigned*)h->err_host) return SSL4GIE_EPEER;  // sticky: an earlier bucket lost a peer
     if (n_elems == 0) return 0;
     REQUIRE(n_elems <= h->chunk_cap * (size_t)h->world && ((uintptr_t)grad & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
@@ -227,17 +263,29 @@ extern "C" int ssl4gie_allreduce_direct_enqueue(ssl4gie_ar_handle* h, float* gra
                        L.slots[par], h->chunk_cap);
     hipLaunchKernelGGL(ar_signal_kernel, dim3(1), dim3(64), 0, st, peers, fa, me, W, seq);
     hipLaunchKernelGGL(ar_reduce_kernel, dim3(bx * 2), dim3(256), 0, st, grad, n_elems, me, W, peers, L.slots[par],
-                       L.result[par], fa, h->chunk_cap, scale, seq);
+                       L.result[par], fa, h->chunk_cap, scale, seq, h->max_spins, h->err_dev);
     hipLaunchKernelGGL(ar_signal_kernel, dim3(1), dim3(64), 0, st, peers, fb, me, W, seq);
     hipLaunchKernelGGL(ar_gather_kernel, dim3(bx, W), dim3(256), 0, st, grad, n_elems, me, W, peers, L.result[par],
-                       fb, h->chunk_cap, seq);
+                       fb, h->chunk_cap, seq, h->max_spins, h->err_dev);
     LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" unsigned ssl4gie_allreduce_direct_error(const ssl4gie_ar_handle* h) {
+    return (h && h->err_host) ? *(volatile unsigned*)h->err_host : 0u;
+}
+
+extern "C" int ssl4gie_allreduce_direct_set_timeout(ssl4gie_ar_handle* h, double seconds) {
+    REQUIRE(h && seconds > 0);
+    h->max_spins = (long long)(seconds * 3.0e6);
+    if (h->max_spins < 1) h->max_spins = 1;
     return 0;
 }
 
 extern "C" int ssl4gie_allreduce_direct_destroy(ssl4gie_ar_handle* h) {
     if (!h) return 0;
     int rc = 0;
+    if (h->err_host) (void)hipHostFree(h->err_host);
     for (int p = 0; p < h->world; ++p) {
         if (!h->region[p]) continue;
         const hipError_t e = (p == h->rank) ? hipFree(h->region[p]) : hipIpcCloseMemHandle(h->region[p]);

@@ -96,8 +96,12 @@ class ParamArena:
         return self._lp
 
     def lp_flat_is_current(self):
-        """called after bump_weights_epoch() by an optimizer that wrote the flat shadow itself"""
+        """called after bump_weights_epoch() by an optimizer that wrote the flat shadow itself.  The
+        claim only holds while nobody edits a parameter through torch afterwards (load_state_dict,
+        p.copy_, re-initialisation move Tensor._version, not the epoch): the versions are recorded and
+        _refresh_lp() trusts the flat shadow only if none has moved since."""
         self._lp_flat_stamp = weights_epoch()
+        self._lp_flat_versions = [p._version for p in self.params]
 
     def _refresh_lp(self):
         L = _lib.load()
@@ -114,7 +118,9 @@ class ParamArena:
                             torch.tensor([m[1] for m in mats], dtype=torch.int32, device=dev),
                             torch.tensor([m[2] for m in mats], dtype=torch.int32, device=dev),
                             torch.tensor(starts, dtype=torch.int32, device=dev), len(mats), starts[-1])
-        if getattr(self, "_lp_flat_stamp", None) != weights_epoch():
+        flat_ok = getattr(self, "_lp_flat_stamp", None) == weights_epoch() and \
+            getattr(self, "_lp_flat_versions", None) == [p._version for p in self.params]
+        if not flat_ok:
             _lib.check(L.ssl4gie_cast(ops.ptr(self.data), ops.ptr(self._lp), _lib.BF16, self.numel,
                                       ops.stream()), "cast(arena)")
         off, rows, cols, ts, S, total = self._lp_tab

@@ -208,6 +208,11 @@ class ArenaAdamW(_ArenaOptimizer):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(a.data.device))  # the block's backward, incl. its dW join
         self._stream.wait_event(ev)
+        # ... unless the block's dW products were deferred to the library's weight-gradient stream
+        # (SSL4GIE_WGRAD_GROUP): wait for the latest group of either slot, as DataParallel does
+        L = _lib.load()
+        for slot in (0, 1):
+            L.ssl4gie_wgrad_wait(slot, self._stream.cuda_stream)
         self._launch(a, lo, hi, self._stream.cuda_stream)
         self._done.append((lo, hi))
 

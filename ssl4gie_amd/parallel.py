@@ -467,6 +467,10 @@ class DirectAllReduce:
         dist.barrier(group=process_group)  # every rank has mapped every region before the first push
         self.max_elems = int(max_elems)
 
+    def set_timeout(self, seconds: float):
+        """bound of one in-kernel wait for a peer (default 30 s / SSL4GIE_AR_TIMEOUT_S)"""
+        self._check(self.L.ssl4gie_allreduce_direct_set_timeout(self.h, float(seconds)), "allreduce_direct_set_timeout")
+
     def all_reduce_(self, t: torch.Tensor, scale: float, stream=None):
         """t (fp32, contiguous, 16-byte aligned) <- scale * sum over ranks, enqueued on `stream`"""
         assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
@@ -482,12 +486,11 @@ class DirectAllReduce:
         """a peer that never signalled (poll time-out inside a kernel) leaves a sticky error word in
         the handle; enqueue returns it from then on and DataParallel raises instead of stepping on
         stale sums"""
-        err = getattr(self.L, "ssl4gie_allreduce_direct_error", None)
-        if err is not None and self.h:
-            rc = err(self.h)
-            if rc:
-                raise RuntimeError(f"ssl4gie direct all-reduce: a peer did not arrive in time (error word {rc}); "
-                                   "gradients of this step are not reduced")
+        rc = self.L.ssl4gie_allreduce_direct_error(self.h) if self.h else 0
+        if rc:
+            raise RuntimeError(f"ssl4gie direct all-reduce: rank {(rc & 255) - 1} did not arrive in time in "
+                               f"collective #{rc >> 8}; the gradients of that step were poisoned with NaN, "
+                               "not reduced")
 
     def close(self):
         if self.h:

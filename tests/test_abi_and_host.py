@@ -217,8 +217,20 @@ def test_checkpoint_files_with_non_tensor_payload_load(tmp_path):
     f2 = tmp_path / "finetune.pth"
     torch.save({"model_state_dict": sd, "py_state": random.getstate(), "np_state": np.random.get_state(),
                 "torch_state": torch.get_rng_state()}, f2)
+    torch.save({"model_state_dict": sd, "py_state": random.getstate(), "np_state": np.random.get_state(),
+                "torch_state": torch.get_rng_state(), "loss": np.float64(0.25), "val_perf": np.float32(1.5)}, f2)
     ck = checkpoints.load_file(str(f2))
     assert torch.equal(checkpoints._unwrap(ck)["blocks.0.norm1.weight"], sd["blocks.0.norm1.weight"])
+    assert float(ck["loss"]) == 0.25 and np.array_equal(ck["np_state"][1], np.random.get_state()[1])
+    # anything beyond the reference's known payload is refused, not silently unpickled:
+    # only an explicit opt-in runs the unrestricted loader
+    import fractions
+    f3 = tmp_path / "other.pth"
+    torch.save({"model": sd, "extra": {"a": fractions.Fraction(1, 1)}}, f3)
+    with pytest.raises(RuntimeError, match="trusted"):
+        checkpoints.load_file(str(f3))
+    with pytest.warns(UserWarning):
+        assert checkpoints.load_file(str(f3), trusted=True)["extra"]["a"] == 1
 
 
 def test_augreg_npz_loader_round_trip(tmp_path, monkeypatch):

@@ -84,6 +84,68 @@ def test_direct_allreduce_two_processes_one_device():
         assert ok, (rank, detail)
 
 
+def _timeout_worker(rank, world, port, q):
+    """rank 1 never enqueues the second bucket: rank 0's waiting kernels give up after the (shortened)
+    bound, poison their output with NaN instead of passing stale sums on, and leave the sticky error
+    word that every later enqueue returns"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from ssl4gie_amd.parallel import DirectAllReduce
+    out = {}
+    try:
+        ar = DirectAllReduce(max_elems=1 << 16)
+        ar.set_timeout(0.5)
+        g = torch.full((1000,), float(rank + 1), device="cuda")
+        ar.all_reduce_(g, 1.0)                    # both ranks: fine
+        torch.cuda.synchronize()
+        out["first_ok"] = bool((g == 3.0).all())
+        ar.raise_if_failed()
+        if rank == 0:
+            g2 = torch.ones(1000, device="cuda")
+            ar.all_reduce_(g2, 1.0)               # the peer never comes
+            torch.cuda.synchronize()
+            out["poisoned"] = bool(torch.isnan(g2).any())
+            out["word"] = int(ar.L.ssl4gie_allreduce_direct_error(ar.h))
+            try:
+                ar.raise_if_failed()
+                out["raised"] = False
+            except RuntimeError as e:
+                out["raised"] = "rank 1" in str(e)
+            try:
+                ar.all_reduce_(g2, 1.0)
+                out["sticky"] = False
+            except RuntimeError:
+                out["sticky"] = True
+        dist.barrier()
+        ar.close()
+    except Exception as e:  # noqa
+        out["error"] = repr(e)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_direct_allreduce_reports_a_peer_that_never_signals():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert "error" not in res[0] and "error" not in res[1], res
+    assert res[0]["first_ok"] and res[1]["first_ok"]
+    assert res[0]["poisoned"] and res[0]["raised"] and res[0]["sticky"], res[0]
+    assert res[0]["word"] & 255 == 2 and res[0]["word"] >> 8 == 2, res[0]   # peer rank 1, collective #2
+
+
 def _dp_worker(rank, world, port, q, transport):
     import torch.distributed as dist
     import torch.nn as nn

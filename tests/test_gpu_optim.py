@@ -276,3 +276,38 @@ def test_bf16_training_curve_is_the_same_under_fused_and_foreach_adamw():
     a, b = curves
     assert a[-1] < 0.8 * a[0], a  # it trains
     assert max(abs(x - y) for x, y in zip(a, b)) < 2e-2 * a[0], (a, b)
+
+
+def test_operand_copies_after_arena_step_then_load_state_dict():
+    """ADVICE r2 (engine.py:117): ArenaAdamW.step() marks the flat bf16 shadow current for the new
+    epoch; a load_state_dict() before the next forward moves only Tensor._version.  The refresh must
+    not skip the flat cast then (forward would use the optimizer's W, the data gradient the loaded
+    W^T): every operand copy equals the loaded weights and the loss equals a fresh model's."""
+    from ssl4gie_amd.Models.mae import models_mae
+    from ssl4gie_amd.optim import ArenaAdamW
+
+    def make():
+        torch.manual_seed(3)
+        return models_mae.MaskedAutoencoderViT(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2,
+                                               decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2,
+                                               mlp_ratio=3).to(DEV).set_precision("bf16")
+    model = make()
+    imgs = torch.randn(4, 3, 32, 32, device=DEV)
+    noise = torch.rand(4, 16, device=DEV)
+    opt = ArenaAdamW(model, [p for p in model.parameters() if p.requires_grad], lr=5e-2)
+    for _ in range(2):
+        opt.zero_grad()
+        loss, _, _ = model(imgs, mask_ratio=0.5, noise=noise)
+        loss.backward()
+        opt.step()                       # writes the flat shadow itself, bumps the epoch
+    fresh = make()
+    sd = {k: v.clone() for k, v in fresh.state_dict().items()}
+    model.load_state_dict(sd)            # versions move, the epoch does not
+    loss, _, _ = model(imgs, mask_ratio=0.5, noise=noise)
+    ref, _, _ = fresh(imgs, mask_ratio=0.5, noise=noise)
+    assert float(loss) == float(ref)
+    for name, p in model.named_parameters():
+        if p.ndim == 2 and "pos_embed" not in name:
+            w, wt = model.lp_cache.get(p, torch.bfloat16)
+            r = p.detach().to(torch.bfloat16)
+            assert torch.equal(w, r) and torch.equal(wt, r.t().contiguous()), name
