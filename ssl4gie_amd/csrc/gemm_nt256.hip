@@ -55,7 +55,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                      const float* __restrict__ bias, const float* __restrict__ residual,
                      const long long ldr, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out2,
                      const int accumulate, TC* __restrict__ C, long long ldc, int rbase, int cbase,
-                     int M, int N, int lane, float* __restrict__ colstats) {
+                     int M, int N, int lane, float* __restrict__ colstats, bool sc1 = false) {
     const int r16 = lane & 15, g4 = lane >> 4;
     f32x4 bias4[4];
 #pragma unroll
@@ -71,7 +71,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                                       MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX)) {
         constexpr int AUXF = MODE == SSL4GIE_EPI_DGELU ? 2
                            : (MODE == SSL4GIE_EPI_RELU_MASK_AUX ? 3 : (MODE == SSL4GIE_EPI_ADD_AUX ? 4 : 1));
-        p_store_bf16_aux<FULL, AUXF>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane);
+        p_store_bf16_aux<FULL, AUXF>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane, sc1);
     } else if constexpr (sizeof(TC) == 2) {
         // bf16: stage 16 rows x 64 columns (2 KiB), chunk c of row r at position c ^ (r & 7)
         const int R0 = lane >> 3, Cc = lane & 7;
@@ -95,7 +95,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                 const u32x4 w = *(const u32x4*)(stg + base + R * 128 + ((Cc ^ (R & 7)) << 4));
                 const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
                 if (FULL || (gm < M && gn < N)) {
-                    *(u32x4*)(dst + (size_t)gm * ldc + gn) = w;
+                    p_st16(dst + (size_t)gm * ldc + gn, w, sc1);
                     if constexpr (STATS) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -160,7 +160,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
     } else {
         p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL>(
             acc, stg, alpha, bias4, residual, ldr, MODE == SSL4GIE_EPI_NONE && accumulate, (float*)C,
-            ldc, rbase, cbase, M, N, lane);
+            ldc, rbase, cbase, M, N, lane, sc1);
     }
 }
 
@@ -170,7 +170,11 @@ template <typename TC, int MODE, int CONV, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
     TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e,
-    int dbg_skip_epilogue /* ablation knob: 1 = no epilogue (timing only, wrong output) */,
+    int dbg /* ablation knobs (timing only, wrong output): 1 = no epilogue; 2 = epilogue arithmetic and LDS
+               transposition without any global access; 3 = every global access of the epilogue lands in
+               ONE row per workgroup (L2-resident: store issue without HBM write-back) */,
+    int flags /* bit 0: pre-issue the next-but-one K-tile's last half-tile before the epilogue's stores;
+                 bit 1: walk the tiles in reverse order */,
     ConvK cg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -179,6 +183,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const int G = gridDim.x;
     const int pos = xcd_remap(blockIdx.x, G);
     const int my_tiles = (ntiles - pos + G - 1) / G;
+    const bool f_early = (flags & 1) != 0, f_rev = (flags & 2) != 0;
+    auto tile_of = [&](int ti) { const int tl = pos + ti * G; return f_rev ? ntiles - 1 - tl : tl; };
     const int nk = K / P_BK;
     const int total_kt = my_tiles * nk;
     // epilogue arguments as plain scalars (a by-reference struct ends up on the stack)
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const char* c_zero = (const char*)cg.zero;
     const int c_cpt = c_C / P_BK;  // K-tiles per tap
     auto point_at = [&](int ti) {
-        const int tile = pos + ti * G;
+        const int tile = tile_of(ti);
         const int sm0 = (tile / tiles_n) * P_BM, sn0 = (tile % tiles_n) * P_BN;
         auto offs = [&](int i, int h, bool is_a) -> unsigned {
             const int lr = (wave * 2 + i) * 8 + (lane >> 3);  // local row of the half-tile
@@ -327,6 +333,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         __builtin_amdgcn_s_setprio(0);
     };
 
+    // experiment (SSL4GIE_NT256_SKEW_US): every other workgroup starts `skew` microseconds late, so
+    // that half the chip is in its K-loop while the other half drains its stores
+    if (const int skew = (flags >> 8) & 0xff; skew && (pos & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)skew * 100ull)
+            __builtin_amdgcn_s_sleep(32);
+    }
     // ------------------------------------------------------------------ prologue
     point_at(0);
     issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
@@ -336,7 +349,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
 
+    // vector-memory instructions one wave's epilogue issues for a whole (FULL) tile AFTER the point where
+    // the pre-issue happens, all stores (its own loads are consumed, hence complete, before the last store)
+    constexpr int EPI_STORES = (sizeof(TC) == 4 ? 32
+                                : (MODE == SSL4GIE_EPI_BIAS_GELU || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD ||
+                                   MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
+                                   MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX) ? 32 : 16);
     int c_kt = 0, c_ti = 0;
+    bool pre_issued = false;   // half-tile 3 of K-tile T+1 went out before the previous tile's stores
+    bool stores_behind = false;  // ... and exactly EPI_STORES stores sit between it and this K-tile's issues
     for (int T = 0; T < total_kt; ++T) {
         const int cb = T & 1;
         // ---------------- P0
@@ -350,7 +371,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 0, mi, ks);
         __builtin_amdgcn_sched_barrier(0);
-        issue(I3{});
+        if (!pre_issued) issue(I3{});
+        pre_issued = false;
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // B_h0 reads retired (WAR, see header)
         __builtin_amdgcn_s_barrier();
         mma(I0{}, I0{}, b0);
@@ -382,8 +404,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         issue(I2{});
         // K-tile T+1 must have landed before the next phase reads it; the three half-tiles issued
         // in P1..P3 (of K-tile T+2) may stay in flight
-        if (T + 2 < total_kt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (T + 2 >= total_kt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (stores_behind && !STATS)
+            // first K-tile behind an epilogue whose stores are YOUNGER than every piece of K-tile T+1
+            // (pre-issue): the in-order counter lets them stay in flight for one more K-tile
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EPI_STORES + 6) : "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        stores_behind = false;
         __builtin_amdgcn_s_barrier();
         mma(I1{}, I0{}, b0);
         __builtin_amdgcn_sched_barrier(0);
@@ -392,17 +419,38 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             // epilogue in the next one, where the wr=1 group (one barrier behind) runs its own: the
             // two epilogues overlap instead of costing two MFMA-idle intervals per tile.
             c_kt = 0;
-            const int tile = pos + c_ti * G;
+            const int tile = tile_of(c_ti);
             ++c_ti;
             const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * P_BN;
             if (wr == 0) __builtin_amdgcn_s_barrier();
             char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
-            if (dbg_skip_epilogue) {
+            const bool full = m0 + P_BM <= M && n0 + P_BN <= N;
+            if (f_early && T + 2 < total_kt) {
+                // The A_h1 image of this buffer was last read in P2 (both wave rows retired those reads
+                // at least one barrier ago: header, WAR), so half-tile 3 of K-tile T+2 may go out now,
+                // BEFORE the stores: K-tile T+2 is then complete in front of them in the in-order
+                // vmcnt queue and the first K-tile of the next tile need not wait for the stores.
+                issue(I3{});
+                pre_issued = true;
+                stores_behind = full && dbg == 0;
+            }
+            if (dbg == 1) {
                 asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[7][3][3]));
-            } else if (m0 + P_BM <= M && n0 + P_BN <= N)
+            } else if (dbg == 2) {
+                p_epilogue<TC, MODE, false, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                                                   e_out2, e_accumulate, C, ldc, m0 + wr * 128,
+                                                   n0 + wc * 64, 0, N, lane, e_colstats);
+            } else if (dbg == 3) {
+                const size_t row = (size_t)(pos % (M > 0 ? M : 1));
+                p_epilogue<TC, MODE, true, STATS>(acc, stg, e_alpha, e_bias,
+                                                  e_residual ? e_residual + row * e_ldr : nullptr, 0,
+                                                  e_aux ? e_aux + row * ldc : nullptr,
+                                                  e_out2 ? e_out2 + row * ldc : nullptr, e_accumulate,
+                                                  C + row * ldc, 0, 0, n0 + wc * 64, M, N, lane, e_colstats);
+            } else if (full)
                 p_epilogue<TC, MODE, true, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                   e_out2, e_accumulate, C, ldc, m0 + wr * 128,
-                                                  n0 + wc * 64, M, N, lane, e_colstats);
+                                                  n0 + wc * 64, M, N, lane, e_colstats, (flags & 4) != 0);
             else
                 p_epilogue<TC, MODE, false, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                    e_out2, e_accumulate, C, ldc, m0 + wr * 128,
@@ -471,8 +519,20 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     dim3 grid(ntiles < cus ? ntiles : cus), block(512);
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate,
               d->colstats};
-    static int skip_epi = -1;  // SSL4GIE_NT256_NOEPI=1: ablation (K-loop only; outputs are garbage)
-    if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] == '1') ? 1 : 0; }
+    // SSL4GIE_NT256_NOEPI=1..3: ablations (see the kernel's `dbg`; outputs are garbage)
+    static int skip_epi = -1;
+    if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] >= '1' && s[0] <= '3') ? s[0] - '0' : 0; }
+    // SSL4GIE_NT256_EARLY=0 turns the pre-issue off; SSL4GIE_NT256_SNAKE=1 reverses the tile walk of
+    // every other launch (a consumer then starts with what its producer wrote last)
+    static int early = -1, snake = -1;
+    static unsigned launches = 0;
+    if (early < 0) { const char* s = getenv("SSL4GIE_NT256_EARLY"); early = (s && s[0] == '0') ? 0 : 1; }
+    if (snake < 0) { const char* s = getenv("SSL4GIE_NT256_SNAKE"); snake = (s && s[0] == '1') ? 1 : 0; }
+    static int skew = -1;
+    if (skew < 0) { const char* s = getenv("SSL4GIE_NT256_SKEW_US"); skew = s ? (atoi(s) & 0xff) : 0; }
+    static int sc1 = -1;
+    if (sc1 < 0) { const char* s = getenv("SSL4GIE_NT256_SC1"); sc1 = (s && s[0] == '1') ? 1 : 0; }
+    const int flags = (early ? 1 : 0) | ((snake && (launches++ & 1)) ? 2 : 0) | (sc1 ? 4 : 0) | (skew << 8);
     ConvK ck{};
     if (d->conv) {
         const int rc = ssl4gie_internal_conv_k(d->conv, &ck);
@@ -492,7 +552,7 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         }                                                                                          \
         hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAm,         \
                            (const bf16_t*)d->B, d->sBn, (TC_*)d->C, d->ldc, d->M, d->N, d->K, tn,  \
-                           ntiles, e, skip_epi, ck);                                                \
+                           ntiles, e, skip_epi, flags, ck);                                                \
     } while (0)
     if (d->colstats) {  // bf16, plain epilogue (checked by nt256_ok)
         const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
