@@ -111,14 +111,19 @@ def test_mae_vitb_bf16_close_to_reference():
     assert not bad, bad[:8]
 
 
-def _train_curve(cfg, precision, steps, g):
+def _train_curve(cfg, precision, steps, g, optim="torch"):
+    """optim: "torch" = torch.optim.AdamW (the reference driver's, main_pretrain.py:179-180);
+    "arena" = ssl4gie_amd.optim.ArenaAdamW, bench.py's default, incl. the bf16 operand copies it writes"""
     from oracle import synth
     m, _ = _build(cfg, 0, precision)
     decay = [p for n, p in m.named_parameters() if p.requires_grad and p.ndim > 1 and not n.endswith(".bias")]
     no_decay = [p for n, p in m.named_parameters() if p.requires_grad and not (p.ndim > 1 and not n.endswith(".bias"))]
-    opt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0},
-                             {"params": decay, "weight_decay": 0.05}], lr=float(g["lr"]),
-                            betas=(0.9, 0.95))
+    groups = [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.05}]
+    if optim == "arena":
+        from ssl4gie_amd.optim import ArenaAdamW
+        opt = ArenaAdamW(m, groups, lr=float(g["lr"]), betas=(0.9, 0.95))
+    else:
+        opt = torch.optim.AdamW(groups, lr=float(g["lr"]), betas=(0.9, 0.95))
     b = int(g["batch"])
     losses = []
     for it in range(steps):
@@ -151,13 +156,35 @@ def test_loss_curve_vitb_fp32_100_steps():
     assert err.max() < 1e-3, (int(err.argmax()), float(err.max()))
 
 
-def test_loss_curve_vitb_bf16_tracks_reference():
+def test_loss_curve_vitb_fp32_arena_adamw_100_steps():
+    """the optimizer bench.py actually runs (ArenaAdamW: one kernel over the arena, also emitting the bf16
+    operand copies) against the reference's 100-step curve, at the north_star's 1e-3"""
     from oracle import mae_ref
     g = load_golden("g5_curve_vitb.npz")
     cfg = mae_ref.MAEConfig(**{**mae_ref.VIT_B.__dict__, "norm_pix_loss": True})
-    losses = _train_curve(cfg, "bf16", 40, g)
-    err = np.abs(losses - g["losses"][:40]) / g["losses"][:40]
-    assert err.max() < 2e-2, (int(err.argmax()), float(err.max()))
+    losses = _train_curve(cfg, "fp32", 100, g, optim="arena")
+    err = np.abs(losses - g["losses"]) / g["losses"]
+    assert err.max() < 1e-3, (int(err.argmax()), float(err.max()))
+
+
+# bf16 production engine over the SAME 100 steps as the fp32 gate.  Measured on MI355X (round 3,
+# profiles/r03e_loss_curves.log): max |loss - reference| / reference over the 100 steps = 2.17e-4 with
+# torch.optim.AdamW and 2.18e-4 with ArenaAdamW (at step 1; mean 1.8e-5, final step 2e-6) — inside the
+# north_star's 1e-3 even at bf16 operand precision.  The bar is 1.5x the measurement.
+BF16_CURVE_MEASURED = 2.2e-4
+BF16_CURVE_BAR = 1.5 * BF16_CURVE_MEASURED
+
+
+@pytest.mark.parametrize("optim", ["torch", "arena"])
+def test_loss_curve_vitb_bf16_100_steps(optim):
+    from oracle import mae_ref
+    g = load_golden("g5_curve_vitb.npz")
+    cfg = mae_ref.MAEConfig(**{**mae_ref.VIT_B.__dict__, "norm_pix_loss": True})
+    losses = _train_curve(cfg, "bf16", 100, g, optim=optim)
+    err = np.abs(losses - g["losses"]) / g["losses"]
+    print(f"bf16 curve [{optim}]: max rel deviation {err.max():.3e} at step {int(err.argmax())}, "
+          f"mean {err.mean():.3e}, final {err[-1]:.3e}")
+    assert err.max() < BF16_CURVE_BAR, (int(err.argmax()), float(err.max()))
     assert losses[-1] < 0.75 * losses[0]
 
 

@@ -312,6 +312,52 @@ def test_reference_loop_features_world2():
     assert all(ok for _, ok in res), res
 
 
+def _infonce_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    import torch.nn.functional as F
+    from ssl4gie_amd.Models.moco_v3.moco.builder import MoCo
+    T, n = 0.2, 6
+    g = torch.Generator().manual_seed(77)
+    q_all = torch.randn(world * n, 16, generator=g, dtype=torch.float64)
+    k_all = q_all + 0.5 * torch.randn(world * n, 16, generator=g, dtype=torch.float64)
+    q = q_all[rank * n:(rank + 1) * n].clone().requires_grad_(True)
+    k = k_all[rank * n:(rank + 1) * n].clone()
+    loss = MoCo.contrastive_loss(SimpleNamespace(T=T), q, k)   # keys gathered, labels arange(n) + n * rank
+    loss.backward()
+    # single process, whole batch: every query against every key, label = its own index
+    qa = q_all.clone().requires_grad_(True)
+    logits = F.normalize(qa, dim=1) @ F.normalize(k_all, dim=1).t() / T
+    ref = F.cross_entropy(logits, torch.arange(world * n)) * (2 * T)
+    ref.backward()
+    mean = loss.detach().clone()
+    dist.all_reduce(mean)
+    mean /= world                       # what DDP's gradient averaging and the logged loss see
+    ok = abs(float(mean) - float(ref)) < 1e-12 * abs(float(ref))
+    # DDP averages gradients over ranks; a query only lives on its own rank, so rank r's gradient / world
+    # must be the whole-batch gradient's rows of that rank
+    ok &= torch.allclose(q.grad / world, qa.grad[rank * n:(rank + 1) * n], rtol=1e-10, atol=1e-14)
+    # wrong label offset (the bug the `+ n * rank` guards against) would give a different value on rank 1
+    wrong = F.cross_entropy(F.normalize(q.detach(), dim=1) @ F.normalize(k_all, dim=1).t() / T, torch.arange(n)) * (2 * T)
+    ok &= (rank == 0) == (abs(float(wrong) - float(loss)) < 1e-12)
+    return bool(ok)
+
+
+def _infonce_entry(rank, world, port, q):
+    ok = _infonce_worker(rank, world, port, q)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_infonce_two_ranks_equals_single_process_on_the_concatenated_batch():
+    """reference builder.py:63-73: keys all-gathered without gradient, labels arange(N) + N * rank —
+    the mean over ranks of the per-rank loss is the whole-batch InfoNCE loss, gradients likewise"""
+    res = _run(None, None, None, target=_infonce_entry)
+    assert all(ok for _, ok in res), res
+
+
 def _syncbn_worker(rank, world, port, q):
     import os
     import torch
