@@ -45,125 +45,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-// ---- epilogue of one wave's 128 x 64 sub-tile ---------------------------------------------------
-// acc[mt][nt]: rows rbase + 16 mt + (l & 15), columns cbase + 16 nt + 4 (l >> 4) + 0..3
-// STATS (bf16 C, plain epilogue): per-column sums and sums of squares of the STORED (bf16-rounded)
-// values over the wave's 128 rows -> colstats[(rbase / 128)][{0,1}][N]: the BatchNorm statistics of
-// the layer that follows ride on the producing GEMM instead of costing a pass over the activation.
-template <typename TC, int MODE, bool FULL, bool STATS>
-DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
-                     const float* __restrict__ bias, const float* __restrict__ residual,
-                     const long long ldr, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out2,
-                     const int accumulate, TC* __restrict__ C, long long ldc, int rbase, int cbase,
-                     int M, int N, int lane, float* __restrict__ colstats, bool sc1 = false) {
-    const int r16 = lane & 15, g4 = lane >> 4;
-    f32x4 bias4[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = cbase + 16 * nt + 4 * g4;
-        bias4[nt] = f32x4{0, 0, 0, 0};
-        if constexpr (MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
-                      MODE == SSL4GIE_EPI_BIAS_RESIDUAL || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
-            if (bias && (FULL || n < N)) bias4[nt] = ld4(bias + n);
-        }
-    }
-    if constexpr (sizeof(TC) == 2 && (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
-                                      MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX)) {
-        constexpr int AUXF = MODE == SSL4GIE_EPI_DGELU ? 2
-                           : (MODE == SSL4GIE_EPI_RELU_MASK_AUX ? 3 : (MODE == SSL4GIE_EPI_ADD_AUX ? 4 : 1));
-        p_store_bf16_aux<FULL, AUXF>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane, sc1);
-    } else if constexpr (sizeof(TC) == 2) {
-        // bf16: stage 16 rows x 64 columns (2 KiB), chunk c of row r at position c ^ (r & 7)
-        const int R0 = lane >> 3, Cc = lane & 7;
-        // stage one 16 x 64 bf16 block at byte offset `base` of the wave's staging area
-        auto put = [&](int base, int nt, const f32x4& x) {
-            u32x2 pk;
-            pk[0] = pack_bf2(x[0], x[1]);
-            pk[1] = pack_bf2(x[2], x[3]);
-            const int c = nt * 2 + (g4 >> 1);
-            *(u32x2*)(stg + base + r16 * 128 + ((c ^ (r16 & 7)) << 4) + ((g4 & 1) << 3)) = pk;
-        };
-        float cs[8], cq[8];  // STATS: this lane's 8 columns, summed over the rows it flushes
-        if constexpr (STATS) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
-        }
-        auto flush = [&](int base, bf16_t* __restrict__ dst, int mt) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int R = R0 + 8 * hh;
-                const u32x4 w = *(const u32x4*)(stg + base + R * 128 + ((Cc ^ (R & 7)) << 4));
-                const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
-                if (FULL || (gm < M && gn < N)) {
-                    p_st16(dst + (size_t)gm * ldc + gn, w, sc1);
-                    if constexpr (STATS) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
-                            cs[2 * j] += lo; cq[2 * j] += lo * lo;
-                            cs[2 * j + 1] += hi; cq[2 * j + 1] += hi * hi;
-                        }
-                    }
-                }
-            }
-        };
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const f32x4 v = acc[mt][nt] * alpha + bias4[nt];
-                if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
-                    // gelu(u) and gelu'(u) share exp(-u^2/2) and the erf polynomial
-                    f32x4 g, d;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float cdf, xpdf;
-                        gelu_parts_fast(v[q], cdf, xpdf);
-                        g[q] = v[q] * cdf;
-                        d[q] = cdf + xpdf;
-                    }
-                    put(0, nt, d);
-                    put(2048, nt, g);
-                } else if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU) {
-                    f32x4 g;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] = gelu_fast(v[q]);
-                    put(0, nt, v);
-                    put(2048, nt, g);
-                } else {
-                    put(0, nt, v);
-                }
-            }
-            flush(0, (bf16_t*)C, mt);
-            if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD || MODE == SSL4GIE_EPI_BIAS_GELU)
-                flush(2048, out2, mt);
-        }
-        if constexpr (STATS) {
-            // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row groups
-#pragma unroll
-            for (int o = 8; o < 64; o <<= 1)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    cs[j] += __shfl_xor(cs[j], o, 64);
-                    cq[j] += __shfl_xor(cq[j], o, 64);
-                }
-            const int gn = cbase + 8 * Cc;
-            // a 128-row block that starts past M has no row in colstats (ceil(M / 128) blocks)
-            if (lane < 8 && (FULL || (gn < N && rbase < M))) {
-                float* p = colstats + (size_t)(rbase >> 7) * 2 * N + gn;
-                st4(p, f32x4{cs[0], cs[1], cs[2], cs[3]});
-                st4(p + 4, f32x4{cs[4], cs[5], cs[6], cs[7]});
-                st4(p + N, f32x4{cq[0], cq[1], cq[2], cq[3]});
-                st4(p + N + 4, f32x4{cq[4], cq[5], cq[6], cq[7]});
-            }
-        }
-    } else {
-        p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL>(
-            acc, stg, alpha, bias4, residual, ldr, MODE == SSL4GIE_EPI_NONE && accumulate, (float*)C,
-            ldc, rbase, cbase, M, N, lane, sc1);
-    }
-}
-
 // CONV: 0 = A is a matrix; 1 = A is the implicit 3x3 patch matrix of the map at `A` (geometry cg,
 // header of ssl4gie_conv3x3_geom); 2 = the same with ReLU applied to the A fragments.
 template <typename TC, int MODE, int CONV, bool STATS = false>
@@ -522,11 +403,11 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     // SSL4GIE_NT256_NOEPI=1..3: ablations (see the kernel's `dbg`; outputs are garbage)
     static int skip_epi = -1;
     if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] >= '1' && s[0] <= '3') ? s[0] - '0' : 0; }
-    // SSL4GIE_NT256_EARLY=0 turns the pre-issue off; SSL4GIE_NT256_SNAKE=1 reverses the tile walk of
+    // SSL4GIE_NT256_EARLY=1 turns the pre-issue on (measured null, profiles/r03b); SSL4GIE_NT256_SNAKE=1 reverses the tile walk of
     // every other launch (a consumer then starts with what its producer wrote last)
     static int early = -1, snake = -1;
     static unsigned launches = 0;
-    if (early < 0) { const char* s = getenv("SSL4GIE_NT256_EARLY"); early = (s && s[0] == '0') ? 0 : 1; }
+    if (early < 0) { const char* s = getenv("SSL4GIE_NT256_EARLY"); early = (s && s[0] == '1') ? 1 : 0; }
     if (snake < 0) { const char* s = getenv("SSL4GIE_NT256_SNAKE"); snake = (s && s[0] == '1') ? 1 : 0; }
     static int skew = -1;
     if (skew < 0) { const char* s = getenv("SSL4GIE_NT256_SKEW_US"); skew = s ? (atoi(s) & 0xff) : 0; }
