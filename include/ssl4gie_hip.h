@@ -428,6 +428,13 @@ int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, const float* ga
  *             caller all-reduces sums -> ssl4gie_bn_bwd_apply with 1 / global row count. */
 int ssl4gie_bn_stats(const void* x, float* mean, float* var, float* workspace, int dtype,
                      long long rows, int C, void* stream);
+/* The exchange's arithmetic as ONE launch: gathered [world][2C + 1] = every rank's (mean[C], biased var[C],
+ * row count) -> pooled mean / rstd (ranks may hold different row counts), the total row count (device
+ * scalar) and, if given, the running statistics (unbiased variance, momentum) — what torch.nn.SyncBatchNorm
+ * does between its all_gather and its normalisation kernel. */
+int ssl4gie_bn_combine_stats(const float* gathered, int world, int C, float eps, float momentum,
+                             float* running_mean, float* running_var, float* mean, float* rstd, float* total,
+                             void* stream);
 int ssl4gie_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean,
                           const float* rstd, void* dres, float* sums, int relu, float* workspace,
                           int dtype, long long rows, int C, void* stream);
@@ -569,6 +576,13 @@ int ssl4gie_allreduce_direct_init(int rank, int world, size_t max_elems, void* e
                                   ssl4gie_ar_handle** out);
 int ssl4gie_allreduce_direct_connect(ssl4gie_ar_handle* h, const void* all_blobs);
 int ssl4gie_allreduce_direct_enqueue(ssl4gie_ar_handle* h, float* grad, size_t n_elems, float scale,
+                                     void* stream);
+/* All-gather of n_elems floats per rank over the same handle (n_elems <= ceil(max_elems / world)):
+ * dst[w * n_elems + i] = rank w's src[i], in rank order on every rank; 3 launches, no host synchronisation.
+ * Carries nn.SyncBatchNorm's per-layer (mean, var, count) exchange and its backward sums
+ * (reference Models/moco_v3/main_moco.py:196, Depth_estimation/train_depth.py:225) without an RCCL launch;
+ * use a handle of its own per stream (calls on one handle are ordered by the stream they are enqueued on). */
+int ssl4gie_allgather_direct_enqueue(ssl4gie_ar_handle* h, const float* src, size_t n_elems, float* dst,
                                      void* stream);
 unsigned ssl4gie_allreduce_direct_error(const ssl4gie_ar_handle* h);
 int ssl4gie_allreduce_direct_set_timeout(ssl4gie_ar_handle* h, double seconds);

@@ -88,8 +88,8 @@ class ResNet50(EngineModule):
     def _c1(self, x, conv, join=None):
         """1x1 convolution -> (map, BatchNorm partial statistics of the map or None)"""
         if conv.stride[0] == 2:
-            x = Subsample2Fn.apply(x)
-            join = None  # the pixel pick sits between x and the GEMM: its gradient is not x's
+            x = Subsample2Fn.apply(x, join)  # the pixel pick deposits its scattered gradient in the join
+            join = None  # ... and sits between x and the GEMM: the GEMM's gradient is not x's
         B, H, W, C = x.shape
         r = LinearFn.apply(x.reshape(-1, C), conv.weight, None, self.dtype_, self.dtype_, self.sink(),
                            self.lp_cache, _BN_STATS, join)

@@ -160,6 +160,8 @@ PROTOTYPES = {
     "ssl4gie_allreduce_direct_init": (i32, [i32, i32, sz, vp, C.POINTER(vp)]),
     "ssl4gie_allreduce_direct_connect": (i32, [vp, vp]),
     "ssl4gie_allreduce_direct_enqueue": (i32, [vp, vp, sz, f32, vp]),
+    "ssl4gie_allgather_direct_enqueue": (i32, [vp, vp, sz, vp, vp]),
+    "ssl4gie_bn_combine_stats": (i32, [vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp]),
     "ssl4gie_allreduce_direct_error": (C.c_uint, [vp]),
     "ssl4gie_allreduce_direct_set_timeout": (i32, [vp, C.c_double]),
     "ssl4gie_allreduce_direct_destroy": (i32, [vp]),

@@ -173,6 +173,29 @@ __global__ void ar_gather_kernel(float* __restrict__ grad, size_t n, int me, int
     if (blockIdx.x == 0 && threadIdx.x < (len & 3)) dst[n4 * 4 + threadIdx.x] = src[n4 * 4 + threadIdx.x] + poison;
 }
 
+// all-gather of n floats per rank through the same regions: push (every rank writes its payload into
+// slot [me] of every peer), signal, then wait + copy out in rank order.  Small payloads (SyncBatchNorm's
+// 2C + 1 statistics, <= 33 KB): one workgroup per peer.
+__global__ void ag_push_kernel(const float* __restrict__ src, size_t n, int me, int W, ArPeers peers,
+                               size_t slots_off, size_t chunk_cap) {
+    const int p = blockIdx.y;
+    float* dst = (float*)(peers.region[p] + slots_off) + (size_t)me * chunk_cap;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+    __threadfence_system();
+}
+
+__global__ void ag_collect_kernel(float* __restrict__ dst, size_t n, int me, int W, ArPeers peers,
+                                  size_t slots_off, size_t flag_off, size_t chunk_cap, unsigned seq,
+                                  long long max_spins, unsigned* err) {
+    const bool ok = ar_wait((const unsigned*)(peers.region[me] + flag_off), W, seq, max_spins, err);
+    const int w = blockIdx.y;
+    const float* src = (const float*)(peers.region[me] + slots_off) + (size_t)w * chunk_cap;
+    const float poison = ok ? 0.f : __builtin_nanf("");
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[(size_t)w * n + i] = src[i] + poison;
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" size_t ssl4gie_allreduce_direct_blob_bytes(void) { return sizeof(hipIpcMemHandle_t) + 16; }
 
@@ -267,6 +290,31 @@ extern "C" int ssl4gie_allreduce_direct_enqueue(ssl4gie_ar_handle* h, float* gra
     hipLaunchKernelGGL(ar_signal_kernel, dim3(1), dim3(64), 0, st, peers, fb, me, W, seq);
     hipLaunchKernelGGL(ar_gather_kernel, dim3(bx, W), dim3(256), 0, st, grad, n_elems, me, W, peers, L.result[par],
                        fb, h->chunk_cap, seq, h->max_spins, h->err_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ssl4gie_allgather_direct_enqueue(ssl4gie_ar_handle* h, const float* src, size_t n_elems,
+                                                float* dst, void* stream) {
+    REQUIRE(h && h->connected && src && dst);
+    if (*(volatile unsigned*)h->err_host) return SSL4GIE_EPEER;
+    if (n_elems == 0) return 0;
+    REQUIRE(n_elems <= h->chunk_cap);
+    hipStream_t st = (hipStream_t)stream;
+    const int W = h->world, me = h->rank;
+    const unsigned seq = ++h->seq;
+    const int par = seq & 1;
+    const ArLayout L = ar_layout(W, h->chunk_cap);
+    ArPeers peers;
+    for (int p = 0; p < AR_MAX_WORLD; ++p) peers.region[p] = p < W ? h->region[p] : nullptr;
+    unsigned bx = (unsigned)((n_elems + 1023) / 1024);
+    if (bx > 8) bx = 8;
+    const size_t fa = L.flag_a + (size_t)par * AR_MAX_WORLD * sizeof(unsigned);
+    hipLaunchKernelGGL(ag_push_kernel, dim3(bx, W), dim3(256), 0, st, src, n_elems, me, W, peers, L.slots[par],
+                       h->chunk_cap);
+    hipLaunchKernelGGL(ar_signal_kernel, dim3(1), dim3(64), 0, st, peers, fa, me, W, seq);
+    hipLaunchKernelGGL(ag_collect_kernel, dim3(bx, W), dim3(256), 0, st, dst, n_elems, me, W, peers, L.slots[par],
+                       fa, h->chunk_cap, seq, h->max_spins, h->err_dev);
     LAUNCH_CHECK();
     return 0;
 }

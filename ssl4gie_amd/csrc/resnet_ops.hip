@@ -946,3 +946,45 @@ extern "C" int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x
               workspace, (T*)dx, relu, C, total);
     return 0;
 }
+
+// ---- SyncBatchNorm: pooled statistics out of the gathered per-rank records ----------------------------
+// gathered [W][2C + 1] = (mean_w[C], biased var_w[C], rows_w) of every rank (ranks may hold different
+// row counts): total = sum rows_w, mean = sum rows_w/total mean_w, var = sum rows_w/total (var_w +
+// (mean_w - mean)^2); rstd = rsqrt(var + eps); running statistics with the unbiased factor total/(total-1).
+// One launch instead of ~10 torch kernels on [W, 2C+1] floats per layer; everything stays on the device.
+__global__ void bn_combine_stats_kernel(const float* __restrict__ g, int W, int C, float eps, float momentum,
+                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                        float* __restrict__ total_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rec = 2 * C + 1;
+    float total = 0.f;
+    for (int w = 0; w < W; ++w) total += g[(size_t)w * rec + 2 * C];
+    if (c == 0) *total_out = total;
+    if (c >= C) return;
+    const float inv = 1.f / total;
+    float mean = 0.f;
+    for (int w = 0; w < W; ++w) mean += g[(size_t)w * rec + c] * (g[(size_t)w * rec + 2 * C] * inv);
+    float var = 0.f;
+    for (int w = 0; w < W; ++w) {
+        const float d = g[(size_t)w * rec + c] - mean;
+        var += (g[(size_t)w * rec + C + c] + d * d) * (g[(size_t)w * rec + 2 * C] * inv);
+    }
+    mean_out[c] = mean;
+    rstd_out[c] = rsqrtf(var + eps);
+    if (running_mean) {
+        const float unb = total / fmaxf(total - 1.f, 1.f);
+        running_mean[c] = running_mean[c] * (1.f - momentum) + mean * momentum;
+        running_var[c] = running_var[c] * (1.f - momentum) + var * unb * momentum;
+    }
+}
+
+extern "C" int ssl4gie_bn_combine_stats(const float* gathered, int world, int C, float eps, float momentum,
+                                        float* running_mean, float* running_var, float* mean, float* rstd,
+                                        float* total, void* stream) {
+    REQUIRE(gathered && mean && rstd && total && world >= 1 && C >= 1 && (!running_mean == !running_var));
+    hipLaunchKernelGGL(bn_combine_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gathered,
+                       world, C, eps, momentum, running_mean, running_var, mean, rstd, total);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -467,6 +467,14 @@ class DirectAllReduce:
         dist.barrier(group=process_group)  # every rank has mapped every region before the first push
         self.max_elems = int(max_elems)
 
+    def all_gather_(self, src: torch.Tensor, dst: torch.Tensor, stream=None):
+        """dst [world * n] <- every rank's src [n] (fp32, contiguous), in rank order, enqueued on `stream`"""
+        assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.is_cuda and dst.is_cuda
+        assert src.is_contiguous() and dst.is_contiguous() and dst.numel() == self.world * src.numel()
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        self._check(self.L.ssl4gie_allgather_direct_enqueue(self.h, src.data_ptr(), src.numel(), dst.data_ptr(), st),
+                    "allgather_direct_enqueue")
+
     def set_timeout(self, seconds: float):
         """bound of one in-kernel wait for a peer (default 30 s / SSL4GIE_AR_TIMEOUT_S)"""
         self._check(self.L.ssl4gie_allreduce_direct_set_timeout(self.h, float(seconds)), "allreduce_direct_set_timeout")
@@ -497,6 +505,24 @@ class DirectAllReduce:
             torch.cuda.synchronize()
             self.L.ssl4gie_allreduce_direct_destroy(self.h)
             self.h = None
+
+
+_SYNCBN_EXCHANGE = {}
+
+
+def syncbn_exchange(process_group=None, max_channels: int = 8192):
+    """The node-local exchange SyncBatchNorm layers use when SSL4GIE_SYNCBN=direct: one DirectAllReduce
+    handle of its own (the layers run on the compute stream; the gradient slices have theirs on the comm
+    stream), created on first use — a collective, so every rank reaches it at the same layer.  None when
+    the option is off (torch.distributed carries the statistics then)."""
+    import os
+    if os.environ.get("SSL4GIE_SYNCBN", "").lower() != "direct" or not torch.cuda.is_available():
+        return None
+    key = id(process_group)
+    if key not in _SYNCBN_EXCHANGE:
+        world = dist.get_world_size(process_group)
+        _SYNCBN_EXCHANGE[key] = DirectAllReduce(world * (2 * max_channels + 4), process_group)
+    return _SYNCBN_EXCHANGE[key]
 
 
 def comm_cus() -> int:

@@ -118,19 +118,27 @@ class StemConvFn(torch.autograd.Function):
 
 
 class Subsample2Fn(torch.autograd.Function):
-    """the pixel pick of a stride-2 1x1 convolution (Bottleneck.downsample[0])"""
+    """the pixel pick of a stride-2 1x1 convolution (Bottleneck.downsample[0]).  join: engine.GradJoin of
+    the block input, which also feeds conv1: the scattered gradient is deposited there and summed in
+    conv1's data-gradient GEMM epilogue (EPI_ADD_AUX) instead of by an autograd add kernel over the map."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, join=None):
         ctx.hw = x.shape[1:3]
+        ctx.join = join if (join is not None and join.claim() == "depositor") else None
         return ops.subsample2(x.contiguous())
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.subsample2_bwd(dy.contiguous(), *ctx.hw)
+        g = ops.subsample2_bwd(dy.contiguous(), *ctx.hw)
+        if ctx.join is not None:
+            ctx.join.deposit(g)
+            return None, None
+        return g, None
 
 
-SYNC_BN_COLLECTIVES = [0]  # collectives issued by SyncBatchNorm layers (read by the rehearsal / tests)
+SYNC_BN_COLLECTIVES = [0]  # torch.distributed collectives issued by SyncBatchNorm layers (rehearsal / tests)
+SYNC_BN_DIRECT = [0]       # exchanges carried by the library's peer-to-peer all-gather instead (SSL4GIE_SYNCBN=direct)
 
 
 def combine_batch_stats(mean_l, var_l, count_l, group=None):
@@ -156,6 +164,58 @@ def combine_batch_stats(mean_l, var_l, count_l, group=None):
     mean = (g[:, :C] * wgt).sum(0)
     var = ((g[:, C:2 * C] + (g[:, :C] - mean) ** 2) * wgt).sum(0)
     return mean, var, total
+
+
+def sync_batch_stats(mean_l, var_l, rows, bn, group=None):
+    """SyncBatchNorm's forward exchange -> (mean, rstd, total rows as a 0-d device tensor), running
+    statistics updated.  Default: one torch.distributed all_gather + the pooled combine in torch.  With
+    SSL4GIE_SYNCBN=direct on the GPU: the record goes through the library's peer-to-peer all-gather (three
+    tiny launches, no RCCL call) and ONE kernel does the pooled combine, rstd and the running statistics."""
+    from . import parallel
+    ex = parallel.syncbn_exchange(group) if mean_l.is_cuda else None
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    if ex is None:
+        mean, var, total = combine_batch_stats(mean_l, var_l, rows, group)
+        rstd = torch.rsqrt(var + bn.eps)
+        if bn.running_mean is not None:
+            with torch.no_grad():  # unbiased variance: n / (n - 1), on the device
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (total / (total - 1.0).clamp_(min=1.0)), alpha=mom)
+        return mean, rstd, total
+    from . import _lib
+    C = mean_l.numel()
+    rec = torch.empty(2 * C + 1, dtype=torch.float32, device=mean_l.device)
+    rec[:C] = mean_l
+    rec[C:2 * C] = var_l
+    rec[2 * C] = float(rows)
+    gathered = torch.empty(ex.world * (2 * C + 1), dtype=torch.float32, device=mean_l.device)
+    ex.all_gather_(rec, gathered)
+    SYNC_BN_DIRECT[0] += 1
+    out = torch.empty(2 * C + 1, dtype=torch.float32, device=mean_l.device)
+    mean, rstd, total = out[:C], out[C:2 * C], out[2 * C]
+    rm = bn.running_mean if bn.running_mean is not None else None
+    _lib.check(_lib.load().ssl4gie_bn_combine_stats(
+        gathered.data_ptr(), ex.world, C, float(bn.eps), float(mom), ops.ptr(rm),
+        ops.ptr(bn.running_var if rm is not None else None), mean.data_ptr(), rstd.data_ptr(), total.data_ptr(),
+        ops.stream()), "bn_combine_stats")
+    return mean, rstd, total
+
+
+def sync_sum(sums, group=None):
+    """SyncBatchNorm's backward exchange: element-wise sum over ranks of the [2, C] local sums"""
+    import torch.distributed as dist
+    from . import parallel
+    ex = parallel.syncbn_exchange(group) if sums.is_cuda else None
+    if ex is None:
+        g = sums.clone()
+        dist.all_reduce(g, group=group)
+        SYNC_BN_COLLECTIVES[0] += 1
+        return g
+    flat = sums.contiguous().view(-1)
+    gathered = torch.empty(ex.world * flat.numel(), dtype=torch.float32, device=sums.device)
+    ex.all_gather_(flat, gathered)
+    SYNC_BN_DIRECT[0] += 1
+    return gathered.view(ex.world, -1).sum(0).view_as(sums)   # rank order: bitwise the same on every rank
 
 
 def _sync_group(bn):
@@ -226,13 +286,7 @@ class BatchNormFn(torch.autograd.Function):
                                        True, partials=stats)
         elif training:
             mean_l, var_l = ops.bn_stats(x2, partials=stats)
-            mean, var, total = combine_batch_stats(mean_l, var_l, x2.shape[0], group)
-            rstd = torch.rsqrt(var + bn.eps)
-            if bn.running_mean is not None:
-                mom = bn.momentum if bn.momentum is not None else 0.1
-                with torch.no_grad():  # unbiased variance: n / (n - 1), on the device
-                    bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                    bn.running_var.mul_(1 - mom).add_(var * (total / (total - 1.0).clamp_(min=1.0)), alpha=mom)
+            mean, rstd, total = sync_batch_stats(mean_l, var_l, x2.shape[0], bn, group)
             y, _, _ = ops.bn_fwd(x2, g, b, r2, None, None, 0.0, bn.eps, relu, False, mean, rstd)
         else:
             mean = bn.running_mean
@@ -266,9 +320,7 @@ class BatchNormFn(torch.autograd.Function):
                         tgt.add_(sums[row])
                     else:
                         tgt.copy_(sums[row])
-            gsums = sums.clone()
-            dist.all_reduce(gsums, group=group)
-            SYNC_BN_COLLECTIVES[0] += 1
+            gsums = sync_sum(sums, group)
             gsums /= total  # the 1 / count of the dx formula, folded into the sums on the device
             dx = ops.bn_bwd_apply(dy2, y, x2, gd, mean, rstd, gsums, 1.0, relu)
         gres = dres.view(shp) if has_res else None
