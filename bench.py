@@ -53,7 +53,8 @@ def dp_info(ddp, steps_run):
                    "overlapped_with_backward_per_step": round(ddp.n_overlapped / n, 2),
                    "late_params": ddp.n_late, "transport": ddp.transport,
                    "passes_closed_in_backward": ddp.n_passes,
-                   "syncbn_collectives_per_step": round(resnet_engine.SYNC_BN_COLLECTIVES[0] / n, 1)}}
+                   "syncbn_collectives_per_step": round(resnet_engine.SYNC_BN_COLLECTIVES[0] / n, 1),
+                   "syncbn_direct_exchanges_per_step": round(resnet_engine.SYNC_BN_DIRECT[0] / n, 1)}}
 
 
 def self_launch(argv):

@@ -69,6 +69,7 @@ struct TnSecond {
 #define TN_GROUP_MAX 16
 struct TnExtras {
     int n, total_tiles;
+    int m_inner;  // walk the shorter tile dimension innermost (gemm_tn256.hip)
     TnSecond p[TN_GROUP_MAX - 1];
 };
 int ssl4gie_internal_tn256_group_splits(const ssl4gie_gemm_desc* descs, int n);

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     int tiles_n, int ntiles, int splits, float alpha, int accumulate, float* __restrict__ colsum,
     float* __restrict__ colsum_part, ConvK cg, TnExtras ex) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool tn_m_inner_ok = ex.m_inner != 0;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -74,7 +75,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
             }
         }
     }
-    const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * P_BN;
+    // Consecutive tiles of one K-split sit on one XCD (xcd_remap) and share operand slabs through its
+    // L2: a run of r x c tiles reads r + c slabs, so the run should be as square as possible — the
+    // SHORTER tile dimension is the inner one (a 3 x 12 product walked row by row makes a 27-tile XCD
+    // chunk read 3 + 12 slabs and its 9-tile neighbour 1 + 9; column by column they read 3 + 9 and 3 + 3:
+    // 18 slab reads instead of 25 against a minimum of 15).  SSL4GIE_TN_INNER=n restores the old walk.
+    const int tiles_m = (M + P_BM - 1) / P_BM;
+    const bool m_inner = tiles_m < tiles_n && tn_m_inner_ok;
+    const int m0 = (m_inner ? tile % tiles_m : tile / tiles_n) * P_BM;
+    const int n0 = (m_inner ? tile / tiles_m : tile % tiles_n) * P_BN;
     const int nkt = K / P_BK;
     const int kt0 = (int)((long long)nkt * split / splits);
     const int kt1 = (int)((long long)nkt * (split + 1) / splits);
@@ -414,6 +423,9 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, 
         any_colsum = any_colsum || d2->colsum_a != nullptr;
     }
     sec.n = n - 1;
+    static int m_inner = -1;  // SSL4GIE_TN_INNER=n: the row-by-row tile walk of rounds 1-2 (A/B)
+    if (m_inner < 0) { const char* s = getenv("SSL4GIE_TN_INNER"); m_inner = (s && (s[0] == 'n' || s[0] == 'N')) ? 0 : 1; }
+    sec.m_inner = m_inner;
     dim3 grid((tm * tn + sec.total_tiles) * splits), block(512);
     ConvK ck{};
     if (d->conv) {

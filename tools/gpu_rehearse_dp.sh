@@ -1,7 +1,9 @@
 #!/bin/bash
 # Rehearsal of the multi-rank code path on a ONE-GPU box: 2 ranks share the GPU, collectives go
 # through gloo (RCCL refuses two ranks on one device).  Exercises DataParallel's bucket hooks, comm
-# stream, finish(), SyncBatchNorm exchange and the Barlow Twins all-reduce with real HIP kernels.
+# stream, the in-backward close of a pass (no finish()), the SyncBatchNorm exchange (torch.distributed and
+# the library's peer-to-peer one) and the Barlow Twins all-reduce with real HIP kernels; the last line is
+# `python bench.py --gpus 2` invoked plainly (no torchrun): bench.py starts its own ranks.
 # With SSL4GIE_BENCH_SAME_DATA=1 the 2-rank MAE loss must equal the 1-rank loss at the same batch.
 set -u
 mkdir -p gpurun_out
@@ -13,3 +15,5 @@ echo "== mae 2 ranks (same data), direct all-reduce transport (csrc/allreduce.hi
 echo "== depth 2 ranks"; run2 29512 --workload depth --steps 2 --warmup 1 --batch 16 2>&1 | grep -a "^{\|Error\|error" | cut -c1-600
 echo "== moco 2 ranks (SyncBN)"; run2 29513 --workload moco --steps 2 --warmup 1 --batch 32 2>&1 | grep -a "^{\|Error\|error" | cut -c1-600
 echo "== bt 2 ranks"; run2 29514 --workload bt --steps 2 --warmup 1 --batch 64 2>&1 | grep -a "^{\|Error\|error" | cut -c1-600
+echo "== moco 2 ranks (SyncBN carried by the direct exchange: 0 torch.distributed collectives for it)"; SSL4GIE_SYNCBN=direct run2 29516 --workload moco --steps 2 --warmup 1 --batch 32 2>&1 | grep -a "^{\|Error\|error" | cut -c1-700
+echo "== mae, plain 'python bench.py --gpus 2' (self-launched ranks)"; timeout -k 10 500 python bench.py --gpus 2 --steps 4 --warmup 2 --batch 64 --no-cpu-baseline --prof-steps 0 2>&1 | grep -a "^{" | cut -c1-900
