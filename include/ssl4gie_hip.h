@@ -570,6 +570,10 @@ int ssl4gie_dice_loss(const float* logits, const float* target, float* loss, flo
  *   destroy  unmaps / frees (after the streams that used the handle have drained).
  * init fails (hipError_t) when fine-grained device memory is not available: peer stores and in-kernel
  * flag polls are not coherent on coarse-grained memory, so there is no fallback to it. */
+/* Diagnostics: the in-kernel time stamps of the 256x256 NT kernel (SSL4GIE_NT256_NOEPI=4; csrc/gemm_nt256.hip):
+ * [16 workgroups][16 tiles][5] uint64 ticks of the 100 MHz s_memrealtime counter, copied to host memory. */
+int ssl4gie_debug_nt256_stamps(void* dst, size_t bytes);
+
 typedef struct ssl4gie_ar_handle ssl4gie_ar_handle;
 size_t ssl4gie_allreduce_direct_blob_bytes(void);
 int ssl4gie_allreduce_direct_init(int rank, int world, size_t max_elems, void* export_blob,

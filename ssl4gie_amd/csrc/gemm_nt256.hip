@@ -45,6 +45,20 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// Diagnostics (SSL4GIE_NT256_NOEPI=4): wave 0 of every 16th workgroup stamps s_memrealtime (100 MHz) at five
+// points of every output tile — K-loop start, epilogue start, epilogue end (last store issued), end of the
+// next tile's first K-tile (its counted vmcnt wait has passed) and of its second — into this buffer, read
+// back with ssl4gie_debug_nt256_stamps.  Outputs stay correct; the stamps' own stores perturb a little.
+#define NT256_STAMP_WGS 16
+#define NT256_STAMP_TILES 16
+__device__ unsigned long long g_nt256_stamps[NT256_STAMP_WGS][NT256_STAMP_TILES][5];
+
+extern "C" int ssl4gie_debug_nt256_stamps(void* dst, size_t bytes) {
+    REQUIRE(dst && bytes <= sizeof(g_nt256_stamps));
+    HIP_RET(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_nt256_stamps), bytes));
+    return 0;
+}
+
 // CONV: 0 = A is a matrix; 1 = A is the implicit 3x3 patch matrix of the map at `A` (geometry cg,
 // header of ssl4gie_conv3x3_geom); 2 = the same with ReLU applied to the A fragments.
 template <typename TC, int MODE, int CONV, bool STATS = false>
@@ -236,11 +250,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
                                 : (MODE == SSL4GIE_EPI_BIAS_GELU || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD ||
                                    MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
                                    MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX) ? 32 : 16);
+    const bool stamping = dbg == 4 && wave == 0 && lane == 0 && (blockIdx.x & 15) == 0 && (blockIdx.x >> 4) < NT256_STAMP_WGS;
+    auto stamp = [&](int ti, int k) {
+        if (stamping && ti < NT256_STAMP_TILES) g_nt256_stamps[blockIdx.x >> 4][ti][k] = __builtin_amdgcn_s_memrealtime();
+    };
     int c_kt = 0, c_ti = 0;
     bool pre_issued = false;   // half-tile 3 of K-tile T+1 went out before the previous tile's stores
     bool stores_behind = false;  // ... and exactly EPI_STORES stores sit between it and this K-tile's issues
     for (int T = 0; T < total_kt; ++T) {
         const int cb = T & 1;
+        if (c_kt == 0) stamp(c_ti, 0);
         // ---------------- P0
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -295,6 +314,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         __builtin_amdgcn_s_barrier();
         mma(I1{}, I0{}, b0);
         __builtin_amdgcn_sched_barrier(0);
+        if (c_ti > 0 && c_kt == 0) stamp(c_ti - 1, 3);
+        if (c_ti > 0 && c_kt == 1) stamp(c_ti - 1, 4);
         if (++c_kt == nk) {
             // Output tile finished.  The wr=0 group ends its MMA interval first and runs its
             // epilogue in the next one, where the wr=1 group (one barrier behind) runs its own: the
@@ -304,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             ++c_ti;
             const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * P_BN;
             if (wr == 0) __builtin_amdgcn_s_barrier();
+            stamp(c_ti - 1, 1);
             char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
             const bool full = m0 + P_BM <= M && n0 + P_BN <= N;
             if (f_early && T + 2 < total_kt) {
@@ -336,6 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
                 p_epilogue<TC, MODE, false, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                    e_out2, e_accumulate, C, ldc, m0 + wr * 128,
                                                    n0 + wc * 64, M, N, lane, e_colstats);
+            stamp(c_ti - 1, 2);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -402,7 +425,7 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
               d->colstats};
     // SSL4GIE_NT256_NOEPI=1..3: ablations (see the kernel's `dbg`; outputs are garbage)
     static int skip_epi = -1;
-    if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] >= '1' && s[0] <= '3') ? s[0] - '0' : 0; }
+    if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] >= '1' && s[0] <= '4') ? s[0] - '0' : 0; }
     // SSL4GIE_NT256_EARLY=1 turns the pre-issue on (measured null, profiles/r03b); SSL4GIE_NT256_SNAKE=1 reverses the tile walk of
     // every other launch (a consumer then starts with what its producer wrote last)
     static int early = -1, snake = -1;
