@@ -65,17 +65,6 @@ DEVI bf16x8 p_relu8(bf16x8 v) {
     return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, v), z));
 }
 
-// output stores: plain (write-back: the line stays in the XCD's L2) or, experiment, write-through
-// `sc1` (the line is not kept: no L2 pollution next to a K-loop that lives on L2 hits)
-DEVI void p_st16(void* p, u32x4 v, bool sc1) {
-    if (sc1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-    else *(u32x4*)p = v;
-}
-DEVI void p_st8(void* p, u32x2 v, bool sc1) {
-    if (sc1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-    else *(u32x2*)p = v;
-}
-
 #define P_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // fp32 outputs of one wave's 128 x 64 sub-tile.  acc[mt][nt]: rows rbase + 16 mt + (l & 15),
@@ -88,7 +77,7 @@ template <bool FULL, bool RESID>
 DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f32x4 (&bias4)[4],
                       const float* __restrict__ residual, const long long ldr, const bool accumulate,
                       float* __restrict__ C, const long long ldc, int rbase, int cbase, int M, int N,
-                      int lane, bool sc1 = false) {
+                      int lane) {
     const int r16 = lane & 15, g4 = lane >> 4;
     const int R0 = lane >> 4, Cc = lane & 15;
     const int gn = cbase + 4 * Cc;
@@ -125,7 +114,7 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
             if (FULL || (gm < M && gn < N)) {
                 float* c = C + (size_t)gm * ldc + gn;
                 if (accumulate) w += ld4(c);
-                p_st16(c, __builtin_bit_cast(u32x4, w), sc1);
+                st4(c, w);
             }
         }
         if constexpr (RESID) {
@@ -141,8 +130,7 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
 template <bool FULL, int AUXF>
 DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
                            const bf16_t* __restrict__ aux, bf16_t* __restrict__ C,
-                           const long long ldc, int rbase, int cbase, int M, int N, int lane,
-                           bool sc1 = false) {
+                           const long long ldc, int rbase, int cbase, int M, int N, int lane) {
     const int r16 = lane & 15, g4 = lane >> 4;
     const int R0 = lane >> 4, Cc = lane & 15;
     const int gn = cbase + 4 * Cc;
@@ -186,12 +174,7 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
             } else {
                 w *= u;
             }
-            if (FULL || (gm < M && gn < N)) {
-                u32x2 pk;
-                pk[0] = pack_bf2(w[0], w[1]);
-                pk[1] = pack_bf2(w[2], w[3]);
-                p_st8(C + (size_t)gm * ldc + gn, pk, sc1);
-            }
+            if (FULL || (gm < M && gn < N)) st4(C + (size_t)gm * ldc + gn, w);
         }
         if (mt + PF < 8) fetch(mt + PF, ax[mt % PF]);
     }
@@ -207,7 +190,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                      const float* __restrict__ bias, const float* __restrict__ residual,
                      const long long ldr, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out2,
                      const int accumulate, TC* __restrict__ C, long long ldc, int rbase, int cbase,
-                     int M, int N, int lane, float* __restrict__ colstats, bool sc1 = false) {
+                     int M, int N, int lane, float* __restrict__ colstats) {
     const int r16 = lane & 15, g4 = lane >> 4;
     f32x4 bias4[4];
 #pragma unroll
@@ -223,7 +206,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                                       MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX)) {
         constexpr int AUXF = MODE == SSL4GIE_EPI_DGELU ? 2
                            : (MODE == SSL4GIE_EPI_RELU_MASK_AUX ? 3 : (MODE == SSL4GIE_EPI_ADD_AUX ? 4 : 1));
-        p_store_bf16_aux<FULL, AUXF>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane, sc1);
+        p_store_bf16_aux<FULL, AUXF>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane);
     } else if constexpr (sizeof(TC) == 2) {
         // bf16: stage 16 rows x 64 columns (2 KiB), chunk c of row r at position c ^ (r & 7)
         const int R0 = lane >> 3, Cc = lane & 7;
@@ -247,7 +230,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                 const u32x4 w = *(const u32x4*)(stg + base + R * 128 + ((Cc ^ (R & 7)) << 4));
                 const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
                 if (FULL || (gm < M && gn < N)) {
-                    p_st16(dst + (size_t)gm * ldc + gn, w, sc1);
+                    *(u32x4*)(dst + (size_t)gm * ldc + gn) = w;
                     if constexpr (STATS) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -312,7 +295,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
     } else {
         p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL>(
             acc, stg, alpha, bias4, residual, ldr, MODE == SSL4GIE_EPI_NONE && accumulate, (float*)C,
-            ldc, rbase, cbase, M, N, lane, sc1);
+            ldc, rbase, cbase, M, N, lane);
     }
 }
 

@@ -68,8 +68,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     int dbg /* ablation knobs (timing only, wrong output): 1 = no epilogue; 2 = epilogue arithmetic and LDS
                transposition without any global access; 3 = every global access of the epilogue lands in
                ONE row per workgroup (L2-resident: store issue without HBM write-back) */,
-    int flags /* bit 0: pre-issue the next-but-one K-tile's last half-tile before the epilogue's stores;
-                 bit 1: walk the tiles in reverse order */,
     ConvK cg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -78,8 +76,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const int G = gridDim.x;
     const int pos = xcd_remap(blockIdx.x, G);
     const int my_tiles = (ntiles - pos + G - 1) / G;
-    const bool f_early = (flags & 1) != 0, f_rev = (flags & 2) != 0;
-    auto tile_of = [&](int ti) { const int tl = pos + ti * G; return f_rev ? ntiles - 1 - tl : tl; };
+    auto tile_of = [&](int ti) { return pos + ti * G; };
     const int nk = K / P_BK;
     const int total_kt = my_tiles * nk;
     // epilogue arguments as plain scalars (a by-reference struct ends up on the stack)
@@ -228,13 +225,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // experiment (SSL4GIE_NT256_SKEW_US): every other workgroup starts `skew` microseconds late, so
-    // that half the chip is in its K-loop while the other half drains its stores
-    if (const int skew = (flags >> 8) & 0xff; skew && (pos & 1)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)skew * 100ull)
-            __builtin_amdgcn_s_sleep(32);
-    }
     // ------------------------------------------------------------------ prologue
     point_at(0);
     issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
@@ -244,19 +234,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
 
-    // vector-memory instructions one wave's epilogue issues for a whole (FULL) tile AFTER the point where
-    // the pre-issue happens, all stores (its own loads are consumed, hence complete, before the last store)
-    constexpr int EPI_STORES = (sizeof(TC) == 4 ? 32
-                                : (MODE == SSL4GIE_EPI_BIAS_GELU || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD ||
-                                   MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
-                                   MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX) ? 32 : 16);
     const bool stamping = dbg == 4 && wave == 0 && lane == 0 && (blockIdx.x & 15) == 0 && (blockIdx.x >> 4) < NT256_STAMP_WGS;
     auto stamp = [&](int ti, int k) {
         if (stamping && ti < NT256_STAMP_TILES) g_nt256_stamps[blockIdx.x >> 4][ti][k] = __builtin_amdgcn_s_memrealtime();
     };
     int c_kt = 0, c_ti = 0;
-    bool pre_issued = false;   // half-tile 3 of K-tile T+1 went out before the previous tile's stores
-    bool stores_behind = false;  // ... and exactly EPI_STORES stores sit between it and this K-tile's issues
     for (int T = 0; T < total_kt; ++T) {
         const int cb = T & 1;
         if (c_kt == 0) stamp(c_ti, 0);
@@ -271,8 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 0, mi, ks);
         __builtin_amdgcn_sched_barrier(0);
-        if (!pre_issued) issue(I3{});
-        pre_issued = false;
+        issue(I3{});
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // B_h0 reads retired (WAR, see header)
         __builtin_amdgcn_s_barrier();
         mma(I0{}, I0{}, b0);
@@ -304,13 +285,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         issue(I2{});
         // K-tile T+1 must have landed before the next phase reads it; the three half-tiles issued
         // in P1..P3 (of K-tile T+2) may stay in flight
-        if (T + 2 >= total_kt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (stores_behind && !STATS)
-            // first K-tile behind an epilogue whose stores are YOUNGER than every piece of K-tile T+1
-            // (pre-issue): the in-order counter lets them stay in flight for one more K-tile
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EPI_STORES + 6) : "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        stores_behind = false;
+        if (T + 2 < total_kt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         mma(I1{}, I0{}, b0);
         __builtin_amdgcn_sched_barrier(0);
@@ -328,15 +304,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             stamp(c_ti - 1, 1);
             char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
             const bool full = m0 + P_BM <= M && n0 + P_BN <= N;
-            if (f_early && T + 2 < total_kt) {
-                // The A_h1 image of this buffer was last read in P2 (both wave rows retired those reads
-                // at least one barrier ago: header, WAR), so half-tile 3 of K-tile T+2 may go out now,
-                // BEFORE the stores: K-tile T+2 is then complete in front of them in the in-order
-                // vmcnt queue and the first K-tile of the next tile need not wait for the stores.
-                issue(I3{});
-                pre_issued = true;
-                stores_behind = full && dbg == 0;
-            }
             if (dbg == 1) {
                 asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[7][3][3]));
             } else if (dbg == 2) {
@@ -353,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             } else if (full)
                 p_epilogue<TC, MODE, true, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                   e_out2, e_accumulate, C, ldc, m0 + wr * 128,
-                                                  n0 + wc * 64, M, N, lane, e_colstats, (flags & 4) != 0);
+                                                  n0 + wc * 64, M, N, lane, e_colstats);
             else
                 p_epilogue<TC, MODE, false, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                    e_out2, e_accumulate, C, ldc, m0 + wr * 128,
@@ -426,17 +393,6 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     // SSL4GIE_NT256_NOEPI=1..3: ablations (see the kernel's `dbg`; outputs are garbage)
     static int skip_epi = -1;
     if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] >= '1' && s[0] <= '4') ? s[0] - '0' : 0; }
-    // SSL4GIE_NT256_EARLY=1 turns the pre-issue on (measured null, profiles/r03b); SSL4GIE_NT256_SNAKE=1 reverses the tile walk of
-    // every other launch (a consumer then starts with what its producer wrote last)
-    static int early = -1, snake = -1;
-    static unsigned launches = 0;
-    if (early < 0) { const char* s = getenv("SSL4GIE_NT256_EARLY"); early = (s && s[0] == '1') ? 1 : 0; }
-    if (snake < 0) { const char* s = getenv("SSL4GIE_NT256_SNAKE"); snake = (s && s[0] == '1') ? 1 : 0; }
-    static int skew = -1;
-    if (skew < 0) { const char* s = getenv("SSL4GIE_NT256_SKEW_US"); skew = s ? (atoi(s) & 0xff) : 0; }
-    static int sc1 = -1;
-    if (sc1 < 0) { const char* s = getenv("SSL4GIE_NT256_SC1"); sc1 = (s && s[0] == '1') ? 1 : 0; }
-    const int flags = (early ? 1 : 0) | ((snake && (launches++ & 1)) ? 2 : 0) | (sc1 ? 4 : 0) | (skew << 8);
     ConvK ck{};
     if (d->conv) {
         const int rc = ssl4gie_internal_conv_k(d->conv, &ck);
@@ -456,7 +412,7 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         }                                                                                          \
         hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAm,         \
                            (const bf16_t*)d->B, d->sBn, (TC_*)d->C, d->ldc, d->M, d->N, d->K, tn,  \
-                           ntiles, e, skip_epi, flags, ck);                                                \
+                           ntiles, e, skip_epi, ck);                                                \
     } while (0)
     if (d->colstats) {  // bf16, plain epilogue (checked by nt256_ok)
         const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
