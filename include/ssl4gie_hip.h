@@ -14,9 +14,10 @@
  *   - returns 0 on success, SSL4GIE_EARG (1000) for an invalid argument, otherwise a hipError_t;
  *   - callable from any host thread; the only mutable process-wide settings are the execution
  *     options ssl4gie_set_wgrad_stream / ssl4gie_set_compute_cus and the profiler;
- *   - ssl4gie_abi_version() = 3 (1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`; 2: before
+ *   - ssl4gie_abi_version() = 4 (1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`; 2: before
  *     ssl4gie_block_bwd's `accumulate` became a flag word and the grouped / deferred weight-gradient
- *     entry points existed);
+ *     entry points existed; 3: before the direct transport's error word / time-out / all-gather,
+ *     ssl4gie_bn_combine_stats and ssl4gie_debug_nt256_stamps existed — additions only);
  *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
  *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
  */

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libssl4gie_hip.so")
 
 # the one copy of the ABI revision on the Python side: build(), the tests and load() compare the
 # library's ssl4gie_abi_version() with it (include/ssl4gie_hip.h documents the history)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F32, BF16 = 0, 1
 BWD_ACCUMULATE, BWD_DEFER_WGRAD = 1, 2
