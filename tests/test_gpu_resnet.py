@@ -254,8 +254,17 @@ def test_gemm_colstats_match_the_stored_outputs(T, K, N):
     assert rel_err(m2, m1) < 1e-4 and rel_err(v2, v1) < 1e-4
 
 
+# bf16 engine on the same well-conditioned blocks: measured worst errors over the three blocks (round 3,
+# profiles/r03p_bottleneck_fp32_bf16.log: output 8.2e-3, input gradient 6.2e-3, parameter gradients 2.5e-2 of the
+# largest gradient of their kind) and bars at 1.5x them; with no mask flips what remains is operand rounding
+# (8 significant bits, ~6 roundings per bottleneck) — the loose 15-30 % bars of the random-init trunk tests
+# above are conditioning, not arithmetic.  The fp32 engine's own numbers on these blocks: 9e-7 / 9e-7 / 1.2e-4.
+BF16_BLOCK_MEASURED = {"out": 8.2e-3, "dx": 6.2e-3, "param": 2.5e-2}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("layer,idx,hw", [("layer1", 1, 28), ("layer2", 0, 28), ("layer3", 0, 14)])
-def test_bottleneck_well_conditioned_fp32_every_gradient_1e3(layer, idx, hw):
+def test_bottleneck_well_conditioned_fp32_every_gradient_1e3(layer, idx, hw, precision):
     """One torchvision Bottleneck (v1.5: stride on the 3x3; `Models/models.py:63-69`) in training mode on an
     input where NO ReLU pre-activation lies within 1e-2 of zero: the BatchNorm shifts are +-6 / +-12 per
     channel (half the channels always on, half always off), so no mask can flip between two evaluations
@@ -275,7 +284,9 @@ def test_bottleneck_well_conditioned_fp32_every_gradient_1e3(layer, idx, hw):
                 big = 12.0 if name in ("bn3",) else (0.0 if name.startswith("downsample") else 6.0)
                 mod.weight.copy_(0.8 + 0.4 * torch.rand(c, generator=g))
                 mod.bias.copy_(big * sign + 0.1 * torch.randn(c, generator=g))
-    net.to(DEV).set_precision("fp32")
+    net.to(DEV).set_precision(precision)
+    bars = {"out": 1e-3, "dx": 1e-3, "param": 1e-3} if precision == "fp32" else \
+        {k: 1.5 * v for k, v in BF16_BLOCK_MEASURED.items()}
     cin = blk.conv1.weight.shape[1]
     stride, has_down = blk.conv2.stride[0], blk.downsample is not None
     x = torch.randn(4, cin, hw, hw, generator=g)
@@ -297,11 +308,13 @@ def test_bottleneck_well_conditioned_fp32_every_gradient_1e3(layer, idx, hw):
     dy = torch.randn(yr.shape, generator=g).double()
     yr.backward(dy)
     net._prepare()
-    xd = nhwc(x).to(DEV).requires_grad_(True)
+    dt = torch.float32 if precision == "fp32" else torch.bfloat16
+    xd = nhwc(x).to(DEV).to(dt).requires_grad_(True)
     y = net._block(xd, blk)
-    y.backward(nhwc(dy.float()).to(DEV))
-    assert rel_err(nchw(y.detach().cpu()), yr.detach()) < 1e-3
-    assert rel_err(nchw(xd.grad.cpu()), xr.grad) < 1e-3
+    y.backward(nhwc(dy.float()).to(DEV).to(dt))
+    e_out, e_dx = rel_err(nchw(y.detach().float().cpu()), yr.detach()), rel_err(nchw(xd.grad.float().cpu()), xr.grad)
+    assert e_out < bars["out"], e_out
+    assert e_dx < bars["dx"], e_dx
     # Some gradients are analytically ZERO here (a BatchNorm shift in front of an always-on ReLU, a linear
     # convolution and another BatchNorm is removed by that BatchNorm's mean subtraction: bn2.bias, half of
     # bn1.bias; the fp64 reference holds 1e-13 there): an error relative to the tensor's own maximum means
@@ -311,12 +324,18 @@ def test_bottleneck_well_conditioned_fp32_every_gradient_1e3(layer, idx, hw):
     scale = {}
     for name, _ in blk.named_parameters():
         scale[kind(name)] = max(scale.get(kind(name), 0.0), float(sd[name].grad.abs().max()))
-    n = 0
+    n, worst = 0, 0.0
     for name, p in blk.named_parameters():
         assert p.grad is not None, name
         ref = sd[name].grad
-        den = max(float(ref.abs().max()), 1e-2 * scale[kind(name)])
+        # bf16: the analytically-zero gradients are sums of ~1e3 terms rounded to 8 bits each; they are judged
+        # against the largest gradient of their kind (floor 1.0), the fp32 engine against 1e-2 of it
+        den = max(float(ref.abs().max()), (1e-2 if precision == "fp32" else 1.0) * scale[kind(name)])
         err = float((p.grad.double().cpu() - ref).abs().max()) / den
-        assert err < 1e-3, (name, err)
+        worst = max(worst, err)
+        if precision == "fp32":
+            assert err < bars["param"], (name, err)
         n += 1
     assert n == (12 if has_down else 9)
+    assert worst < bars["param"], worst
+    print(f"bottleneck[{layer}.{idx} {precision}]: out {e_out:.2e} dx {e_dx:.2e} worst parameter gradient {worst:.2e}")
