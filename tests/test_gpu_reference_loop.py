@@ -91,7 +91,7 @@ def _depth_loop(rank, world, verbatim, steps=4):
     return losses, info
 
 
-def _mae_loop(rank, world, verbatim, steps=6, accum_iter=2):
+def _mae_loop(rank, world, verbatim, steps=6, accum_iter=2, arena=False):
     """engine_pretrain.py:39-69 with misc.NativeScalerWithGradNormCount (misc.py:251-271)"""
     import torch.distributed as dist
     from functools import partial
@@ -108,7 +108,12 @@ def _mae_loop(rank, world, verbatim, steps=6, accum_iter=2):
     model.cuda(0).set_precision("fp32")
     model_without_ddp = model
     model = DataParallel(model, device_ids=[0], find_unused_parameters=True)   # main_pretrain.py:175
-    optimizer = torch.optim.AdamW(model_without_ddp.parameters(), lr=1.5e-4, betas=(0.9, 0.95))
+    if arena:   # the bench's optimizer behind the same GradScaler statements (duck-typed param_groups / step)
+        from ssl4gie_amd.optim import ArenaAdamW
+        optimizer = ArenaAdamW(model_without_ddp, [p for p in model_without_ddp.parameters() if p.requires_grad],
+                               lr=1.5e-4, betas=(0.9, 0.95))
+    else:
+        optimizer = torch.optim.AdamW(model_without_ddp.parameters(), lr=1.5e-4, betas=(0.9, 0.95))
     _scaler = torch.cuda.amp.GradScaler()
 
     def loss_scaler(loss, optimizer, parameters=None, update_grad=True):   # misc.py:257-271
@@ -207,6 +212,7 @@ def _worker(rank, world, port, q):
         out["depth_plain"] = _depth_loop(rank, world, False)
         out["mae_verbatim"] = _mae_loop(rank, world, True)
         out["mae_plain"] = _mae_loop(rank, world, False)
+        out["mae_arena"] = _mae_loop(rank, world, True, arena=True)
         out["mae_grad"] = _mae_grad_two_ranks_vs_one(rank, world)
     except Exception as e:  # noqa: BLE001 - reported to the parent
         import traceback
@@ -243,6 +249,8 @@ def test_reference_statement_sequences_two_ranks_one_device():
         assert np.allclose(mv, mp_, rtol=1e-4), (mv, mp_)
         assert np.allclose(nv, np_, rtol=1e-3), (nv, np_)
         assert jv["passes"] == 6 and jp["passes"] == 6 and jv["same"] and jp["same"]
+        ma, na, ja = res[r]["mae_arena"]     # ArenaAdamW under the scaler == torch.optim.AdamW under the scaler
+        assert np.allclose(ma, mv, rtol=1e-4) and np.allclose(na, nv, rtol=1e-3) and ja["passes"] == 6 and ja["same"]
         worst, overlapped = res[r]["mae_grad"]
         assert worst < 1e-4, worst
         assert overlapped >= 1
