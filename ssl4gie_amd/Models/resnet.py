@@ -115,6 +115,18 @@ class ResNet50(EngineModule):
             join = None  # bn3's residual input is the downsample branch, not x
         return self._bn(out, blk.bn3, True, res=identity, stats=st, join=join)  # relu(bn3(out) + identity)
 
+    def prepare_inputs(self, imgs):
+        """build the per-batch stem operand (bf16: the packed image) on the CURRENT stream, so that two
+        forward passes over the same batch on different streams only read it (moco/builder.py)"""
+        from .. import ops
+        from ..resnet_engine import STEM_COLS, _STEM_DIRECT
+        if imgs.dtype != torch.float32 or not imgs.is_contiguous():
+            return  # StemConvFn makes its own copy: nothing is shared between the passes
+        if _STEM_DIRECT and self.dtype_ == torch.bfloat16 and self.conv1.weight.shape[0] == 64 and imgs.shape[1] == 3:
+            STEM_COLS.get(imgs, self.dtype_, ops.stem7x7_pack)
+        else:
+            STEM_COLS.get(imgs, self.dtype_)   # the patch matrix (fp32 parity mode)
+
     def forward_maps(self, imgs, all_stages=False):
         self._prepare()
         r = StemConvFn.apply(imgs, self.conv1.weight, self.dtype_, self.sink(), self.lp_cache, _BN_STATS)

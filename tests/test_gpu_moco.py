@@ -139,3 +139,47 @@ def test_momentum_encoder_uses_updated_weights_after_ema():
         kb = m.encode(m.base_encoder, x1)
         km = m.encode(m.momentum_encoder, x1)
     assert rel_err(km, kb) < 1e-6
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_momentum_branch_on_a_side_stream_is_the_same_arithmetic(precision, monkeypatch):
+    """By default (SSL4GIE_MOCO_OVERLAP != 0) the momentum encoder's two forward passes run on a second stream beside the
+    base encoder's (momentum update first: it only reads base weights, which the forward does not change —
+    the reference's order, builder.py:75-96, gives the same numbers).  Three optimizer steps with and without:
+    losses, every gradient, the momentum weights and BatchNorm running statistics must be IDENTICAL bit for
+    bit (same kernels, same operands; any difference is a race between the streams)."""
+    from ssl4gie_amd.Models.moco_v3.moco.optimizer import LARS
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.randn(16, 3, 96, 96, generator=g).to(DEV)
+    x2 = torch.randn(16, 3, 96, 96, generator=g).to(DEV)
+
+    def run(overlap):
+        monkeypatch.setenv("SSL4GIE_MOCO_OVERLAP", "1" if overlap else "0")
+        m = _moco()
+        with torch.no_grad():
+            for name, p in m.named_parameters():
+                if name.endswith("bn3.weight"):
+                    p.fill_(0.5)
+        m.to(DEV).set_precision(precision)
+        opt = LARS([p for p in m.parameters() if p.requires_grad], lr=0.05, weight_decay=1e-6, momentum=0.9)
+        out = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = m(x1, x2, 0.99)
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            out.append(loss.detach().cpu().clone())
+        grads = [p.grad.detach().cpu().clone() for p in m.parameters() if p.grad is not None]
+        mom = [p.detach().cpu().clone() for p in m.momentum_encoder.parameters()]
+        stats = [b.detach().cpu().clone() for n, b in m.named_buffers() if "running" in n]
+        return out, grads, mom, stats
+
+    a = run(False)
+    b = run(True)
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y), (float(x), float(y))
+    for part in (1, 2, 3):
+        assert len(a[part]) == len(b[part]) and len(a[part]) > 50
+        for x, y in zip(a[part], b[part]):
+            assert torch.equal(x, y)
