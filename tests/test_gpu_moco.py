@@ -183,3 +183,39 @@ def test_momentum_branch_on_a_side_stream_is_the_same_arithmetic(precision, monk
         assert len(a[part]) == len(b[part]) and len(a[part]) > 50
         for x, y in zip(a[part], b[part]):
             assert torch.equal(x, y)
+
+
+def test_momentum_branch_on_a_side_stream_vit(monkeypatch):
+    """the same for MoCo_ViT (reference builder.py:112-123 on vits.py): block executor, patch embedding and
+    the operand-copy cache are shared host-side state of the two branches"""
+    from ssl4gie_amd.Models.moco_v3 import vits
+    from ssl4gie_amd.Models.moco_v3.moco import builder
+    g = torch.Generator().manual_seed(6)
+    x1 = torch.randn(8, 3, 224, 224, generator=g).to(DEV)
+    x2 = torch.randn(8, 3, 224, 224, generator=g).to(DEV)
+
+    def run(overlap):
+        monkeypatch.setenv("SSL4GIE_MOCO_OVERLAP", "1" if overlap else "0")
+        torch.manual_seed(0)
+        m = builder.MoCo_ViT(partial(vits.VisionTransformerMoCo, embed_dim=192, depth=2, num_heads=3), 64, 256, 0.2)
+        m.to(DEV).set_precision("bf16")
+        opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        out = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = m(x1, x2, 0.99)
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            out.append(loss.detach().cpu().clone())
+        grads = [p.grad.detach().cpu().clone() for p in m.parameters() if p.grad is not None]
+        mom = [p.detach().cpu().clone() for p in m.momentum_encoder.parameters()]
+        return out, grads, mom
+
+    a, b = run(False), run(True)
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y), (float(x), float(y))
+    for part in (1, 2):
+        assert len(a[part]) == len(b[part]) and len(a[part]) > 10
+        for x, y in zip(a[part], b[part]):
+            assert torch.equal(x, y)
