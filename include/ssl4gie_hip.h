@@ -315,6 +315,17 @@ int ssl4gie_set_compute_cus(int n);
  *   act = ReLU if `relu` (ResidualConvUnit_custom.forward :225-229 activates the conv INPUT);
  *   row stride ld >= 9C, columns [9C, ld) zero-filled; s in {1, 2} (act_postprocess42.1 :397-403).
  * col2im3x3: gather-form transpose (data gradient of the strided conv). */
+/* Operand images of an nn.Conv2d(k = 3) weight [Cout][Cin][3][3] (fp32 parameter) in one launch, cast included:
+ * mode 0 out[co][tap Cin + ci] (row stride ld >= 9 Cin: forward / weight-gradient layout), mode 1
+ * out[ci][(8 - tap) Cout + co] (ld >= 9 Cout: the flipped kernel of the stride-1 data gradient), mode 2
+ * out[tap Cin + ci][co] (ld >= 9 Cin rows: transpose of mode 0); padding is written as zeros.  What cuDNN's
+ * filter transforms do behind the reference's nn.Conv2d calls (Models/DPT_decoder.py:212-233,397-447,469-478;
+ * torchvision Bottleneck.conv2), once per optimizer step. */
+int ssl4gie_conv3x3_weight_pack(const float* w, void* out, int dtype, int Cout, int Cin, int mode, int ld,
+                                void* stream);
+/* ... and back for the weight gradient: dw2 [Cout][ld] fp32 with columns (tap, ci) -> (+)= dW [Cout][Cin][3][3] */
+int ssl4gie_conv3x3_wgrad_unpack(const float* dw2, float* dw, int Cout, int Cin, int ld, int accumulate,
+                                 void* stream);
 int ssl4gie_im2col3x3(const void* x, void* cols, int dtype, int B, int H, int W, int C, int stride,
                       int relu, long long ld, void* stream);
 int ssl4gie_col2im3x3(const void* dcols, void* dx, int dtype, int B, int H, int W, int C,

@@ -498,3 +498,70 @@ extern "C" int ssl4gie_depth_head_bwd(const void* x, const float* w, const float
     if (rc) return rc;
     return ssl4gie_internal_reduce_partials(workspace + C, db, nb, 1, (size_t)(C + 1), accumulate, st);
 }
+
+// ---- operand images of a Conv2d(k = 3) weight ---------------------------------------------------------
+// w [Cout][Cin][3][3] fp32 (the parameter) -> the GEMM / direct-kernel operand in ONE launch (cast included):
+//   mode 0  out[co][tap * Cin + ci]            row stride ld >= 9 Cin   (forward, weight-gradient layout)
+//   mode 1  out[ci][(8 - tap) * Cout + co]     row stride ld >= 9 Cout  (data gradient: flipped kernel)
+//   mode 2  out[tap * Cin + ci][co]            rows ld >= 9 Cin         (transpose of mode 0: stride-2 data gradient)
+// padding columns / rows are written as zeros.  Replaces a torch permute-copy (+ flip) + cast per operand and
+// optimizer step (reference: the cuDNN filter transforms behind nn.Conv2d, Models/DPT_decoder.py:212-233,
+// torchvision Bottleneck.conv2).
+template <typename TO>
+__global__ void conv3x3_weight_pack_kernel(const float* __restrict__ w, TO* __restrict__ out, int Cout, int Cin,
+                                           int mode, int ld, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float v = 0.f;
+    if (mode == 0) {
+        const int co = (int)(i / ld), k = (int)(i % ld);
+        if (k < 9 * Cin) { const int tap = k / Cin, ci = k - tap * Cin; v = w[((size_t)co * Cin + ci) * 9 + tap]; }
+    } else if (mode == 1) {
+        const int ci = (int)(i / ld), k = (int)(i % ld);
+        if (k < 9 * Cout) { const int ft = k / Cout, co = k - ft * Cout; v = w[((size_t)co * Cin + ci) * 9 + (8 - ft)]; }
+    } else {
+        const int k = (int)(i / Cout), co = (int)(i % Cout);
+        if (k < 9 * Cin) { const int tap = k / Cin, ci = k - tap * Cin; v = w[((size_t)co * Cin + ci) * 9 + tap]; }
+    }
+    if constexpr (sizeof(TO) == 2) out[i] = f2bf(v);
+    else out[i] = v;
+}
+
+extern "C" int ssl4gie_conv3x3_weight_pack(const float* w, void* out, int dtype, int Cout, int Cin, int mode, int ld,
+                                           void* stream) {
+    REQUIRE(w && out && Cout > 0 && Cin > 0 && mode >= 0 && mode <= 2 && (dtype == SSL4GIE_BF16 || dtype == SSL4GIE_F32));
+    REQUIRE(ld >= 9 * (mode == 1 ? Cout : Cin));
+    const long long total = mode == 0 ? (long long)Cout * ld : (mode == 1 ? (long long)Cin * ld : (long long)ld * Cout);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(conv3x3_weight_pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                           (bf16_t*)out, Cout, Cin, mode, ld, total);
+    else
+        hipLaunchKernelGGL(conv3x3_weight_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                           (float*)out, Cout, Cin, mode, ld, total);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// the inverse for the weight GRADIENT: dw2 [Cout][ld] fp32 (columns (tap, ci), as the TN product / the direct
+// kernels deliver it) -> (+)= dW [Cout][Cin][3][3], the parameter's layout, in one launch
+__global__ void conv3x3_wgrad_unpack_kernel(const float* __restrict__ dw2, float* __restrict__ dw, int Cout, int Cin,
+                                            int ld, int accumulate, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int tap = (int)(i % 9);
+    const long long r = i / 9;
+    const int ci = (int)(r % Cin), co = (int)(r / Cin);
+    const float v = dw2[(size_t)co * ld + tap * Cin + ci];
+    dw[i] = accumulate ? dw[i] + v : v;
+}
+
+extern "C" int ssl4gie_conv3x3_wgrad_unpack(const float* dw2, float* dw, int Cout, int Cin, int ld, int accumulate,
+                                            void* stream) {
+    REQUIRE(dw2 && dw && Cout > 0 && Cin > 0 && ld >= 9 * Cin);
+    const long long total = (long long)Cout * Cin * 9;
+    hipLaunchKernelGGL(conv3x3_wgrad_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dw2, dw, Cout, Cin, ld, accumulate, total);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -40,7 +40,7 @@ def _fills_chip(x, stride, n_out):
 def _w_direct(lp, weight, dtype):
     """[Cout, 9 Cin] operand of the direct kernels (taps row-major, channels innermost, unpadded)"""
     Cout = weight.shape[0]
-    return _derived(lp, weight, "c3x", dtype, lambda w: w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
+    return _derived(lp, weight, "c3x", dtype, lambda w: ops.conv3x3_weight_pack(w, dtype, 0))
 
 
 def _derived(lp: LPCache, p: torch.Tensor, tag: str, dtype, fn):
@@ -102,8 +102,7 @@ class Conv3x3Fn(torch.autograd.Function):
         Cout = weight.shape[0]
         dt = x.dtype
         ld = ops.k_pad(9 * Cin, dt)
-        w2 = _derived(lp, weight, f"c3:{ld}", dt,
-                      lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), ld))
+        w2 = _derived(lp, weight, f"c3:{ld}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 0, ld))
         x = x.contiguous()
         b = bias.detach() if bias is not None else None
         ctx.save_for_backward(x, weight, bias)
@@ -165,20 +164,21 @@ class Conv3x3Fn(torch.autograd.Function):
                 del cols
             if tb is not None and not fuse_b:
                 ops.colsum(dy2, out=tb, accumulate=True)
-            _write_grad(tw, dw2[:, :9 * Cin].view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), acc)
+            if dw2.dtype == torch.float32 and dw2.stride(1) == 1 and tw.is_contiguous():
+                ops.conv3x3_wgrad_unpack(dw2, tw, acc)
+            else:
+                _write_grad(tw, dw2[:, :9 * Cin].view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), acc)
         elif tb is not None:
             ops.colsum(dy2, out=tb, accumulate=acc)
         dx = None
         if ctx.needs_input_grad[0]:
             if stride == 1:
                 ld2 = ops.k_pad(9 * Cout, dt)
-                wd = _derived(lp, weight, f"c3d:{ld2}", dt,
-                              lambda w: _pad_cols(w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout), ld2))
+                wd = _derived(lp, weight, f"c3d:{ld2}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1, ld2))
                 dy4 = dy.view(B, H, W, Cout)
                 if _DIRECT and ops.conv3x3_direct_ok(dy4, Cin):
                     # the data gradient is the same direct kernel on dy with the flipped weight
-                    wdd = _derived(lp, weight, "c3dd", dt,
-                                   lambda w: w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous())
+                    wdd = _derived(lp, weight, "c3dd", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1))
                     dxr = ops.conv3x3_direct_fwd(dy4, wdd, None, relu_mask=x if relu_in else None)
                     return dxr, rets[0], rets[1], None, None, None, None, None
                 if _IMPLICIT and ld2 == 9 * Cout and _fills_chip(dy4, 1, Cin) and \
@@ -190,10 +190,8 @@ class Conv3x3Fn(torch.autograd.Function):
                     dcols = ops.im2col3x3(dy4, 1, False, ld2)
                     dxr = ops.linear_fwd(dcols, wd, None, out_dtype=dt).view(B, H, W, Cin)
             else:
-                w2 = _derived(lp, weight, f"c3:{ld}", dt,
-                              lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), ld))
-                w2t = _derived(lp, weight, f"c3t:{ld}", dt,
-                               lambda w: _pad_cols(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), ld).t())
+                w2 = _derived(lp, weight, f"c3:{ld}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 0, ld))
+                w2t = _derived(lp, weight, f"c3t:{ld}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 2, ld))
                 dcols = ops.linear_bwd_data(dy2, w2, w2t)  # [M_out, ld]
                 dxr = ops.col2im3x3(dcols, B, H, W, Cin, stride)
             dx = ops.relu_bwd(x, dxr) if relu_in else dxr

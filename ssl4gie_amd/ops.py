@@ -679,6 +679,33 @@ def stem7x7_pack(imgs):
     return out
 
 
+def conv3x3_weight_pack(weight, dtype, mode, ld=None):
+    """operand image of a Conv2d(k=3) weight [Cout, Cin, 3, 3] fp32 in one launch (cast included):
+    mode 0 -> [Cout, ld] rows (tap, ci); mode 1 -> [Cin, ld] rows (flipped tap, co); mode 2 -> [ld, Cout]"""
+    _dev(weight)
+    assert weight.dtype == torch.float32 and weight.dim() == 4 and weight.shape[2:] == (3, 3)
+    w = weight.contiguous()
+    Cout, Cin = w.shape[:2]
+    need = 9 * (Cout if mode == 1 else Cin)
+    ld = need if ld is None else ld
+    shape = (Cout, ld) if mode == 0 else ((Cin, ld) if mode == 1 else (ld, Cout))
+    out = torch.empty(shape, dtype=dtype, device=w.device)
+    _lib.check(_lib.load().ssl4gie_conv3x3_weight_pack(ptr(w), ptr(out), code(dtype), Cout, Cin, mode, ld, stream()),
+               "conv3x3_weight_pack")
+    return out
+
+
+def conv3x3_wgrad_unpack(dw2, target, accumulate=False):
+    """dw2 [Cout, ld >= 9 Cin] fp32, columns (tap, ci) -> (+)= target [Cout, Cin, 3, 3] (contiguous) in one launch"""
+    _dev(dw2, target)
+    Cout, Cin = target.shape[:2]
+    assert dw2.dtype == torch.float32 and target.dtype == torch.float32 and target.is_contiguous()
+    assert dw2.stride(1) == 1 and dw2.shape[0] == Cout and dw2.shape[1] >= 9 * Cin
+    _lib.check(_lib.load().ssl4gie_conv3x3_wgrad_unpack(ptr(dw2), ptr(target), Cout, Cin, dw2.stride(0),
+                                                         int(accumulate), stream()), "conv3x3_wgrad_unpack")
+    return target
+
+
 def stem7x7_weight(weight):
     """[64, 3, 7, 7] fp32 -> [64, 256] in the kernels' layout [co][ky (8)][kx (8)][c (4)], zeros in the padding"""
     w = torch.zeros(weight.shape[0], 8, 8, 4, dtype=weight.dtype, device=weight.device)

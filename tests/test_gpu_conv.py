@@ -151,3 +151,34 @@ def test_conv_descriptor_rejected_when_geometry_does_not_fit():
     d.C, d.ldc = ops.ptr(y), 16
     rc = _lib.load().ssl4gie_gemm(C.byref(d), None, 0, ops.stream())
     assert rc == 1000
+
+
+@pytest.mark.parametrize("cout,cin", [(32, 128), (96, 96), (64, 40)])
+def test_conv3x3_weight_pack_equals_the_torch_relayouts(cout, cin):
+    """ssl4gie_conv3x3_weight_pack (one launch, cast included) == the permute / flip / pad / cast chains it
+    replaced, bit for bit, in the three layouts and both operand types"""
+    from ssl4gie_amd import ops
+    w = torch.randn(cout, cin, 3, 3, generator=torch.Generator().manual_seed(cout + cin)).to(DEV)
+    for dt in (torch.bfloat16, torch.float32):
+        for ld_extra in (0, 24):
+            ld0, ld1 = 9 * cin + ld_extra, 9 * cout + ld_extra
+            ref0 = torch.zeros(cout, ld0, device=DEV)
+            ref0[:, :9 * cin] = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin)
+            ref1 = torch.zeros(cin, ld1, device=DEV)
+            ref1[:, :9 * cout] = w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout)
+            assert torch.equal(ops.conv3x3_weight_pack(w, dt, 0, ld0), ref0.to(dt))
+            assert torch.equal(ops.conv3x3_weight_pack(w, dt, 1, ld1), ref1.to(dt))
+            assert torch.equal(ops.conv3x3_weight_pack(w, dt, 2, ld0), ref0.to(dt).t().contiguous())
+
+
+def test_conv3x3_wgrad_unpack_equals_the_torch_scatter():
+    from ssl4gie_amd import ops
+    cout, cin, ld = 48, 40, 9 * 40 + 24
+    g = torch.Generator().manual_seed(2)
+    dw2 = torch.randn(cout, ld, generator=g).to(DEV)
+    base = torch.randn(cout, cin, 3, 3, generator=g).to(DEV)
+    ref = dw2[:, :9 * cin].view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    t = torch.empty_like(base)
+    assert torch.equal(ops.conv3x3_wgrad_unpack(dw2, t, False), ref.contiguous())
+    t = base.clone()
+    assert torch.equal(ops.conv3x3_wgrad_unpack(dw2, t, True), base + ref)
