@@ -756,8 +756,15 @@ extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, cons
                        rstd, gamma, 1.0f / (float)rows, coef, dgamma, dbeta, accumulate, C);
     LAUNCH_CHECK();
     const long long total = rows * C;
-    RN_LAUNCH(dtype, bn_bwd_apply_kernel, total / rvn(dtype), (const T*)dy, (const T*)y, (const T*)x,
-              coef, (T*)dx, relu, C, total);
+    // with a residual branch the reduction pass has just written dres = the MASKED gradient (dy or 0, no
+    // rounding): the apply pass reads that one tensor instead of dy and the ReLU output (6 -> 4 B/element
+    // read on the widest BatchNorm of a bottleneck)
+    const bool masked = relu && dres;
+    const void* gsrc = masked ? dres : dy;
+    const void* ysrc = masked ? nullptr : y;
+    const int relu_apply = masked ? 0 : relu;
+    RN_LAUNCH(dtype, bn_bwd_apply_kernel, total / rvn(dtype), (const T*)gsrc, (const T*)ysrc, (const T*)x,
+              coef, (T*)dx, relu_apply, C, total);
     return 0;
 }
 extern "C" int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* arg, int dtype, int B,

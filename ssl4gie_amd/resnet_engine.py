@@ -322,7 +322,10 @@ class BatchNormFn(torch.autograd.Function):
                         tgt.copy_(sums[row])
             gsums = sync_sum(sums, group)
             gsums /= total  # the 1 / count of the dx formula, folded into the sums on the device
-            dx = ops.bn_bwd_apply(dy2, y, x2, gd, mean, rstd, gsums, 1.0, relu)
+            if relu and has_res:   # dres is the masked gradient: one tensor instead of dy and the ReLU output
+                dx = ops.bn_bwd_apply(dres, None, x2, gd, mean, rstd, gsums, 1.0, False)
+            else:
+                dx = ops.bn_bwd_apply(dy2, y, x2, gd, mean, rstd, gsums, 1.0, relu)
         gres = dres.view(shp) if has_res else None
         if gres is not None and ctx.join is not None:
             ctx.join.deposit(gres)  # joined in the data-gradient GEMM of the block's first convolution
