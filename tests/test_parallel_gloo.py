@@ -306,6 +306,40 @@ def _loop_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _nooverlap_worker(rank, world, port, q):
+    """overlap=False (everything leaves at the end of backward, still inside it) and a bucket smaller than
+    any parameter (one slice per parameter run): same averages"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssl4gie_amd.parallel import DataParallel
+    batches = _batches(world, False)
+    expect = _single_process_grads(1234, batches)
+    ok = True
+    for kw in (dict(overlap=False), dict(bucket_bytes=4)):
+        torch.manual_seed(1234)
+        m = _Toy()
+        model = DataParallel(m, **kw)
+        for step in range(2):
+            for p in m.parameters():
+                p.grad = None
+            before = model.n_overlapped
+            model(*batches[rank]).backward()
+            if "overlap" in kw:
+                ok &= model.n_overlapped == before       # nothing leaves before the end of backward
+            for k, p in m.named_parameters():
+                if expect[k] is not None:
+                    ok &= torch.allclose(p.grad, expect[k], rtol=1e-5, atol=1e-7)
+        ok &= model.n_passes == 2
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_no_overlap_and_tiny_buckets_world2():
+    res = _run(None, None, None, target=_nooverlap_worker)
+    assert all(ok for _, ok in res), res
+
+
 @pytest.mark.timeout(120)
 def test_reference_loop_features_world2():
     res = _run(None, None, None, target=_loop_worker)
