@@ -10,6 +10,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libssl4gie_hip.so")
+# kernel-development builds only: `make -C ssl4gie_amd/csrc DEBUG_KNOBS=1` produces a second library with the
+# ablation / time-stamp modes of the NT GEMM compiled in; it is loaded only on this explicit request (and says
+# so on stderr) — the release library has no environment knob that changes results.
+if os.environ.get("SSL4GIE_DEBUG_LIB") == "1":
+    LIB_PATH = os.path.join(_HERE, "libssl4gie_hip_dbg.so")
+    import sys as _sys
+    print(f"ssl4gie_amd: SSL4GIE_DEBUG_LIB=1 -> loading the DEBUG library {LIB_PATH}", file=_sys.stderr)
 
 # the one copy of the ABI revision on the Python side: build(), the tests and load() compare the
 # library's ssl4gie_abi_version() with it (include/ssl4gie_hip.h documents the history)

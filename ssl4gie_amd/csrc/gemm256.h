@@ -38,6 +38,34 @@ DEVI void p_glds2(const void* sbase, unsigned v0, unsigned v1, unsigned l0, unsi
         : "memory");
 }
 
+// a single 1-KiB piece (the 64-row B half-tile of the 256 x 192 variant has one piece per wave)
+DEVI void p_glds1(const void* sbase, unsigned v0, unsigned l0) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(sbase), "v"(v0), "s"(l0)
+        : "memory");
+}
+
+// one LDS-DMA of 4 B per lane (256 B per wave): the bias row of a wave's 64 output columns
+DEVI void p_glds1_dword(const void* sbase, unsigned v0, unsigned l0) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %2, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(sbase), "v"(v0), "s"(l0)
+        : "memory");
+}
+
 // the same with per-lane 64-bit addresses (gathered operands: a lane may point at the zero page)
 DEVI void p_glds2v(const void* a0, const void* a1, unsigned l0, unsigned l1) {
     unsigned keep;
@@ -73,48 +101,67 @@ DEVI bf16x8 p_relu8(bf16x8 v) {
 // back with a lane holding 16 B of a row and 16 lanes covering 256 contiguous bytes; the residual /
 // accumulate operand is read in that same layout.  Staging image: 16-B chunk c of row r at position
 // c ^ r (ds_write_b128 and ds_read_b128 conflict-free, tools/lds_bank_sim.py).
-template <bool FULL, bool RESID>
-DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f32x4 (&bias4)[4],
+// NJ: 16-column accumulator blocks per wave (4: 128 x 64 wave tile; 3: 128 x 48, the 256 x 192 variant — the
+// staging image keeps its 64-column geometry, lanes that would own columns 48 .. 63 stay idle).
+template <bool FULL, bool RESID, int NJ = 4>
+DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f32x4 bias_t /* columns gn .. gn + 3 */,
                       const float* __restrict__ residual, const long long ldr, const bool accumulate,
                       float* __restrict__ C, const long long ldc, int rbase, int cbase, int M, int N,
                       int lane) {
     const int r16 = lane & 15, g4 = lane >> 4;
     const int R0 = lane >> 4, Cc = lane & 15;
     const int gn = cbase + 4 * Cc;
+    const bool mine = NJ == 4 || Cc < 4 * NJ;  // this lane's 4 columns exist in the wave tile
     // the residual rows are fetched PF blocks ahead (a ring of PF x 4 row segments in the registers
     // that held the operand fragments): one exposed HBM round trip per tile instead of one per block
-    constexpr int PF = 3;
+    constexpr int PF = 2;  // (+ the 16 registers of the pipelined block: 48 in all, the dead operand fragments)
     f32x4 rs[PF][4];
     auto fetch = [&](int mt, f32x4 (&dst)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int gm = rbase + 16 * mt + R0 + 4 * q;
-            dst[q] = (FULL || (gm < M && gn < N)) ? ld4(residual + (size_t)gm * ldr + gn)
-                                                  : f32x4{0, 0, 0, 0};
+            dst[q] = (mine && (FULL || (gm < M && gn < N))) ? ld4(residual + (size_t)gm * ldr + gn)
+                                                            : f32x4{0, 0, 0, 0};
         }
     };
     if constexpr (RESID) {
 #pragma unroll
         for (int mt = 0; mt < PF; ++mt) fetch(mt, rs[mt]);
     }
+    // Software pipeline over the 8 row blocks: the transposed reads of block mt are issued, then block mt + 1 is
+    // scaled and staged (VALU + ds_writes: LDS executes one wave's instructions in order, so those writes land
+    // after the reads without any wait), and only then block mt's stores go out — the reads' latency hides
+    // under the next block's arithmetic instead of stalling every block.
+    auto put = [&](int mt) {
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const f32x4 v = acc[mt][nt] * alpha + bias4[nt];
+        for (int nt = 0; nt < NJ; ++nt) {
+            const f32x4 v = acc[mt][nt] * alpha;
             const int c = nt * 4 + g4;
             *(f32x4*)(stg + r16 * 256 + ((c ^ r16) << 4)) = v;
         }
+    };
+    put(0);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        f32x4 w[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int R = R0 + 4 * q;
-            f32x4 w = *(const f32x4*)(stg + R * 256 + ((Cc ^ R) << 4));
+            w[q] = *(const f32x4*)(stg + R * 256 + ((Cc ^ R) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt + 1 < 8) put(mt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = R0 + 4 * q;
             const int gm = rbase + 16 * mt + R;
-            if constexpr (RESID) w += rs[mt % PF][q];
-            if (FULL || (gm < M && gn < N)) {
+            w[q] += bias_t;  // in the transposed layout a lane owns 4 columns: one bias quad instead of four
+            if constexpr (RESID) w[q] += rs[mt % PF][q];
+            if (mine && (FULL || (gm < M && gn < N))) {
                 float* c = C + (size_t)gm * ldc + gn;
-                if (accumulate) w += ld4(c);
-                st4(c, w);
+                if (accumulate) w[q] += ld4(c);
+                st4(c, w[q]);
             }
         }
         if constexpr (RESID) {
@@ -127,37 +174,49 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
 // fp32 through the staging area, the aux rows requested 6 row blocks ahead (48 VGPRs, the registers of the
 // dead operand fragments) in the coalesced row layout.
 // AUXF: 1 multiply by aux, 2 multiply by gelu'(aux), 3 zero where aux <= 0 (ReLU mask), 4 add aux.
-template <bool FULL, int AUXF>
+template <bool FULL, int AUXF, int NJ = 4>
 DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
                            const bf16_t* __restrict__ aux, bf16_t* __restrict__ C,
                            const long long ldc, int rbase, int cbase, int M, int N, int lane) {
     const int r16 = lane & 15, g4 = lane >> 4;
     const int R0 = lane >> 4, Cc = lane & 15;
     const int gn = cbase + 4 * Cc;
-    constexpr int PF = AUXF == 2 ? 4 : 6;  // ring of 6 (4) of the 8 row blocks: 48 VGPRs
+    const bool mine = NJ == 4 || Cc < 4 * NJ;
+    constexpr int PF = 4;  // ring of 4 of the 8 row blocks (32 VGPRs) + the 16 of the pipelined block
     u32x2 ax[PF][4];
     auto fetch = [&](int mt, u32x2 (&dst)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int gm = rbase + 16 * mt + R0 + 4 * q;
-            dst[q] = (FULL || (gm < M && gn < N)) ? *(const u32x2*)(aux + (size_t)gm * ldc + gn)
-                                                  : u32x2{0, 0};
+            dst[q] = (mine && (FULL || (gm < M && gn < N))) ? *(const u32x2*)(aux + (size_t)gm * ldc + gn)
+                                                            : u32x2{0, 0};
         }
     };
 #pragma unroll
     for (int mt = 0; mt < PF; ++mt) fetch(mt, ax[mt]);
+    auto put = [&](int mt) {
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NJ; ++nt) {
             const f32x4 v = acc[mt][nt] * alpha;
             const int c = nt * 4 + g4;
             *(f32x4*)(stg + r16 * 256 + ((c ^ r16) << 4)) = v;
         }
+    };
+    put(0);  // pipelined as p_store_f32: reads of block mt, staging of block mt + 1, stores of block mt
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        f32x4 w[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int R = R0 + 4 * q;
-            f32x4 w = *(const f32x4*)(stg + R * 256 + ((Cc ^ R) << 4));
+            w[q] = *(const f32x4*)(stg + R * 256 + ((Cc ^ R) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt + 1 < 8) put(mt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = R0 + 4 * q;
             const int gm = rbase + 16 * mt + R;
             const u32x2 r = ax[mt % PF][q];
             f32x4 u = {__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u),
@@ -168,13 +227,13 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
             }
             if constexpr (AUXF == 3) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = u[j] > 0.f ? w[j] : 0.f;
+                for (int j = 0; j < 4; ++j) w[q][j] = u[j] > 0.f ? w[q][j] : 0.f;
             } else if constexpr (AUXF == 4) {
-                w += u;
+                w[q] += u;
             } else {
-                w *= u;
+                w[q] *= u;
             }
-            if (FULL || (gm < M && gn < N)) st4(C + (size_t)gm * ldc + gn, w);
+            if (mine && (FULL || (gm < M && gn < N))) st4(C + (size_t)gm * ldc + gn, w[q]);
         }
         if (mt + PF < 8) fetch(mt + PF, ax[mt % PF]);
     }
@@ -185,28 +244,52 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
 // STATS (bf16 C, plain epilogue): per-column sums and sums of squares of the STORED (bf16-rounded)
 // values over the wave's 128 rows -> colstats[(rbase / 128)][{0,1}][N]: the BatchNorm statistics of
 // the layer that follows ride on the producing GEMM instead of costing a pass over the activation.
-template <typename TC, int MODE, bool FULL, bool STATS>
+// BIAS_LDS: the kernel has already brought the wave's 64 bias values (columns cbase .. cbase + 63) into the first
+// 256 B of `stg` by LDS-DMA (gemm_nt256.hip: issued in the tile's first K-tile, landed long before): the
+// epilogue then starts without a single vector-memory load — four global loads here would queue behind the
+// partner wave row's stores in the CU's in-order memory pipe (measured: +3.5 us per tile on the wr = 1 waves).
+template <typename TC, int MODE, bool FULL, bool STATS, bool BIAS_LDS = false, int NJ = 4>
 DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                      const float* __restrict__ bias, const float* __restrict__ residual,
                      const long long ldr, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out2,
                      const int accumulate, TC* __restrict__ C, long long ldc, int rbase, int cbase,
                      int M, int N, int lane, float* __restrict__ colstats) {
     const int r16 = lane & 15, g4 = lane >> 4;
-    f32x4 bias4[4];
+    constexpr bool HAS_BIAS = MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
+                              MODE == SSL4GIE_EPI_BIAS_RESIDUAL || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD;
+    // bf16 outputs add the bias in the accumulator layout (before packing): four quads per lane; fp32 outputs
+    // add it after the transposition, where a lane owns 4 columns: one quad (12 registers less)
+    f32x4 bias4[4], bias_t = {0, 0, 0, 0};
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = cbase + 16 * nt + 4 * g4;
-        bias4[nt] = f32x4{0, 0, 0, 0};
-        if constexpr (MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
-                      MODE == SSL4GIE_EPI_BIAS_RESIDUAL || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
-            if (bias && (FULL || n < N)) bias4[nt] = ld4(bias + n);
+    for (int nt = 0; nt < 4; ++nt) bias4[nt] = f32x4{0, 0, 0, 0};
+    static_assert(NJ == 4 || !STATS, "column statistics ride on the 64-column wave tile only");
+    if constexpr (HAS_BIAS && sizeof(TC) == 2) {
+#pragma unroll
+        for (int nt = 0; nt < NJ; ++nt) {
+            const int n = cbase + 16 * nt + 4 * g4;
+            if constexpr (BIAS_LDS) {  // unconditional read + select: no branch, one wait for the four reads
+                const f32x4 t = *(const f32x4*)(stg + (16 * nt + 4 * g4) * 4);
+                bias4[nt] = bias ? t : f32x4{0, 0, 0, 0};
+            } else {
+                if (bias && (FULL || n < N)) bias4[nt] = ld4(bias + n);
+            }
         }
     }
+    if constexpr (HAS_BIAS && sizeof(TC) == 4) {
+        const int c4 = 4 * (lane & 15);
+        if constexpr (BIAS_LDS) {
+            const f32x4 t = *(const f32x4*)(stg + c4 * 4);
+            bias_t = bias ? t : f32x4{0, 0, 0, 0};
+        } else {
+            if (bias && (FULL || cbase + c4 < N)) bias_t = ld4(bias + cbase + c4);
+        }
+    }
+    if constexpr (BIAS_LDS) __builtin_amdgcn_sched_barrier(0);  // the reads above come before any write to `stg`
     if constexpr (sizeof(TC) == 2 && (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
                                       MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX)) {
         constexpr int AUXF = MODE == SSL4GIE_EPI_DGELU ? 2
                            : (MODE == SSL4GIE_EPI_RELU_MASK_AUX ? 3 : (MODE == SSL4GIE_EPI_ADD_AUX ? 4 : 1));
-        p_store_bf16_aux<FULL, AUXF>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane);
+        p_store_bf16_aux<FULL, AUXF, NJ>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane);
     } else if constexpr (sizeof(TC) == 2) {
         // bf16: stage 16 rows x 64 columns (2 KiB), chunk c of row r at position c ^ (r & 7)
         const int R0 = lane >> 3, Cc = lane & 7;
@@ -223,29 +306,12 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
 #pragma unroll
             for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
         }
-        auto flush = [&](int base, bf16_t* __restrict__ dst, int mt) {
+        constexpr bool PAIR = MODE == SSL4GIE_EPI_BIAS_GELU_GRAD || MODE == SSL4GIE_EPI_BIAS_GELU;
+        // scale / activate block mt and stage it (PAIR: first output at 0, the GELU output at 2048)
+        const bool mine = NJ == 4 || Cc < 2 * NJ;  // this lane's 8 columns exist in the wave tile
+        auto stage = [&](int mt) {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int R = R0 + 8 * hh;
-                const u32x4 w = *(const u32x4*)(stg + base + R * 128 + ((Cc ^ (R & 7)) << 4));
-                const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
-                if (FULL || (gm < M && gn < N)) {
-                    *(u32x4*)(dst + (size_t)gm * ldc + gn) = w;
-                    if constexpr (STATS) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
-                            cs[2 * j] += lo; cq[2 * j] += lo * lo;
-                            cs[2 * j + 1] += hi; cq[2 * j + 1] += hi * hi;
-                        }
-                    }
-                }
-            }
-        };
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NJ; ++nt) {
                 const f32x4 v = acc[mt][nt] * alpha + bias4[nt];
                 if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
                     // gelu(u) and gelu'(u) share exp(-u^2/2) and the erf polynomial
@@ -269,9 +335,48 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                     put(0, nt, v);
                 }
             }
-            flush(0, (bf16_t*)C, mt);
-            if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD || MODE == SSL4GIE_EPI_BIAS_GELU)
-                flush(2048, out2, mt);
+        };
+        auto fetch = [&](int base, u32x4 (&w)[2]) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int R = R0 + 8 * hh;
+                w[hh] = *(const u32x4*)(stg + base + R * 128 + ((Cc ^ (R & 7)) << 4));
+            }
+        };
+        auto store = [&](const u32x4 (&w)[2], bf16_t* __restrict__ dst, int mt, bool stats) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int R = R0 + 8 * hh;
+                const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
+                if (mine && (FULL || (gm < M && gn < N))) {
+                    *(u32x4*)(dst + (size_t)gm * ldc + gn) = w[hh];
+                    if constexpr (STATS) {
+                        if (stats) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float lo = __uint_as_float(w[hh][j] << 16), hi = __uint_as_float(w[hh][j] & 0xffff0000u);
+                                cs[2 * j] += lo; cq[2 * j] += lo * lo;
+                                cs[2 * j + 1] += hi; cq[2 * j + 1] += hi * hi;
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        // Software pipeline over the 8 row blocks (see p_store_f32): the transposed reads of block mt, then the
+        // arithmetic and staging of block mt + 1 (in-order LDS: those writes land after the reads), then block
+        // mt's stores — the GELU arithmetic of the next block hides the LDS round trip of this one.
+        stage(0);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            u32x4 w0[2], w1[2];
+            fetch(0, w0);
+            if constexpr (PAIR) fetch(2048, w1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (mt + 1 < 8) stage(mt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            store(w0, (bf16_t*)C, mt, true);
+            if constexpr (PAIR) store(w1, out2, mt, false);
         }
         if constexpr (STATS) {
             // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row groups
@@ -293,8 +398,8 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
             }
         }
     } else {
-        p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL>(
-            acc, stg, alpha, bias4, residual, ldr, MODE == SSL4GIE_EPI_NONE && accumulate, (float*)C,
+        p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL, NJ>(
+            acc, stg, alpha, bias_t, residual, ldr, MODE == SSL4GIE_EPI_NONE && accumulate, (float*)C,
             ldc, rbase, cbase, M, N, lane);
     }
 }

@@ -42,15 +42,21 @@
 #include "gemm256.h"
 #include "prof.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+
+#define NT256_DEFAULT_ROLE 0
 
 // Diagnostics (SSL4GIE_NT256_NOEPI=4): wave 0 of every 16th workgroup stamps s_memrealtime (100 MHz) at five
 // points of every output tile — K-loop start, epilogue start, epilogue end (last store issued), end of the
 // next tile's first K-tile (its counted vmcnt wait has passed) and of its second — into this buffer, read
 // back with ssl4gie_debug_nt256_stamps.  Outputs stay correct; the stamps' own stores perturb a little.
+// The stamps, like every ablation mode, exist in the debug library only (make DEBUG_KNOBS=1); the release
+// library's ssl4gie_debug_nt256_stamps returns SSL4GIE_ENOTBUILT-style ARG_ERR.
 #define NT256_STAMP_WGS 16
 #define NT256_STAMP_TILES 16
+#ifdef SSL4GIE_DEBUG_KNOBS
 __device__ unsigned long long g_nt256_stamps[NT256_STAMP_WGS][NT256_STAMP_TILES][5];
 
 extern "C" int ssl4gie_debug_nt256_stamps(void* dst, size_t bytes) {
@@ -58,17 +64,37 @@ extern "C" int ssl4gie_debug_nt256_stamps(void* dst, size_t bytes) {
     HIP_RET(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_nt256_stamps), bytes));
     return 0;
 }
+#else
+extern "C" int ssl4gie_debug_nt256_stamps(void*, size_t) { return ARG_ERR; }
+#endif
 
 // CONV: 0 = A is a matrix; 1 = A is the implicit 3x3 patch matrix of the map at `A` (geometry cg,
 // header of ssl4gie_conv3x3_geom); 2 = the same with ReLU applied to the A fragments.
-template <typename TC, int MODE, int CONV, bool STATS = false>
+// ROLE: 0 = every wave issues its two LDS-DMA pieces of each half-tile and executes the counted wait;
+//       1 = the four wr = 1 waves ("loaders") issue the whole half-tile (four pieces each) and are the only ones
+//           that wait on vmcnt in the K-loop: the wr = 0 waves then have nothing but their own output stores in
+//           their (in-order) vector-memory queue and never wait for them — the barriers publish the landed tiles.
+// NJ:   16-column accumulator blocks per wave: 4 = the 256 x 256 tile (wave tile 128 x 64); 3 = a 256 x 192 tile
+//       (wave tile 128 x 48) for products whose 256-wide tiles leave a large part of the chip idle (N = 768 at
+//       M = 12800: 150 tiles on 240 CUs -> 200 tiles of 3/4 the work).  Same four phases, barriers and LDS-DMA
+//       placement; the second B half-tile shrinks to 64 rows (one piece per wave, columns 48 wc + 32 .. 47) and
+//       the phases that use it run 8 MFMAs instead of 16.
+template <typename TC, int MODE, int CONV, bool STATS = false, int ROLE = 0, int NJ = 4>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
     TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e,
-    int dbg /* ablation knobs (timing only, wrong output): 1 = no epilogue; 2 = epilogue arithmetic and LDS
-               transposition without any global access; 3 = every global access of the epilogue lands in
-               ONE row per workgroup (L2-resident: store issue without HBM write-back) */,
+    int dbg_arg /* ablation knobs, compiled in with -DSSL4GIE_DEBUG_KNOBS only (timing only, wrong output):
+               1 = no epilogue; 2 = epilogue arithmetic and LDS transposition without any global access; 3 = every
+               global access of the epilogue lands in ONE row per workgroup (L2-resident: store issue without HBM
+               write-back); 4 = time stamps (outputs correct); 5 = the wr = 1 waves skip their epilogue; 6 = they
+               skip it and the wr = 0 waves run theirs twice (second time on the partner's rows); 7 = no LDS-DMA,
+               no MFMA: the epilogues alone; 8 = the time stamps of 4 taken by wave 4 (a wr = 1 wave) */,
     ConvK cg) {
+#ifdef SSL4GIE_DEBUG_KNOBS
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -90,40 +116,71 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     float* e_colstats = e.colstats;
 
     // ------------------------------------------------------------------ LDS-DMA stream state
-    // this lane's source byte offsets: v<item>_<piece> for the 4 half-tiles x 2 pieces (named
-    // scalars on purpose: an indexed array can end up in scratch, and a scratch reload is a VMEM
-    // load whose compiler-inserted wait would drain the LDS-DMA stream)
-    unsigned v0_0 = 0, v0_1 = 0, v1_0 = 0, v1_1 = 0, v2_0 = 0, v2_1 = 0, v3_0 = 0, v3_1 = 0;
-    // CONV: v1_* / v3_* hold the (signed) byte offset of tap (0, 0) of the lane's output pixel and
-    // y1_* / y3_* its coordinates (y0 << 16 | x0 & 0xffff, y0 = oy*s - 1, x0 = ox*s - 1)
-    unsigned y1_0 = 0, y1_1 = 0, y3_0 = 0, y3_1 = 0;
+    // A half-tile is 16 pieces of 1 KiB (8 rows x 128 B, one wave instruction each).  ROLE 0: wave w owns
+    // pieces 2w, 2w + 1; ROLE 1: loader wave (wr = 1, wc) owns pieces 4 wc .. 4 wc + 3, the wr = 0 waves none.
+    // vo[J][i]: this lane's source byte offset for piece i of half-tile J (0 B_h0, 1 A_h0, 2 B_h1, 3 A_h1);
+    // every index below is a compile-time constant after unrolling (a runtime-indexed array would live in
+    // scratch, and a scratch reload is a VMEM load whose compiler-inserted wait would drain the stream).
+    constexpr int NP = ROLE ? 4 : 2;
+    const int pbase = ROLE ? wc * 4 : wave * 2;
+    const bool loader = ROLE == 0 || wr == 1;
+    // Pieces i and i + 2 of a loader are 16 rows apart and share their swizzled chunk (p_swz(lr) depends on
+    // bits 1..3 of the row only), so only pieces 0 and 1 keep per-lane state: vo[J][i] = byte offset of the
+    // lane's (clamped) ROW, co[i] = byte offset of its 16-B chunk inside the 128-B K-slice; pieces 2 and 3 are
+    // min(vo + 16 rows, last row) + co.  (Four offsets per half-tile cost 8 more VGPRs and spill.)
+    unsigned vo[4][2], co[2];
+    // CONV (ROLE 0 only): vo[1][*] / vo[3][*] hold the (signed) byte offset of tap (0, 0) of the lane's output
+    // pixel, chunk included, and yo[0][*] / yo[1][*] its coordinates (y0 << 16 | x0 & 0xffff)
+    unsigned yo[2][2];
+    static_assert(CONV == 0 || ROLE == 0, "the gathered operand keeps the two-piece ownership");
+    static_assert(NJ == 4 || (NJ == 3 && ROLE == 0 && CONV == 0 && !STATS), "256 x 192: plain operands, ROLE 0");
+    constexpr int WN = 16 * NJ;   // columns per wave
+    constexpr int BN = 4 * WN;    // columns per tile
+#pragma unroll
+    for (int J = 0; J < 4; ++J) vo[J][0] = vo[J][1] = 0;
+    yo[0][0] = yo[0][1] = yo[1][0] = yo[1][1] = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = (pbase + i) * 8 + (lane >> 3);
+        co[i] = (unsigned)(((lane & 7) ^ p_swz(lr)) * 16);  // ROLE 0: folded into vo (one add less per issue)
+    }
+    const unsigned a_step = (unsigned)(16 * lda * 2), b_step = (unsigned)(16 * ldb * 2);
+    const unsigned a_last = (unsigned)((long long)(M - 1) * lda * 2), b_last = (unsigned)((long long)(N - 1) * ldb * 2);
     const int c_H = cg.H, c_W = cg.W, c_C = cg.C, c_Wo = cg.Wo, c_HoWo = cg.HoWo, c_s = cg.stride;
     const unsigned c_mgw = cg.mg_wo, c_shw = cg.sh_wo, c_mgh = cg.mg_hw, c_shh = cg.sh_hw;
     const char* c_zero = (const char*)cg.zero;
     const int c_cpt = c_C / P_BK;  // K-tiles per tap
     auto point_at = [&](int ti) {
         const int tile = tile_of(ti);
-        const int sm0 = (tile / tiles_n) * P_BM, sn0 = (tile % tiles_n) * P_BN;
+        const int sm0 = (tile / tiles_n) * P_BM, sn0 = (tile % tiles_n) * BN;
         auto offs = [&](int i, int h, bool is_a) -> unsigned {
-            const int lr = (wave * 2 + i) * 8 + (lane >> 3);  // local row of the half-tile
-            const int c = (lane & 7) ^ p_swz(lr);             // global chunk kept at position l&7
+            if (NJ == 3 && !is_a && h == 1) {  // 64-row half-tile: piece `wave`, columns 48 (lr >> 4) + 32 + (lr & 15)
+                const int lr1 = wave * 8 + (lane >> 3);
+                int rb = sn0 + (lr1 >> 4) * WN + 32 + (lr1 & 15);
+                rb = rb < N ? rb : N - 1;
+                return (unsigned)((long long)rb * ldb * 2) + (unsigned)(((lane & 7) ^ p_swz(lr1)) * 16);
+            }
+            const int lr = (pbase + i) * 8 + (lane >> 3);  // local row of the half-tile
             if (is_a) {
                 int ra = sm0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
                 ra = ra < M ? ra : M - 1;
                 if constexpr (CONV != 0) return (unsigned)ra;  // decomposed below
-                return (unsigned)(((long long)ra * lda + c * 8) * 2);
+                return (unsigned)((long long)ra * lda * 2) + (ROLE == 0 ? co[i] : 0u);
             }
-            int rb = sn0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+            int rb = sn0 + (lr >> 5) * WN + h * 32 + (lr & 31);
             rb = rb < N ? rb : N - 1;
-            return (unsigned)(((long long)rb * ldb + c * 8) * 2);
+            return (unsigned)((long long)rb * ldb * 2) + (ROLE == 0 ? co[i] : 0u);
         };
-        v0_0 = offs(0, 0, false); v0_1 = offs(1, 0, false);  // B_h0
-        v1_0 = offs(0, 0, true);  v1_1 = offs(1, 0, true);   // A_h0
-        v2_0 = offs(0, 1, false); v2_1 = offs(1, 1, false);  // B_h1
-        v3_0 = offs(0, 1, true);  v3_1 = offs(1, 1, true);   // A_h1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            vo[0][i] = offs(i, 0, false);  // B_h0
+            vo[1][i] = offs(i, 0, true);   // A_h0
+            vo[2][i] = offs(i, 1, false);  // B_h1
+            vo[3][i] = offs(i, 1, true);   // A_h1
+        }
         if constexpr (CONV != 0) {
             auto pix = [&](unsigned& v, unsigned& yx, int i) {
-                const int lr = (wave * 2 + i) * 8 + (lane >> 3);
+                const int lr = (pbase + i) * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ p_swz(lr);
                 const unsigned m = v;
                 const unsigned b = p_fastdiv(m, c_mgh, c_shh);
@@ -134,23 +191,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
                 v = (unsigned)(((((int)b * c_H + y0) * c_W + x0) * c_C + c * 8) * 2);
                 yx = ((unsigned)y0 << 16) | ((unsigned)x0 & 0xffffu);
             };
-            pix(v1_0, y1_0, 0); pix(v1_1, y1_1, 1);
-            pix(v3_0, y3_0, 0); pix(v3_1, y3_1, 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                pix(vo[1][i], yo[0][i], i);
+                pix(vo[3][i], yo[1][i], i);
+            }
         }
     };
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + wave * 2048);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + pbase * 1024);
     int s_ktg = 0, s_kt = 0, s_ti = 0;  // stream cursor: global K-tile, K-tile in tile, tile
     int s_dy = 0, s_dx = 0, s_cib = 0;  // CONV: tap and 64-channel block of the cursor's K-tile
     // issue half-tile J (0 B_h0, 1 A_h0, 2 B_h1, 3 A_h1) of the stream's current K-tile
     auto issue = [&](auto Jc) {
         constexpr int J = decltype(Jc)::value;
-        if (s_ktg < total_kt) {
+        if (!loader) return;
+        if (s_ktg < total_kt && dbg != 7) {
             const unsigned dst = lds0 + (s_ktg & 1) * P_BUF + J * P_HALF;
             const bf16_t* base = ((J & 1) ? A : B) + (size_t)s_kt * P_BK;
-            const unsigned va = J == 0 ? v0_0 : J == 1 ? v1_0 : J == 2 ? v2_0 : v3_0;
-            const unsigned vb = J == 0 ? v0_1 : J == 1 ? v1_1 : J == 2 ? v2_1 : v3_1;
             if constexpr (CONV != 0 && (J & 1)) {
-                const unsigned ya = J == 1 ? y1_0 : y3_0, yb = J == 1 ? y1_1 : y3_1;
+                const unsigned va = vo[J][0], vb = vo[J][1];
+                const unsigned ya = yo[J >> 1][0], yb = yo[J >> 1][1];
                 const int tapoff = ((s_dy * c_W + s_dx) * c_C + s_cib * P_BK) * 2;
                 auto src = [&](unsigned o, unsigned yx) -> const char* {
                     const int y = ((int)yx >> 16) + s_dy, x = (int)(short)(yx & 0xffffu) + s_dx;
@@ -159,7 +219,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
                 };
                 p_glds2v(src(va, ya), src(vb, yb), dst, dst + 1024);
             } else {
-                p_glds2(base, va, vb, dst, dst + 1024);
+                if constexpr (NJ == 3 && J == 2) {
+                    p_glds1(base, vo[J][0], dst - pbase * 1024 + wave * 1024);
+                } else if constexpr (ROLE == 0) {
+                    p_glds2(base, vo[J][0], vo[J][1], dst, dst + 1024);
+                } else {
+                    p_glds2(base, vo[J][0] + co[0], vo[J][1] + co[1], dst, dst + 1024);
+                    const unsigned step = (J & 1) ? a_step : b_step, last = (J & 1) ? a_last : b_last;
+                    const unsigned r2 = vo[J][0] + step, r3 = vo[J][1] + step;
+                    p_glds2(base, (r2 < last ? r2 : last) + co[0], (r3 < last ? r3 : last) + co[1], dst + 2048,
+                            dst + 3072);
+                }
             }
         }
         if (J == 3) {
@@ -177,6 +247,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             }
         }
     };
+    // the K-loop's counted wait: K-tile T + 1 has landed, three half-tiles of K-tile T + 2 may stay in flight
+    auto stream_wait = [&](bool more) {
+        if (!loader) return;
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ == 3 ? 5 : 3 * NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
@@ -188,25 +264,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     // are l15 + multiples of 16)
     const int sw = p_swz(l15);
     const int offA = (wr * 64 + l15) * 128, offB = (wc * 32 + l15) * 128;
+    const int offB1 = NJ == 3 ? (wc * 16 + l15) * 128 : offB;  // rows of the wave's columns in B_h1
     const int ch0 = ((0 * 4 + lg) ^ sw) << 4, ch1 = ((1 * 4 + lg) ^ sw) << 4;
     auto ldA = [&](int buf, int h, int mi, int ks) -> bf16x8 {
         return *(const bf16x8*)(smem + buf * P_BUF + (h ? 3 : 1) * P_HALF + offA + mi * 2048 +
                                 (ks ? ch1 : ch0));
     };
     auto ldB = [&](int buf, int h, int ni, int ks) -> bf16x8 {
-        return *(const bf16x8*)(smem + buf * P_BUF + (h ? 2 : 0) * P_HALF + offB + ni * 2048 +
+        return *(const bf16x8*)(smem + buf * P_BUF + (h ? 2 : 0) * P_HALF + (h ? offB1 : offB) + ni * 2048 +
                                 (ks ? ch1 : ch0));
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][4];  // NJ == 3: column 3 is never touched
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     bf16x8 a[4][2], b0[2][2], b1[2][2];
+    constexpr int NI1 = NJ == 3 ? 1 : 2;  // 16-column blocks in the second B half-tile
 
     auto mma = [&](auto QMc, auto QNc, bf16x8 (&bb)[2][2]) {
         constexpr int QM = decltype(QMc)::value, QN = decltype(QNc)::value;
+        if (dbg == 7) return;
         __builtin_amdgcn_s_setprio(1);
         if constexpr (CONV == 2 && QM == QN) {  // P0 / P2 have just loaded `a`
 #pragma unroll
@@ -219,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < (QN == 1 ? NI1 : 2); ++ni)
                     acc[QM * 4 + mi][QN * 2 + ni] =
                         P_MFMA(bb[ni][ks], a[mi][ks], acc[QM * 4 + mi][QN * 2 + ni]);
         __builtin_amdgcn_s_setprio(0);
@@ -229,19 +308,42 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     point_at(0);
     issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
     issue(I0{}); issue(I1{}); issue(I2{});
-    if (total_kt >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stream_wait(total_kt >= 2);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
 
-    const bool stamping = dbg == 4 && wave == 0 && lane == 0 && (blockIdx.x & 15) == 0 && (blockIdx.x >> 4) < NT256_STAMP_WGS;
+#ifdef SSL4GIE_DEBUG_KNOBS
+    const bool stamping = ((dbg == 4 && wave == 0) || (dbg == 8 && wave == 4)) && lane == 0 && (blockIdx.x & 15) == 0 && (blockIdx.x >> 4) < NT256_STAMP_WGS;
     auto stamp = [&](int ti, int k) {
         if (stamping && ti < NT256_STAMP_TILES) g_nt256_stamps[blockIdx.x >> 4][ti][k] = __builtin_amdgcn_s_memrealtime();
+    };
+#else
+    auto stamp = [](int, int) {};
+#endif
+    // The tile's bias row (this wave's 64 columns, 256 B) goes into the wave's staging area by ONE LDS-DMA issued
+    // in the tile's first K-tile, in front of that K-tile's half-tile issues: the counted wait of the same
+    // K-tile (which leaves only the three youngest half-tiles in flight) retires it, the staging area is idle
+    // during the K-loop, and the epilogue reads it with four ds_reads (p_epilogue<.., BIAS_LDS>).  With ROLE 1
+    // the wr = 0 waves never wait on vmcnt in the K-loop, so they wait for this one DMA at the epilogue instead.
+    constexpr bool HAS_BIAS = MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
+                              MODE == SSL4GIE_EPI_BIAS_RESIDUAL || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD;
+    const unsigned stg_lds = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + 2 * P_BUF + wave * P_STG_WAVE);
+    auto issue_bias = [&](int ti) {
+        if constexpr (HAS_BIAS) {
+            if (e_bias) {
+                int col = (tile_of(ti) % tiles_n) * BN + wc * WN + lane;
+                col = col < N ? col : N - 1;
+                p_glds1_dword(e_bias, (unsigned)col * 4u, stg_lds);
+            }
+        }
     };
     int c_kt = 0, c_ti = 0;
     for (int T = 0; T < total_kt; ++T) {
         const int cb = T & 1;
-        if (c_kt == 0) stamp(c_ti, 0);
+        if (c_kt == 0) {
+            stamp(c_ti, 0);
+            if (dbg != 7) issue_bias(c_ti);
+        }
         // ---------------- P0
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -261,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         __builtin_amdgcn_s_barrier();
         // ---------------- P1
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI1; ++ni)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = ldB(cb, 1, ni, ks);
         __builtin_amdgcn_sched_barrier(0);
@@ -285,8 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         issue(I2{});
         // K-tile T+1 must have landed before the next phase reads it; the three half-tiles issued
         // in P1..P3 (of K-tile T+2) may stay in flight
-        if (T + 2 < total_kt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stream_wait(T + 2 < total_kt);
         __builtin_amdgcn_s_barrier();
         mma(I1{}, I0{}, b0);
         __builtin_amdgcn_sched_barrier(0);
@@ -299,37 +400,61 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             c_kt = 0;
             const int tile = tile_of(c_ti);
             ++c_ti;
-            const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * P_BN;
+            const int m0 = (tile / tiles_n) * P_BM, n0 = (tile % tiles_n) * BN;
             if (wr == 0) __builtin_amdgcn_s_barrier();
+            if constexpr (ROLE != 0 && HAS_BIAS) {
+                if (!loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (its own older stores, and the bias row)
+            }
             stamp(c_ti - 1, 1);
             char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
-            const bool full = m0 + P_BM <= M && n0 + P_BN <= N;
-            if (dbg == 1) {
-                asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[7][3][3]));
-            } else if (dbg == 2) {
-                p_epilogue<TC, MODE, false, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
-                                                   e_out2, e_accumulate, C, ldc, m0 + wr * 128,
-                                                   n0 + wc * 64, 0, N, lane, e_colstats);
-            } else if (dbg == 3) {
+            const bool full = m0 + P_BM <= M && n0 + BN <= N;
+#ifdef SSL4GIE_DEBUG_KNOBS
+            // one instantiation per FULL; the ablation modes only change its arguments
+            const float* x_res = e_residual;
+            const bf16_t* x_aux = e_aux;
+            bf16_t* x_out2 = e_out2;
+            TC* x_C = C;
+            long long x_ldr = e_ldr;
+            int x_rbase = m0 + wr * 128, x_M = M, reps = 1;
+            bool x_full = full, skip = false;
+            if (dbg == 1 || ((dbg == 5 || dbg == 6) && wr == 1)) skip = true;
+            if (dbg == 2) { x_full = false; x_M = 0; }
+            if (dbg == 3) {
                 const size_t row = (size_t)(pos % (M > 0 ? M : 1));
-                p_epilogue<TC, MODE, true, STATS>(acc, stg, e_alpha, e_bias,
-                                                  e_residual ? e_residual + row * e_ldr : nullptr, 0,
-                                                  e_aux ? e_aux + row * ldc : nullptr,
-                                                  e_out2 ? e_out2 + row * ldc : nullptr, e_accumulate,
-                                                  C + row * ldc, 0, 0, n0 + wc * 64, M, N, lane, e_colstats);
-            } else if (full)
-                p_epilogue<TC, MODE, true, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                if (x_res) x_res += row * e_ldr;
+                if (x_aux) x_aux += row * ldc;
+                if (x_out2) x_out2 += row * ldc;
+                x_C += row * ldc;
+                x_ldr = 0; x_rbase = 0; x_full = true;
+            }
+            if (dbg == 6 && full) reps = 2;  // the partner's rows too (its values are not these: timing only)
+            if (skip) {
+                asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[7][3][3]));
+            } else if (x_full) {
+                for (int rep = 0; rep < reps; ++rep)
+                    p_epilogue<TC, MODE, true, STATS, true, NJ>(acc, stg, e_alpha, e_bias, x_res, x_ldr, x_aux, x_out2,
+                                                      e_accumulate, x_C, dbg == 3 ? 0 : ldc, x_rbase + rep * 128,
+                                                      n0 + wc * WN, x_M, N, lane, e_colstats);
+            } else {
+                p_epilogue<TC, MODE, false, STATS, true, NJ>(acc, stg, e_alpha, e_bias, x_res, x_ldr, x_aux, x_out2,
+                                                   e_accumulate, x_C, ldc, x_rbase, n0 + wc * WN, x_M, N, lane,
+                                                   e_colstats);
+            }
+#else
+            if (full)
+                p_epilogue<TC, MODE, true, STATS, true, NJ>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                   e_out2, e_accumulate, C, ldc, m0 + wr * 128,
-                                                  n0 + wc * 64, M, N, lane, e_colstats);
+                                                  n0 + wc * WN, M, N, lane, e_colstats);
             else
-                p_epilogue<TC, MODE, false, STATS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                p_epilogue<TC, MODE, false, STATS, true, NJ>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                    e_out2, e_accumulate, C, ldc, m0 + wr * 128,
-                                                   n0 + wc * 64, M, N, lane, e_colstats);
+                                                   n0 + wc * WN, M, N, lane, e_colstats);
+#endif
             stamp(c_ti - 1, 2);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+                for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
             if (wr == 1) __builtin_amdgcn_s_barrier();
         } else {
             __builtin_amdgcn_s_barrier();
@@ -383,27 +508,76 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
     return tiles >= 128;
 }
 
+// Columns per tile, per shape: 256, or 192 (NJ = 3) when that means less work per CU — the tiles of a launch
+// are dealt to `cus` persistent workgroups, so the launch takes ceil(tiles / cus) tile times, and a 192-wide
+// tile costs about 0.78 of a 256-wide one (3/4 of the MFMAs and of the epilogue, shorter phases pipeline a
+// little worse; tools/gemm_bench.py).  N = 768 at M = 12800 (ViT-B proj / fc2 and their data gradients):
+// 150 tiles = one round at 62 % of the chip  ->  200 tiles = one round of 0.78.
+static int nt256_pick_nj(const ssl4gie_gemm_desc* d, int cus) {
+    if (d->conv || d->colstats) return 4;
+#ifdef SSL4GIE_DEBUG_KNOBS
+    static int forced = -1;
+    if (forced < 0) { const char* s = getenv("SSL4GIE_NT256_NJ"); forced = s ? atoi(s) : 0; }
+    if (forced == 3 || forced == 4) return forced;
+#endif
+    const long long tm = (d->M + P_BM - 1) / P_BM;
+    const long long r256 = (tm * ((d->N + 255) / 256) + cus - 1) / cus;
+    const long long r192 = (tm * ((d->N + 191) / 192) + cus - 1) / cus;
+    return (double)r192 * 0.78 < (double)r256 ? 3 : 4;
+}
+
 int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
-    const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + P_BN - 1) / P_BN;
-    const int ntiles = tm * tn;
     const int cus = ssl4gie_internal_compute_cus();
+    const int nj = nt256_pick_nj(d, cus);
+    const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + 64 * nj - 1) / (64 * nj);
+    const int ntiles = tm * tn;
     dim3 grid(ntiles < cus ? ntiles : cus), block(512);
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate,
               d->colstats};
-    // SSL4GIE_NT256_NOEPI=1..3: ablations (see the kernel's `dbg`; outputs are garbage)
-    static int skip_epi = -1;
-    if (skip_epi < 0) { const char* s = getenv("SSL4GIE_NT256_NOEPI"); skip_epi = (s && s[0] >= '1' && s[0] <= '4') ? s[0] - '0' : 0; }
+    int skip_epi = 0;
+    [[maybe_unused]] int role = NT256_DEFAULT_ROLE;
+#ifdef SSL4GIE_DEBUG_KNOBS
+    // debug library only (make DEBUG_KNOBS=1 -> libssl4gie_hip_dbg.so, loaded with SSL4GIE_DEBUG_LIB=1):
+    // SSL4GIE_NT256_NOEPI=1..7 ablations (the kernel's `dbg`; all but 4 leave garbage outputs),
+    // SSL4GIE_NT256_ROLE=0/1 the LDS-DMA ownership
+    {
+        static int k_epi = -1, k_role = -1;
+        if (k_epi < 0) {
+            const char* s = getenv("SSL4GIE_NT256_NOEPI");
+            k_epi = (s && s[0] >= '1' && s[0] <= '8') ? s[0] - '0' : 0;
+            s = getenv("SSL4GIE_NT256_ROLE");
+            k_role = s ? (s[0] - '0') : NT256_DEFAULT_ROLE;
+            if (k_epi || s) fprintf(stderr, "ssl4gie: DEBUG KNOBS active: NT256_NOEPI=%d NT256_ROLE=%d\n", k_epi, k_role);
+        }
+        skip_epi = k_epi;
+        role = k_role;
+    }
+#endif
     ConvK ck{};
     if (d->conv) {
         const int rc = ssl4gie_internal_conv_k(d->conv, &ck);
         if (rc) return rc;
     }
     ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
-#define P_LAUNCH(TC_, MODE_) P_LAUNCH_C(TC_, MODE_, 0)
+#ifdef SSL4GIE_DEBUG_KNOBS
+#define P_LAUNCH(TC_, MODE_)                                       \
+    do {                                                            \
+        if (nj == 3) P_LAUNCH_R(TC_, MODE_, 0, false, 0, 3);        \
+        else if (role == 1) P_LAUNCH_R(TC_, MODE_, 0, false, 1, 4); \
+        else P_LAUNCH_R(TC_, MODE_, 0, false, 0, 4);                \
+    } while (0)
+#else
+#define P_LAUNCH(TC_, MODE_)                                                   \
+    do {                                                                        \
+        if (nj == 3) P_LAUNCH_R(TC_, MODE_, 0, false, 0, 3);                    \
+        else P_LAUNCH_R(TC_, MODE_, 0, false, NT256_DEFAULT_ROLE, 4);           \
+    } while (0)
+#endif
 #define P_LAUNCH_C(TC_, MODE_, CONV_) P_LAUNCH_S(TC_, MODE_, CONV_, false)
-#define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_)                                                      \
+#define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_) P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, 0, 4)
+#define P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_)                                          \
     do {                                                                                           \
-        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_>;                              \
+        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_, ROLE_, NJ_>;                  \
         static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
         if (!attr_set) {                                                                           \
             HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
@@ -448,6 +622,7 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
 #undef P_LAUNCH
 #undef P_LAUNCH_C
 #undef P_LAUNCH_S
+#undef P_LAUNCH_R
     LAUNCH_CHECK();
     return 0;
 }

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
         }
     }
     // ---- epilogue: slab (splits > 1) or C
-    const f32x4 zero4[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    const f32x4 zero4 = {0, 0, 0, 0};
     char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
     float* out = (splits == 1) ? C : slabs + (size_t)split * M * N;
     const long long ldo = (splits == 1) ? ldc : N;

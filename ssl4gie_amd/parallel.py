@@ -76,10 +76,15 @@ class DataParallel(nn.Module):
     every trainable parameter is final (or is known never to receive a gradient: learnt during the
     first pass and agreed between the ranks, the reference's `find_unused_parameters=True`); whenever
     `bucket_bytes` of final gradients have accumulated above the frontier, that contiguous slice is
-    all-reduced on the comm stream.  Slices never contain a parameter learnt as unused (so one that
-    turns up later — the graph changed — has nothing in flight over its slice and is reduced on its
-    own), and runs of frozen parameters (MoCo's momentum encoder: half the arena) split the arena
-    into segments that are never communicated."""
+    all-reduced on the comm stream.  The slices are a PLAN: a pure function of the arena layout, the
+    bucket size and the agreed unused set, so every rank issues the same collectives of the same sizes
+    in the same order whatever its own graph did in this pass (a parameter whose hook does not fire on
+    one rank only delays that rank's slices to the end of its backward; it never changes them).  Runs
+    of parameters learnt as unused are left out of the overlapped slices and go out as "tail" slices
+    at the end of every pass — a few KB to MB of zeros normally — so one that does receive a gradient
+    later (the graph changed, on any subset of the ranks) is still averaged in that same pass with
+    nothing in flight over it; runs of frozen parameters (MoCo's momentum encoder: half the arena)
+    split the arena into segments that are never communicated."""
 
     FROZEN_GAP_ELEMS = 1 << 18  # a frozen run >= 1 MiB ends a segment (not worth carrying along)
 
@@ -104,7 +109,7 @@ class DataParallel(nn.Module):
         self._step = 0
         self._armed = False      # the end-of-backward call-back of the current pass is queued
         self.n_collectives = 0
-        self.n_late = 0  # parameters reduced on their own (learnt as unused, then used after all)
+        self.n_late = 0  # gradients seen on parameters learnt as unused (carried by the tail slices)
         self.n_passes = 0        # backward passes closed (from inside backward or by finish())
         self.n_overlapped = 0    # collectives that left while backward was still running
         self._n_at_pass_start = 0
@@ -185,14 +190,42 @@ class DataParallel(nn.Module):
         sink = getattr(self.module, "sink", None)
         if callable(sink) and self.overlap and self.world > 1:
             sink().tracker = self._on_use_done
+        self._build_plan()
         self._reset_pass()
         if self.world > 1:
             for _, _, p, _ in self._items:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_param))
 
+    def _build_plan(self):
+        """The slices of a pass as a pure function of (arena layout, bucket size, unused set): items are
+        walked from the end of the arena; a run of consecutive items of one segment and one kind (used /
+        learnt-unused) is cut greedily into slices of >= bucket_elems (its remainder is a slice of its
+        own).  `_plan` holds the slices of the used runs in walk order as (lo, hi, end_item): slice s may
+        leave once items [0, end_item) are final and slices [0, s) have left; `_tails` the slices of the
+        unused runs, sent at the end of every pass.  Every rank builds the same plan from the same agreed
+        unused set, so collective counts, sizes and order never depend on a rank's own graph."""
+        items, unused, n = self._items, self._unused, len(self._items)
+        plan, tails, i = [], [], 0
+        while i < n:
+            seg, u, j = items[i][3], unused[i], i
+            while j < n and items[j][3] == seg and unused[j] == u:
+                j += 1
+            first = i == 0 or items[i - 1][3] != seg
+            hi = self._seg_hi[seg] if first else items[i - 1][0]
+            if u:
+                tails.append((items[j - 1][0], hi))
+            else:
+                for k in range(i, j):
+                    lo = items[k][0]
+                    if hi - lo >= self.bucket_elems or k == j - 1:
+                        plan.append((lo, hi, k + 1))
+                        hi = lo
+            i = j
+        self._plan, self._tails = plan, tails
+
     def _reset_pass(self):
         self._k = 0                  # items [0, k) are final
-        self._sent = 0               # items [0, sent) have been handed to a collective (or skipped: unused)
+        self._sent = 0               # plan slices [0, sent) have been handed to a collective
         self._fired = self._late = 0
         self._uses = [0] * len(self._items) if hasattr(self, "_items") else []
         self._armed = False
@@ -282,33 +315,17 @@ class DataParallel(nn.Module):
             p.grad = v
 
     def _send(self, upto: int, force: bool = False):
-        """hand items [sent, upto) to collectives.  A slice is a run of consecutive final items of one
-        segment without a learnt-unused parameter in it; it goes out when it has reached bucket size,
-        when it cannot grow any more (segment end, or an unused parameter follows), or when `force`."""
-        items, unused = self._items, self._unused
-        while self._sent < upto:
-            i = self._sent
-            if unused[i]:
-                # left out of every slice, so nothing is ever in flight over it: if it received a
-                # gradient after all (the graph changed) it is reduced on its own
-                if self._stamp[i] == self._step:
-                    self.n_late += 1
-                    self._late += 1
-                    self._reduce_slice(items[i][0], items[i][1])
-                self._sent = i + 1
-                continue
-            seg = items[i][3]
-            j = i
-            while j < upto and items[j][3] == seg and not unused[j]:
-                j += 1
-            closed = j == len(items) or items[j][3] != seg or unused[j]
-            first = i == 0 or items[i - 1][3] != seg
-            hi = self._seg_hi[seg] if first else items[i - 1][0]
-            lo = items[j - 1][0]
-            if not (force or closed or hi - lo >= self.bucket_elems):
-                return
+        """hand the plan's slices to collectives, in plan order: those whose items [.., end_item) are all
+        final (end_item <= upto), or — `force`, the end of the pass — every slice that has not left yet,
+        followed by the tail slices of the learnt-unused runs."""
+        plan = self._plan
+        while self._sent < len(plan) and (force or plan[self._sent][2] <= upto):
+            lo, hi, _ = plan[self._sent]
             self._reduce_slice(lo, hi)
-            self._sent = j
+            self._sent += 1
+        if force:
+            for lo, hi in self._tails:
+                self._reduce_slice(lo, hi)
 
     def _arm(self):
         """queue the end-of-backward call-back (once per pass; only possible from inside backward)"""
@@ -344,6 +361,7 @@ class DataParallel(nn.Module):
         self._drain()
         n = len(self._items)
         self._unused, self._expected, self._learnt = [False] * n, [0] * n, False
+        self._build_plan()
         self._reset_pass()
 
     def _on_param(self, p, early=False):
@@ -359,12 +377,12 @@ class DataParallel(nn.Module):
         self._fired += 1
         if not self.overlap:
             return
-        if i < self._sent:
-            # only a parameter learnt as unused can be behind the frontier, and _send() left its slice
-            # out of every collective: nothing is in flight over it, it is reduced on its own
+        if self._unused[i]:
+            # learnt as unused, used after all (the graph changed): its run is a tail slice, which every
+            # rank sends at the end of every pass — nothing is in flight over it now, and it is averaged
+            # in this same pass whether or not the other ranks saw the change
             self.n_late += 1
             self._late += 1
-            self._reduce_slice(self._items[i][0], self._items[i][1])
             return
         k, n = self._k, len(self._items)
         while k < n and (self._stamp[k] == self._step or self._unused[k]):
@@ -381,8 +399,9 @@ class DataParallel(nn.Module):
                 self._on_param(p)
 
     def _agree_unused(self, used: List[bool]) -> List[bool]:
-        """ranks agree on the unused set (a parameter used on ANY rank is waited for on all): the
-        slices every rank cuts out of its arena are then the same, whatever a rank's own graph did"""
+        """ranks agree on the unused set (a parameter used on ANY rank is waited for on all); called by
+        every rank in the same pass (the first one after construction / relearn()), never on a
+        rank-local condition"""
         t = torch.tensor([1.0 if u else 0.0 for u in used], dtype=torch.float32, device=self._arena.grad.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
         return [v == 0.0 for v in t.tolist()]
@@ -394,17 +413,18 @@ class DataParallel(nn.Module):
         `backward()`, after syncing it with the leaf streams."""
         self.n_overlapped += self.n_collectives - self._n_at_pass_start
         if self.world > 1 and self.require_backward_grad_sync:
-            for _, _, p, _ in self._items[self._sent:]:
+            for _, _, p, _ in self._items:
                 self._adopt(p)
             # the forced send covers items whose hook did not fire as well (zeros, or gradients of an
-            # earlier pass that were never cleared: every rank sends the same slices either way);
-            # the slices of THIS pass are cut with the unused set learnt so far
+            # earlier pass that were never cleared): every rank sends the plan's slices either way
             self._send(len(self._items), force=True)
-            if (not self._learnt or self._late) and self._fired:
-                # first pass (or the graph changed): parameters whose hook did not fire on any rank do
-                # not take part in this graph
+            if not self._learnt:
+                # first pass after construction / relearn() — on every rank alike, so the agreement is a
+                # collective all of them join: parameters whose hook fired on no rank do not take part in
+                # this graph
                 self._unused = self._agree_unused([s == self._step for s in self._stamp])
                 self._expected, self._learnt = list(self._uses), True
+                self._build_plan()
         self._drain()
         self.n_passes += 1
         self._n_at_pass_start = self.n_collectives

@@ -58,6 +58,47 @@ def test_nt_gemm_production_shape_exact(M, N, K):
         assert (dx.double() - refx).abs().max() <= refx.abs().max() * 2 ** -8
 
 
+def test_nt_gemm_192_wide_tiles_ragged_exact():
+    """The 256 x 192 tile variant (chosen per shape when it means fewer chip rounds: N = 768 at M = 12800) on a
+    shape with a ragged last row tile AND a ragged last column tile (712 = 3 x 192 + 136: the third wave column
+    of the last tile is partial, the fourth empty): every epilogue kind, exact integers."""
+    from ssl4gie_amd import _lib, ops
+    M, N, K = 12700, 712, 768
+    x = ints((M, K), 201, -1, 2).to(DEV)
+    w = ints((N, K), 202, -1, 2).to(DEV)
+    bias = ints((N,), 203).to(DEV)
+    ref = x.double() @ w.double().t() + bias.double()
+    xb, wb = x.to(BF), w.to(BF)
+    y = ops.linear_fwd(xb, wb, bias, out_dtype=F32)
+    assert torch.equal(y.double(), ref), f"bias/fp32: max diff {(y.double() - ref).abs().max()}"
+    res = ints((M, N), 204, -8, 9).to(DEV)
+    y = ops.linear_fwd(xb, wb, bias, out_dtype=F32, epilogue=_lib.EPI_BIAS_RESIDUAL, residual=res)
+    assert torch.equal(y.double(), ref + res.double()), "residual epilogue"
+    assert abs(ref).max() < 256
+    y = ops.linear_fwd(xb, wb, bias, out_dtype=BF)
+    assert torch.equal(y.double(), ref), "bf16 output"
+    y = ops.linear_fwd(xb, wb, None, out_dtype=BF)
+    assert torch.equal(y.double(), ref - bias.double()), "bf16 output, no bias"
+    # GELU pair: u exact is not representable after GELU; compare with the torch formulation at bf16 resolution
+    d, g = ops.linear_fwd(xb, wb, bias, epilogue=_lib.EPI_BIAS_GELU_GRAD)
+    u = ref.float()
+    g_ref = torch.nn.functional.gelu(u)
+    cdf = 0.5 * (1 + torch.erf(u / 2 ** 0.5))
+    d_ref = cdf + u * torch.exp(-0.5 * u * u) / (2 * torch.pi) ** 0.5
+    assert (g.float() - g_ref).abs().max() <= 2 ** -7 * g_ref.abs().max() + 1e-3
+    assert (d.float() - d_ref).abs().max() <= 2 ** -7 * 1.2 + 1e-3
+    # multiply-by-aux epilogue (the backward of fc2 into the saved GELU derivative)
+    aux = ints((M, N), 205, -1, 2).to(DEV).to(BF)
+    dsc = ops._desc(M, N, K, _lib.BF16, _lib.BF16)
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    dsc.A, dsc.sAm, dsc.sAk = xb.data_ptr(), K, 1
+    dsc.B, dsc.sBk, dsc.sBn = wb.data_ptr(), 1, K
+    dsc.C, dsc.ldc = out.data_ptr(), N
+    dsc.epilogue, dsc.aux = _lib.EPI_MUL_AUX, aux.data_ptr()
+    ops.gemm_raw(dsc, DEV)
+    assert torch.equal(out.double(), (ref - bias.double()) * aux.double()), "mul-aux epilogue"
+
+
 # (n_out, k_in, T): dW of decoder fc1 / fc2 / qkv / proj and encoder fc2 / qkv
 TN_PROD = [(2048, 512, 50432), (512, 2048, 50432), (1536, 512, 50432), (512, 512, 50432),
            (768, 3072, 12800), (2304, 768, 12800)]

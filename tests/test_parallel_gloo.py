@@ -199,20 +199,21 @@ def test_bucketed_allreduce_world2(two_view):
         # step 0: the never-used parameter sits above the blocks and holds the frontier until the
         # end of backward; afterwards it is known and most slices leave while backward is still running
         assert steps[1][1] >= 2 and steps[2][1] >= 2, steps
-        assert steps[1][2] <= steps[1][1] + 2
+        assert steps[1][2] <= steps[1][1] + 3   # (+ the tail slice of the learnt-unused run)
         assert abs(lm - 1.5) < 1e-6
 
 
 @pytest.mark.timeout(120)
 def test_frozen_run_is_not_communicated_world2():
     """a large frozen block in the middle of the arena (MoCo's momentum encoder) splits it into
-    segments: trainable slices either side are averaged, the frozen run is never sent (the learnt-unused
-    parameter sits at the end of its segment: leaving it out does not split a slice)"""
+    segments: trainable slices either side are averaged, the frozen run is never sent; once the unused
+    parameter is known, its run travels as one small tail slice at the end of every pass (so that a rank
+    whose graph does use it is still averaged correctly)"""
     for rank, same_w, steps, lm in _run(True, 600, 1 << 30):
         assert same_w
-        for ok, during, total, late in steps:
+        for i, (ok, during, total, late) in enumerate(steps):
             assert ok and late == 0
-            assert total == 2, "one slice per trainable segment (bucket larger than either)"
+            assert total == (2 if i == 0 else 3), "one slice per trainable segment (bucket larger than either) + the tail"
 
 
 def _loop_worker(rank, world, port, q):
@@ -261,8 +262,18 @@ def _loop_worker(rank, world, port, q):
     for p in m.parameters():
         p.grad = None
     n_before = model.n_collectives
-    (model(x1) + (m.unused.weight ** 2).sum()).backward()   # re-learnt: part of the slices now
-    ok &= model.n_late == late0 + 1 and model.n_collectives > n_before
+    (model(x1) + (m.unused.weight ** 2).sum()).backward()   # still carried by its tail slice, every pass
+    ok &= model.n_late == late0 + 2 and model.n_collectives > n_before
+    ok &= torch.allclose(m.unused.weight.grad, 2 * m.unused.weight.detach(), rtol=1e-6)
+    model.relearn()                                          # the schedule follows the new graph on request
+    for p in m.parameters():
+        p.grad = None
+    (model(x1) + (m.unused.weight ** 2).sum()).backward()   # learning pass
+    for p in m.parameters():
+        p.grad = None
+    (model(x1) + (m.unused.weight ** 2).sum()).backward()   # `unused` is part of the overlapped slices now
+    ok &= model.n_late == late0 + 2
+    ok &= torch.allclose(m.unused.weight.grad, 2 * m.unused.weight.detach(), rtol=1e-6)
     # --- a backward that raises leaves no stale pass behind
     class Boom(torch.autograd.Function):
         @staticmethod
@@ -304,6 +315,79 @@ def _loop_worker(rank, world, port, q):
     ok &= m.training
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
+
+
+def _ragged_graph_worker(rank, world, port, q):
+    """A rank whose graph differs from the others' in one pass (advisor finding, round 3): rank 1 skips one
+    block in pass 2.  The slices are a plan (a function of the layout and the agreed unused set), so both
+    ranks issue the same collectives of the same sizes in the same order — the pass completes, rank 1's
+    skipped block contributes zeros, and the next (uniform) pass averages as before."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssl4gie_amd.parallel import DataParallel
+    torch.manual_seed(1234)
+    m = _Toy()
+    model = DataParallel(m, bucket_bytes=4 * 2000)     # several slices per pass
+    a = m.arena()
+    batches = _batches(world, False)
+    x = batches[rank][0]
+    ok = True
+
+    def fwd(skip):
+        m.arena(); m._s.new_pass()
+        t = m._lin(x, m.stem) + m.pos * 2.0
+        for i, blk in enumerate(m.blocks):
+            if i == skip:
+                continue
+            t = torch.tanh(m._lin(t, blk))
+        return (m._lin(t, m.head.fc) ** 2).mean()
+
+    def plain_grads(xr, skip):
+        torch.manual_seed(1234)
+        r = _Toy()
+        t = xr @ r.stem.weight.t() + r.stem.bias + r.pos * 2.0
+        for i, blk in enumerate(r.blocks):
+            if i == skip:
+                continue
+            t = torch.tanh(t @ blk.weight.t() + blk.bias)
+        ((t @ r.head.fc.weight.t() + r.head.fc.bias) ** 2).mean().backward()
+        return {k: p.grad for k, p in r.named_parameters()}
+
+    sizes = []
+    for step, skips in enumerate(((None, None), (None, 3), (None, None))):   # (rank 0, rank 1) per pass
+        for p in m.parameters():
+            p.grad = None
+        a.grad.zero_()
+        before = model.n_collectives
+        model.forward  # (the wrapper's forward is bypassed on purpose: a hand-built graph per rank)
+        fwd(skips[rank]).backward()
+        sizes.append(model.n_collectives - before)
+        g = [plain_grads(batches[r][0], skips[r]) for r in range(world)]
+        for k, p in m.named_parameters():
+            parts = [gi[k] for gi in g if gi[k] is not None]
+            if not parts:
+                continue
+            exp = sum(parts) / world
+            got = a.grad_view(p)
+            ok &= torch.allclose(got, exp, rtol=1e-5, atol=1e-7)
+    ok &= sizes[1] == sizes[2]       # same number of collectives whatever the rank's own graph did
+    q.put((rank, bool(ok), sizes))
+    dist.destroy_process_group()
+
+
+def test_rank_local_graph_change_keeps_collectives_uniform_world2():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(o[1] for o in out), out
+    assert out[0][2] == out[1][2], "both ranks issued the same number of collectives in every pass"
 
 
 def _nooverlap_worker(rank, world, port, q):

@@ -64,6 +64,7 @@ for name, T, n, k, ep in NT:
     tot_ms += ms; tot_fl += fl
     print(f"NT {name:10s} M={T:6d} N={n:5d} K={k:5d} {ep:8s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s", flush=True)
 print(f"NT total {tot_ms:.3f} ms  {tot_fl/tot_ms/1e9:.1f} TF/s")
+if os.environ.get("GEMM_SKIP_TN"): TN = []
 tot_ms = tot_fl = 0
 for name, n, k, T in TN:
     dy = (torch.randn(T, n, device=dev) * 0.5).bfloat16()
@@ -73,4 +74,4 @@ for name, n, k, T in TN:
     fl = 2.0 * T * n * k
     tot_ms += ms; tot_fl += fl
     print(f"TN {name:10s} M={n:5d} N={k:5d} K={T:6d} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s", flush=True)
-print(f"TN total {tot_ms:.3f} ms  {tot_fl/tot_ms/1e9:.1f} TF/s")
+if TN: print(f"TN total {tot_ms:.3f} ms  {tot_fl/tot_ms/1e9:.1f} TF/s")

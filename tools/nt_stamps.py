@@ -2,7 +2,8 @@
 """In-kernel timeline of gemm_nt256 per output tile (SSL4GIE_NT256_NOEPI=4 stamps): K-loop, epilogue issue,
 and how long the NEXT tile's first / second K-tile take (its counted vmcnt wait sits behind the stores)."""
 import ctypes, os, sys
-os.environ["SSL4GIE_NT256_NOEPI"] = "4"
+os.environ.setdefault("SSL4GIE_NT256_NOEPI", "4")  # "8": wave 4's view (a wr = 1 wave)
+os.environ["SSL4GIE_DEBUG_LIB"] = "1"  # the stamps exist in the debug library only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
