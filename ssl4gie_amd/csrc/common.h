@@ -90,6 +90,40 @@ DEVI void gelu_parts_fast(float x, float& cdf, float& xpdf) {
     cdf = 0.5f + 0.5f * copysignf(erf_abs, x);
     xpdf = x * e * 0.39894228040143267794f;
 }
+// Four elements at once, as two float2 chains evaluated side by side: every multiply / fma of the polynomial and of
+// the final combinations is a v_pk_*_f32 on a pair, and the two pairs give the scheduler independent chains to
+// interleave (a lone dependent chain of packed ops costs an s_nop after every instruction).  The GELU epilogue of
+// the 256 x 256 NT kernel is VALU-issue-bound: 35 -> 24 instructions per pair (profiles/r04*).  Same formulas
+// as gelu_parts_fast (A&S 7.1.26 with the 1/2 folded into the coefficients); d = gelu'(x), g = gelu(x).
+DEVI void gelu_grad4_fast(const f32x4 x, f32x4& d, f32x4& g) {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    const float P = 0.3275911f * 0.70710678118654752440f;
+    const f2 x0 = {x[0], x[1]}, x1 = {x[2], x[3]};
+    const float C = -0.5f * 1.44269504088896340736f;  // exp(-x^2/2) = exp2(C x^2)
+    const f2 a0 = (x0 * x0) * C, a1 = (x1 * x1) * C;
+    const f2 e0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+    const f2 e1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+    const f2 t0 = {__builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x0[0]), P, 1.0f)),
+                   __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x0[1]), P, 1.0f))};
+    const f2 t1 = {__builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x1[0]), P, 1.0f)),
+                   __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x1[1]), P, 1.0f))};
+    const float A5 = 0.5f * 1.061405429f, A4 = -0.5f * 1.453152027f, A3 = 0.5f * 1.421413741f,
+                A2 = -0.5f * 0.284496736f, A1 = 0.5f * 0.254829592f;
+    f2 p0 = t0 * A5 + A4, p1 = t1 * A5 + A4;
+    p0 = p0 * t0 + A3; p1 = p1 * t1 + A3;
+    p0 = p0 * t0 + A2; p1 = p1 * t1 + A2;
+    p0 = p0 * t0 + A1; p1 = p1 * t1 + A1;
+    p0 = p0 * t0;      p1 = p1 * t1;
+    f2 h0 = 0.5f - p0 * e0, h1 = 0.5f - p1 * e1;  // Phi(|x|) - 1/2
+    h0 = f2{copysignf(h0[0], x0[0]), copysignf(h0[1], x0[1])};
+    h1 = f2{copysignf(h1[0], x1[0]), copysignf(h1[1], x1[1])};
+    const f2 c0 = h0 + 0.5f, c1 = h1 + 0.5f;      // Phi(x)
+    const float S = 0.39894228040143267794f;
+    const f2 d0 = (x0 * e0) * S + c0, d1 = (x1 * e1) * S + c1;
+    const f2 g0 = x0 * c0, g1 = x1 * c1;
+    d = f32x4{d0[0], d0[1], d1[0], d1[1]};
+    g = f32x4{g0[0], g0[1], g1[0], g1[1]};
+}
 DEVI float gelu_fast(float x) { float c, p; gelu_parts_fast(x, c, p); return x * c; }
 DEVI float dgelu_fast(float x) { float c, p; gelu_parts_fast(x, c, p); return c + p; }
 

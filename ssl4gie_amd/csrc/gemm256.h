@@ -93,6 +93,12 @@ DEVI bf16x8 p_relu8(bf16x8 v) {
     return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, v), z));
 }
 
+#ifndef P_EPI_XPOSE_SWAP
+#define P_EPI_XPOSE_SWAP true
+#endif
+#ifndef P_EPI_PRIO_MODE
+#define P_EPI_PRIO_MODE 0  /* measured: no policy changes the tile time (profiles/r04j) */
+#endif
 #define P_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // fp32 outputs of one wave's 128 x 64 sub-tile.  acc[mt][nt]: rows rbase + 16 mt + (l & 15),
@@ -248,12 +254,18 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
 // 256 B of `stg` by LDS-DMA (gemm_nt256.hip: issued in the tile's first K-tile, landed long before): the
 // epilogue then starts without a single vector-memory load — four global loads here would queue behind the
 // partner wave row's stores in the CU's in-order memory pipe (measured: +3.5 us per tile on the wr = 1 waves).
+// (Round 4, measured and dropped: reading the whole residual tile FIRST, in the accumulator layout, and folding it
+// into the accumulators before a plain fp32 store phase — dec.proj 57 -> 65 us: two serial phases lose more than
+// the loads gain by not queueing behind stores; profiles/r04g_nt_epilogue_residual_first.log.)
 template <typename TC, int MODE, bool FULL, bool STATS, bool BIAS_LDS = false, int NJ = 4>
 DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                      const float* __restrict__ bias, const float* __restrict__ residual,
                      const long long ldr, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out2,
                      const int accumulate, TC* __restrict__ C, long long ldc, int rbase, int cbase,
-                     int M, int N, int lane, float* __restrict__ colstats) {
+                     int M, int N, int lane, float* __restrict__ colstats,
+                     unsigned long long* tstamp = nullptr /* debug library: per-row-block time stamps */,
+                     const int prio_mode = P_EPI_PRIO_MODE /* debug library: s_setprio policy of the GELU epilogues */,
+                     const bool xpose_swap = P_EPI_XPOSE_SWAP /* GELU pair: lane exchange instead of the LDS transposition */) {
     const int r16 = lane & 15, g4 = lane >> 4;
     constexpr bool HAS_BIAS = MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
                               MODE == SSL4GIE_EPI_BIAS_RESIDUAL || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD;
@@ -316,13 +328,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                 if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
                     // gelu(u) and gelu'(u) share exp(-u^2/2) and the erf polynomial
                     f32x4 g, d;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float cdf, xpdf;
-                        gelu_parts_fast(v[q], cdf, xpdf);
-                        g[q] = v[q] * cdf;
-                        d[q] = cdf + xpdf;
-                    }
+                    gelu_grad4_fast(v, d, g);
                     put(0, nt, d);
                     put(2048, nt, g);
                 } else if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU) {
@@ -363,9 +369,66 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                 }
             }
         };
+        // GELU pair without LDS (xpose_swap): the accumulator layout gives a lane 4 consecutive columns of a row
+        // (8 B of bf16); v_permlane16_swap between the 16-lane groups g4 and g4 ^ 1 of two neighbouring column
+        // blocks turns that into 8 consecutive columns (16 B) per lane, and a wave instruction then stores
+        // 16 rows x 64 B.  No ds_write / ds_read, no lgkmcnt waits: the LDS round trip (write bandwidth is only
+        // ~85 B/clk per CU) is what the pipelined form below still pays per block.
+        if constexpr (PAIR && NJ == 4) {
+            if (xpose_swap) {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int gm = rbase + 16 * mt + r16;
+#pragma unroll
+                    for (int np = 0; np < 2; ++np) {
+                        f32x4 dA, gA, dB, gB;
+                        const f32x4 vA = acc[mt][2 * np] * alpha + bias4[2 * np];
+                        const f32x4 vB = acc[mt][2 * np + 1] * alpha + bias4[2 * np + 1];
+                        if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
+                            gelu_grad4_fast(vA, dA, gA);
+                            gelu_grad4_fast(vB, dB, gB);
+                        } else {
+                            dA = vA; dB = vB;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { gA[q] = gelu_fast(vA[q]); gB[q] = gelu_fast(vB[q]); }
+                        }
+                        auto xp = [&](const f32x4& a, const f32x4& b) -> u32x4 {
+                            const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pack_bf2(a[0], a[1]), pack_bf2(b[0], b[1]), false, false);
+                            const u32x2 s2 = __builtin_amdgcn_permlane16_swap(pack_bf2(a[2], a[3]), pack_bf2(b[2], b[3]), false, false);
+                            return u32x4{s1[0], s2[0], s1[1], s2[1]};
+                        };
+                        const u32x4 wd = xp(dA, dB), wg = xp(gA, gB);
+                        const int gn = cbase + 32 * np + 16 * (g4 & 1) + 8 * (g4 >> 1);
+                        if (FULL || (gm < M && gn < N)) {
+                            *(u32x4*)((bf16_t*)C + (size_t)gm * ldc + gn) = wd;
+                            *(u32x4*)(out2 + (size_t)gm * ldc + gn) = wg;
+                        }
+                    }
+                    if (tstamp) tstamp[mt] = __builtin_amdgcn_s_memrealtime();
+                }
+                return;
+            }
+        }
         // Software pipeline over the 8 row blocks (see p_store_f32): the transposed reads of block mt, then the
         // arithmetic and staging of block mt + 1 (in-order LDS: those writes land after the reads), then block
         // mt's stores — the GELU arithmetic of the next block hides the LDS round trip of this one.
+        // PAIR (the GELU epilogues are VALU-bound): the two waves of a SIMD are the tile's two wave rows, and
+        // VALU issue goes to the OLDER wave first — left alone the wr = 0 wave finishes at W and its partner,
+        // then alone on the SIMD at half the issue rate, at ~3 W.  Alternating the priority per row block
+        // (even blocks: wr = 0 ahead, odd: wr = 1) lets both finish at ~2 W.
+        const int wrow = (rbase >> 7) & 1;
+        // prio_mode: 0 none; 1 the wr = 1 waves ahead throughout; 2 alternate per block, wr = 1 ahead on even
+        // blocks; 3 alternate per block, wr = 0 ahead on even blocks
+        auto prio = [&](int blk) {
+            if constexpr (PAIR) {
+                const bool hi = prio_mode == 1 ? wrow == 1
+                              : prio_mode == 2 ? ((blk & 1) == 0) == (wrow == 1)
+                              : prio_mode == 3 ? ((blk & 1) == 0) == (wrow == 0) : false;
+                if (hi) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        };
+        prio(0);
         stage(0);
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
@@ -373,11 +436,14 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
             fetch(0, w0);
             if constexpr (PAIR) fetch(2048, w1);
             __builtin_amdgcn_sched_barrier(0);
+            prio(mt + 1);
             if (mt + 1 < 8) stage(mt + 1);
             __builtin_amdgcn_sched_barrier(0);
             store(w0, (bf16_t*)C, mt, true);
             if constexpr (PAIR) store(w1, out2, mt, false);
+            if (tstamp) tstamp[mt] = __builtin_amdgcn_s_memrealtime();
         }
+        if constexpr (PAIR) __builtin_amdgcn_s_setprio(0);
         if constexpr (STATS) {
             // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row groups
 #pragma unroll

@@ -57,7 +57,7 @@
 #define NT256_STAMP_WGS 16
 #define NT256_STAMP_TILES 16
 #ifdef SSL4GIE_DEBUG_KNOBS
-__device__ unsigned long long g_nt256_stamps[NT256_STAMP_WGS][NT256_STAMP_TILES][5];
+__device__ unsigned long long g_nt256_stamps[NT256_STAMP_WGS][NT256_STAMP_TILES][16];  // 0-4: see above; 5-12: row blocks
 
 extern "C" int ssl4gie_debug_nt256_stamps(void* dst, size_t bytes) {
     REQUIRE(dst && bytes <= sizeof(g_nt256_stamps));
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
                no MFMA: the epilogues alone; 8 = the time stamps of 4 taken by wave 4 (a wr = 1 wave) */,
     ConvK cg) {
 #ifdef SSL4GIE_DEBUG_KNOBS
-    const int dbg = dbg_arg;
+    const int dbg = dbg_arg & 15;
+    const int dbg_prio = dbg_arg >> 4;  // SSL4GIE_NT256_PRIO: bits 0-1 s_setprio policy of the GELU epilogues, bit 2 = LDS transposition instead of the lane exchange (gemm256.h)
 #else
     constexpr int dbg = 0;
 #endif
@@ -283,24 +284,46 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     bf16x8 a[4][2], b0[2][2], b1[2][2];
     constexpr int NI1 = NJ == 3 ? 1 : 2;  // 16-column blocks in the second B half-tile
 
-    auto mma = [&](auto QMc, auto QNc, bf16x8 (&bb)[2][2]) {
+    // row blocks [MI0, MI1) of quadrant (QM, QN): 16-row x 16-column MFMA tiles over both K-steps of the K-tile
+    auto mm = [&](auto QMc, auto QNc, auto MI0c, auto MI1c, bf16x8 (&bb)[2][2]) {
         constexpr int QM = decltype(QMc)::value, QN = decltype(QNc)::value;
+        constexpr int MI0 = decltype(MI0c)::value, MI1 = decltype(MI1c)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = MI0; mi < MI1; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < (QN == 1 ? NI1 : 2); ++ni)
+                    acc[QM * 4 + mi][QN * 2 + ni] =
+                        P_MFMA(bb[ni][ks], a[mi][ks], acc[QM * 4 + mi][QN * 2 + ni]);
+    };
+    using I4 = std::integral_constant<int, 4>;
+    // MMA segment of phase PH.  NJ == 4: one quadrant of 16 MFMAs per phase, P0 (0,0), P1 (0,1), P2 (1,1), P3 (1,0).
+    // NJ == 3: the quadrants (.,1) have one column block (8 MFMAs); the 48 MFMAs of a K-tile are dealt 12 per
+    // phase so that the two wave rows still trade equal MMA / LOAD intervals: P0 (0,0) rows 0-2; P1 (0,0) row 3 +
+    // (0,1); P2 (1,1) + (1,0) row 0; P3 (1,0) rows 1-3 — every fragment is in registers where it is used (b0 lives
+    // from P0 to P3, `a` holds A_h0 until P2's reads replace it with A_h1).
+    auto mma = [&](auto PHc) {
+        constexpr int PH = decltype(PHc)::value;
         if (dbg == 7) return;
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (CONV == 2 && QM == QN) {  // P0 / P2 have just loaded `a`
+        if constexpr (CONV == 2 && (PH == 0 || PH == 2)) {  // P0 / P2 have just loaded `a`
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) a[mi][ks] = p_relu8(a[mi][ks]);
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < (QN == 1 ? NI1 : 2); ++ni)
-                    acc[QM * 4 + mi][QN * 2 + ni] =
-                        P_MFMA(bb[ni][ks], a[mi][ks], acc[QM * 4 + mi][QN * 2 + ni]);
+        if constexpr (NJ == 4) {
+            if constexpr (PH == 0) mm(I0{}, I0{}, I0{}, I4{}, b0);
+            if constexpr (PH == 1) mm(I0{}, I1{}, I0{}, I4{}, b1);
+            if constexpr (PH == 2) mm(I1{}, I1{}, I0{}, I4{}, b1);
+            if constexpr (PH == 3) mm(I1{}, I0{}, I0{}, I4{}, b0);
+        } else {
+            if constexpr (PH == 0) mm(I0{}, I0{}, I0{}, I3{}, b0);
+            if constexpr (PH == 1) { mm(I0{}, I0{}, I3{}, I4{}, b0); mm(I0{}, I1{}, I0{}, I4{}, b1); }
+            if constexpr (PH == 2) { mm(I1{}, I1{}, I0{}, I4{}, b1); mm(I1{}, I0{}, I0{}, I1{}, b0); }
+            if constexpr (PH == 3) mm(I1{}, I0{}, I1{}, I4{}, b0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -337,6 +360,33 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             }
         }
     };
+#ifdef SSL4GIE_DEBUG_KNOBS
+    // dbg 9 / 10 (timing only; feasibility of a row-interleaved schedule): the wr = 1 waves keep their LDS-DMA and
+    // barrier duties but neither read fragments nor issue MFMAs (9), or run a GELU-sized VALU chunk (4 elements
+    // per lane) in every MMA segment instead (10) — what does the other row's K-loop cost beside that?
+    if ((dbg == 9 || dbg == 10) && wr == 1) {
+        float fake[4] = {0.01f * lane, 0.02f * lane - 0.4f, 0.3f, -0.01f * lane};
+        auto chunk = [&]() {
+            if (dbg == 10) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float cdf, xpdf;
+                    gelu_parts_fast(fake[q], cdf, xpdf);
+                    fake[q] = fake[q] * cdf * 0.5f + (cdf + xpdf) * 0.25f - 0.3f;
+                }
+            }
+        };
+        for (int T = 0; T < total_kt; ++T) {
+            issue(I3{}); __builtin_amdgcn_s_barrier(); chunk(); __builtin_amdgcn_s_barrier();
+            issue(I0{}); __builtin_amdgcn_s_barrier(); chunk(); __builtin_amdgcn_s_barrier();
+            issue(I1{}); __builtin_amdgcn_s_barrier(); chunk(); __builtin_amdgcn_s_barrier();
+            issue(I2{}); stream_wait(T + 2 < total_kt); __builtin_amdgcn_s_barrier(); chunk();
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("" ::"v"(fake[0] + fake[1] + fake[2] + fake[3]));
+        return;
+    }
+#endif
     int c_kt = 0, c_ti = 0;
     for (int T = 0; T < total_kt; ++T) {
         const int cb = T & 1;
@@ -358,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         issue(I3{});
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // B_h0 reads retired (WAR, see header)
         __builtin_amdgcn_s_barrier();
-        mma(I0{}, I0{}, b0);
+        mma(I0{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---------------- P1
@@ -369,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         __builtin_amdgcn_sched_barrier(0);
         issue(I0{});
         __builtin_amdgcn_s_barrier();
-        mma(I0{}, I1{}, b1);
+        mma(I1{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---------------- P2
@@ -380,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         __builtin_amdgcn_sched_barrier(0);
         issue(I1{});
         __builtin_amdgcn_s_barrier();
-        mma(I1{}, I1{}, b1);
+        mma(I2{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---------------- P3
@@ -389,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         // in P1..P3 (of K-tile T+2) may stay in flight
         stream_wait(T + 2 < total_kt);
         __builtin_amdgcn_s_barrier();
-        mma(I1{}, I0{}, b0);
+        mma(I3{});
         __builtin_amdgcn_sched_barrier(0);
         if (c_ti > 0 && c_kt == 0) stamp(c_ti - 1, 3);
         if (c_ti > 0 && c_kt == 1) stamp(c_ti - 1, 4);
@@ -417,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             long long x_ldr = e_ldr;
             int x_rbase = m0 + wr * 128, x_M = M, reps = 1;
             bool x_full = full, skip = false;
-            if (dbg == 1 || ((dbg == 5 || dbg == 6) && wr == 1)) skip = true;
+            if (dbg == 1 || dbg == 9 || dbg == 10 || ((dbg == 5 || dbg == 6) && wr == 1)) skip = true;
             if (dbg == 2) { x_full = false; x_M = 0; }
             if (dbg == 3) {
                 const size_t row = (size_t)(pos % (M > 0 ? M : 1));
@@ -429,12 +479,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             }
             if (dbg == 6 && full) reps = 2;  // the partner's rows too (its values are not these: timing only)
             if (skip) {
-                asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[7][3][3]));
+                asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[7][NJ - 1][3]));
             } else if (x_full) {
                 for (int rep = 0; rep < reps; ++rep)
                     p_epilogue<TC, MODE, true, STATS, true, NJ>(acc, stg, e_alpha, e_bias, x_res, x_ldr, x_aux, x_out2,
                                                       e_accumulate, x_C, dbg == 3 ? 0 : ldc, x_rbase + rep * 128,
-                                                      n0 + wc * WN, x_M, N, lane, e_colstats);
+                                                      n0 + wc * WN, x_M, N, lane, e_colstats,
+                                                      (stamping && c_ti - 1 < NT256_STAMP_TILES)
+                                                          ? &g_nt256_stamps[blockIdx.x >> 4][c_ti - 1][5] : nullptr,
+                                                      dbg_prio & 3, !(dbg_prio & 4));
             } else {
                 p_epilogue<TC, MODE, false, STATS, true, NJ>(acc, stg, e_alpha, e_bias, x_res, x_ldr, x_aux, x_out2,
                                                    e_accumulate, x_C, ldc, x_rbase, n0 + wc * WN, x_M, N, lane,
@@ -544,10 +597,12 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         static int k_epi = -1, k_role = -1;
         if (k_epi < 0) {
             const char* s = getenv("SSL4GIE_NT256_NOEPI");
-            k_epi = (s && s[0] >= '1' && s[0] <= '8') ? s[0] - '0' : 0;
+            k_epi = s ? (atoi(s) & 15) : 0;
             s = getenv("SSL4GIE_NT256_ROLE");
             k_role = s ? (s[0] - '0') : NT256_DEFAULT_ROLE;
             if (k_epi || s) fprintf(stderr, "ssl4gie: DEBUG KNOBS active: NT256_NOEPI=%d NT256_ROLE=%d\n", k_epi, k_role);
+            s = getenv("SSL4GIE_NT256_PRIO");
+            k_epi |= (s ? atoi(s) : P_EPI_PRIO_MODE) << 4;
         }
         skip_epi = k_epi;
         role = k_role;
