@@ -41,20 +41,86 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
-def dp_info(ddp, steps_run):
+def dp_verify(ddp, step, a, dev):
+    """The N > 1 line proves itself (collective: every rank calls it, right after the timed region):
+      backend_world      what the backend itself says: an all-reduce of ones on the device must sum to N
+      replicas_in_sync   MIN and MAX over ranks of a checksum of the parameter arena (fp64 sum and sum of
+                         squares) after the timed steps are equal — every rank applied the same averaged
+                         gradients (bitwise: ring / one-hop all-reduce deliver identical sums to every rank)
+      exposed_comm_ms    step time minus the same step under no_sync() (no gradient exchange), a few steps
+                         each, barrier + synchronize around both: the communication NOT hidden behind backward
+    A run whose replicas drifted apart is not a data-parallel measurement: main() exits non-zero on it
+    (reference semantics being checked: DDP's gradient averaging, main_pretrain.py:175, train_depth.py:47-48)."""
+    if ddp is None:
+        return None
+    import torch.distributed as dist
+    cuda = dev.type == "cuda"
+
+    def fence():
+        dist.barrier()
+        if cuda:
+            torch.cuda.synchronize()
+
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(ones)
+    if os.environ.get("SSL4GIE_BENCH_DESYNC_RANK") == str(dist.get_rank()):  # test hook: break one replica
+        ddp.module.arena().data[:1].add_(1.0)
+    w = ddp.module.arena().data.double()
+    chk = torch.stack([w.sum(), (w * w).sum()])
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    in_sync = bool(torch.equal(lo, hi)) and bool(torch.isfinite(chk).all())
+    k = max(1, min(a.steps, 5))
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step()
+    fence()
+    t_sync = time.perf_counter() - t0
+    with ddp.no_sync():
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        fence()
+        t_nosync = time.perf_counter() - t0
+    tt = torch.tensor([t_sync, t_nosync], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return {"backend_world": int(round(float(ones.item()))), "backend": str(dist.get_backend()),
+            "replicas_in_sync": in_sync,
+            "param_checksum": [float(lo[0]), float(hi[0])],
+            "exposed_comm_ms": round(1e3 * float(tt[0] - tt[1]) / k, 3),
+            "step_ms_without_exchange": round(1e3 * float(tt[1]) / k, 3),
+            "compute_cus": getattr(ddp, "compute_cus", None)}
+
+
+def dp_exit_if_broken(verify, world):
+    """after rank 0 has printed its line: every rank leaves with a failure code when the run did not prove
+    itself (the verdict is all-reduced, so all ranks agree; the launcher reports the non-zero exit)"""
+    if verify is not None and (not verify["replicas_in_sync"] or verify["backend_world"] != world):
+        sys.stderr.write(f"bench.py: data-parallel self-check FAILED: {verify}\n")
+        sys.exit(3)
+
+
+def dp_info(ddp, steps_run, verify=None):
     """data-parallel bookkeeping for the N > 1 lines: gradient collectives per step and how many of
     them left while backward was still running, parameters that had to be reduced on their own,
-    what carried the slices (rccl / direct / gloo in rehearsals), SyncBatchNorm exchanges per step"""
+    what carried the slices (rccl / direct / gloo in rehearsals), SyncBatchNorm exchanges per step,
+    and the self-check of dp_verify()"""
     if ddp is None:
         return {}
     from ssl4gie_amd import resnet_engine
     n = max(steps_run, 1)
-    return {"dp": {"grad_collectives_per_step": round(ddp.n_collectives / n, 2),
-                   "overlapped_with_backward_per_step": round(ddp.n_overlapped / n, 2),
-                   "late_params": ddp.n_late, "transport": ddp.transport,
-                   "passes_closed_in_backward": ddp.n_passes,
-                   "syncbn_collectives_per_step": round(resnet_engine.SYNC_BN_COLLECTIVES[0] / n, 1),
-                   "syncbn_direct_exchanges_per_step": round(resnet_engine.SYNC_BN_DIRECT[0] / n, 1)}}
+    verify = dict(verify or {})
+    snap = verify.pop("_snap", None) or (ddp.n_collectives, ddp.n_overlapped, ddp.n_late, ddp.n_passes,
+                                         resnet_engine.SYNC_BN_COLLECTIVES[0], resnet_engine.SYNC_BN_DIRECT[0])
+    return {"dp": {**verify,
+                   "grad_collectives_per_step": round(snap[0] / n, 2),
+                   "overlapped_with_backward_per_step": round(snap[1] / n, 2),
+                   "late_params": snap[2], "transport": ddp.transport,
+                   "passes_closed_in_backward": snap[3],
+                   "syncbn_collectives_per_step": round(snap[4] / n, 1),
+                   "syncbn_direct_exchanges_per_step": round(snap[5] / n, 1)}}
 
 
 def self_launch(argv):
@@ -183,16 +249,18 @@ def cpu_baseline(steps=8, warmup=2, b=8):
                       f"CPU oracle (oracle/mae_ref.py), {warmup} warm-up steps"}
 
 
-def timed_steps(step, a, world, dev):
+def timed_steps(step, a, world, dev, ddp=None):
     """the driver's timing contract: W untimed warm-up steps, then exactly K steps bracketed by a
     barrier + torch.cuda.synchronize() on both sides; returns (last loss, MAX over ranks of the
-    elapsed seconds)"""
+    elapsed seconds, the data-parallel self-check of dp_verify() — None for one rank — taken after the
+    timed region)"""
     import torch.distributed as dist
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     loss = None
     for _ in range(a.warmup):
@@ -206,7 +274,15 @@ def timed_steps(step, a, world, dev):
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    return loss, float(tt.item())
+    snap = None
+    if ddp is not None:  # the per-step figures of dp_info() describe the warm-up + timed steps only
+        from ssl4gie_amd import resnet_engine
+        snap = (ddp.n_collectives, ddp.n_overlapped, ddp.n_late, ddp.n_passes,
+                resnet_engine.SYNC_BN_COLLECTIVES[0], resnet_engine.SYNC_BN_DIRECT[0])
+    verify = dp_verify(ddp, step, a, dev)
+    if verify is not None:
+        verify["_snap"] = snap
+    return loss, float(tt.item()), verify
 
 
 def bench_depth(a):
@@ -244,10 +320,10 @@ def bench_depth(a):
         opt.step()
         return loss
 
-    loss, dt = timed_steps(step, a, world, dev)
+    loss, dt, verify = timed_steps(step, a, world, dev, ddp)
     if rank == 0:
         ips = B * world * a.steps / dt
-        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "images/sec (fwd+bwd+AdamW) ViT-B + DPT depth finetune 224x224 (BASELINE.json configs[3])",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -259,6 +335,7 @@ def bench_depth(a):
             "final_loss": round(float(loss.detach()), 5)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    dp_exit_if_broken(verify, world)
 
 
 def bench_moco(a):
@@ -302,10 +379,10 @@ def bench_moco(a):
         opt.step()
         return loss
 
-    loss, dt = timed_steps(step, a, world, dev)
+    loss, dt, verify = timed_steps(step, a, world, dev, ddp)
     if rank == 0:
         ips = B * world * a.steps / dt
-        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "image pairs/sec (fwd+bwd+LARS) MoCo-v3 ResNet50 224x224 (BASELINE.json configs[2])",
             "value": round(ips, 1), "unit": "image pairs/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -317,6 +394,7 @@ def bench_moco(a):
             "final_loss": round(float(loss.detach()), 5)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    dp_exit_if_broken(verify, world)
 
 
 def bench_vit(a):
@@ -352,10 +430,10 @@ def bench_vit(a):
         opt.step()
         return loss
 
-    loss, dt = timed_steps(step, a, world, dev)
+    loss, dt, verify = timed_steps(step, a, world, dev, ddp)
     if rank == 0:
         ips = B * world * a.steps / dt
-        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "images/sec (fwd+bwd+AdamW) ViT-B 224x224 linear-head finetune, un-masked trunk",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -367,6 +445,7 @@ def bench_vit(a):
             "final_loss": round(float(loss.detach()), 5)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    dp_exit_if_broken(verify, world)
 
 
 def bench_det(a):
@@ -402,7 +481,7 @@ def bench_det(a):
         opt.step()
         return loss
 
-    loss, dt = timed_steps(step, a, world, dev)
+    loss, dt, verify = timed_steps(step, a, world, dev, ddp)
     if rank == 0:
         ips = B * world * a.steps / dt
         # GEMM-shaped MACs per image: 12 blocks x 4096 tokens x 12 D^2, windowed attention
@@ -411,7 +490,7 @@ def bench_det(a):
         gmac = (12 * N * 12 * D * D + 8 * 2 * N * 256 * D + 4 * 2 * N * N * D + N * D * D
                 + 2 * (N * D * 4 * D) + 2 * (4 * N * D * 4 * D) + (N // 4 + N + 4 * N + 16 * N) * D * 256
                 + (N // 4 + N + 4 * N + 16 * N) * 9 * 256 * 256) / 1e9
-        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "images/sec (fwd+bwd+AdamW) detection ViT-B backbone + ViTDet FPN 1024x1024 (SURVEY 8f-1)",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -424,6 +503,7 @@ def bench_det(a):
             "final_loss": round(float(loss.detach()), 5)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    dp_exit_if_broken(verify, world)
 
 
 def bench_bt(a):
@@ -463,13 +543,13 @@ def bench_bt(a):
         opt.step()
         return loss
 
-    loss, dt = timed_steps(step, a, world, dev)
+    loss, dt, verify = timed_steps(step, a, world, dev, ddp)
     if rank == 0:
         ips = B * world * a.steps / dt
         # 212.44 GFLOP per image (two views, trunk + projector, fwd+bwd) + the three
         # 8192 x 8192 x B cross-correlation products (c, dz_A, dz_B) = 6 * 8192^2 FLOP per image
         gflop_img = 212.44 + 6 * 8192 * 8192 / 1e9
-        print(json.dumps({**dp_info(ddp, a.steps + a.warmup), 
+        print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "images/sec (two views, fwd+bwd+LARS) Barlow Twins ViT-B 224x224 (BASELINE.json configs[4])",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
@@ -482,6 +562,7 @@ def bench_bt(a):
             "final_loss": round(float(loss.detach()), 5)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    dp_exit_if_broken(verify, world)
 
 
 def main():
@@ -514,10 +595,50 @@ def main():
         t = torch.tensor([float(rank)])
         if world > 1:
             dist.all_reduce(t)
+        out = {"rendezvous": world, "rank_sum": float(t)}
+        verify = None
+        if world > 1:
+            # the N > 1 self-check of the real workloads (dp_verify), on a CPU toy: a small arena model under
+            # DataParallel + SGD, different data per rank
+            import torch.nn as nn
+            from ssl4gie_amd.engine import GradSink, ParamArena
+
+            class Toy(nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.a, self.b = nn.Linear(8, 16), nn.Linear(16, 4)
+                    self._a = ParamArena(list(self.parameters()))
+                    self._s = GradSink(self._a)
+
+                def arena(self):
+                    return self._a
+
+                def sink(self):
+                    return self._s
+
+                def forward(self, x):
+                    return (self.b(torch.tanh(self.a(x))) ** 2).mean()
+
+            torch.manual_seed(100 + rank)
+            toy = Toy()
+            ddp = parallel.DataParallel(toy)
+            opt = torch.optim.SGD(toy.parameters(), lr=0.1)
+            x = torch.randn(5, 8, generator=torch.Generator().manual_seed(7 + rank))
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                loss = ddp(x)
+                loss.backward()
+                opt.step()
+                return loss
+
+            _, _, verify = timed_steps(step, a, world, torch.device("cpu"), ddp)
+            out.update(dp_info(ddp, a.steps + a.warmup, verify))
         if rank == 0:
-            print(json.dumps({"rendezvous": world, "rank_sum": float(t)}), flush=True)
+            print(json.dumps(out), flush=True)
         if world > 1:
             dist.destroy_process_group()
+        dp_exit_if_broken(verify, world)
         return
     if a.workload == "depth":
         return bench_depth(a)
@@ -566,7 +687,7 @@ def main():
         opt.step()
         return loss
 
-    loss, dt = timed_steps(step, a, world, dev)
+    loss, dt, verify = timed_steps(step, a, world, dev, ddp)
     final_loss = float(loss.detach())
 
     # ---- roofline pass (instrumented; outside the timed region)
@@ -640,7 +761,7 @@ def main():
             "model_mfma_frac": round(ips / world * GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS, 4),
             "final_loss": round(final_loss, 5),
         }
-        line.update(dp_info(ddp, a.steps + a.warmup + a.prof_steps))
+        line.update(dp_info(ddp, a.steps + a.warmup, verify))
         if roof is not None:
             line["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
@@ -648,6 +769,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    dp_exit_if_broken(verify, world)
 
 
 if __name__ == "__main__":

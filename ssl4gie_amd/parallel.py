@@ -119,6 +119,7 @@ class DataParallel(nn.Module):
         self._avg_op = self._pick_avg_op()
         # transport of the bucket all-reduce: RCCL (default) or the library's direct xGMI exchange
         self._direct = None
+        self.compute_cus = None  # CUs the persistent GEMM grids are sized for (set below when CUs are reserved)
         import os
         if self._is_cuda and self.world > 1 and os.environ.get("SSL4GIE_ALLREDUCE", "rccl").lower() == "direct":
             self._direct = DirectAllReduce(min(self.bucket_elems * 2, self._arena.grad.numel()), process_group)
@@ -130,6 +131,7 @@ class DataParallel(nn.Module):
             r = comm_cus()
             if r > 0:
                 _lib.check(_lib.load().ssl4gie_set_compute_cus(256 - r), "set_compute_cus")
+                self.compute_cus = 256 - r
         if broadcast_parameters and self.world > 1:
             dist.broadcast(self._arena.data, src=0, group=process_group)
             # DDP also broadcasts buffers (BatchNorm running statistics) from rank 0

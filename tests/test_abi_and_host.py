@@ -285,7 +285,7 @@ def test_position_table_resize_matches_f_interpolate():
         assert gg[0, 0].abs().max() == 0  # the cls row gets no gradient
 
 
-@pytest.mark.timeout(180)
+@pytest.mark.timeout(400)
 def test_bench_self_launches_its_ranks_when_invoked_plainly():
     """`python bench.py --gpus 2 ...` with no torchrun environment (how the driver invokes N = 1) must
     start its own ranks: the parent spawns `torch.distributed.run` children before touching the GPU,
@@ -298,7 +298,20 @@ def test_bench_self_launches_its_ranks_when_invoked_plainly():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
-    assert json.loads(lines[0]) == {"rendezvous": 2, "rank_sum": 1.0}
+    line = json.loads(lines[0])
+    assert line["rendezvous"] == 2 and line["rank_sum"] == 1.0
+    # the N > 1 line proves itself: the backend saw both ranks, the replicas hold the same
+    # parameters after the steps, the exposed communication time is reported
+    dp = line["dp"]
+    assert dp["backend_world"] == 2 and dp["replicas_in_sync"] is True and dp["backend"] == "gloo"
+    assert dp["param_checksum"][0] == dp["param_checksum"][1]
+    assert isinstance(dp["exposed_comm_ms"], float) and dp["grad_collectives_per_step"] >= 1
+    # ... and a run whose replicas drifted apart fails loudly on every rank
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       env=dict(env, SSL4GIE_BENCH_DESYNC_RANK="1"), capture_output=True, text=True, timeout=170)
+    assert r.returncode != 0 and "self-check FAILED" in r.stderr
+    bad = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert bad["dp"]["replicas_in_sync"] is False
     # a failing rank is reported through the exit code
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only",
                         "--no-such-flag"], env=env, capture_output=True, text=True, timeout=170)
