@@ -136,3 +136,30 @@ def keyed_state_dict(shapes: dict, seed: int, keep=()) -> dict:
     """`shapes`: key -> shape (e.g. {k: v.shape for k, v in module.state_dict().items()}); keys in
     `keep` are left out (fixed tables the module builds itself)."""
     return {k: keyed_tensor(k, s, seed) for k, s in shapes.items() if k not in keep}
+
+
+def depth_batches(nb=4, b=2):
+    """the seeded (image, depth target) batches of the G13 curve (tests/golden/make_golden.py g13_depth_curve and
+    tests/test_gpu_curves.py): batch i of the rotation.  The target is a learnable function of the image (a
+    16 x 16 box blur of its channel mean squashed into (0, 1)) — a pure-noise target leaves the scale-and-shift
+    invariant loss flat — with ~10 % of the pixels invalid (zero), as real depth maps have."""
+    from . import mae_ref
+    out = []
+    for i in range(nb):
+        imgs = synth_images(b, mae_ref.VIT_B, seed=300 + i)
+        g = torch.Generator("cpu").manual_seed(400 + i)
+        gray = imgs.mean(1, keepdim=True)
+        blur = torch.nn.functional.avg_pool2d(gray, 17, stride=1, padding=8, count_include_pad=False)
+        tgt = torch.sigmoid(3.0 * blur / blur.std())
+        tgt = torch.where(torch.rand(b, 1, 224, 224, generator=g) < 0.1, torch.zeros(()), tgt)
+        out.append((imgs, tgt))
+    return out
+
+
+def moco_views(nb=4, b=8, size=64):
+    """the seeded view pairs of the G14 curve"""
+    out = []
+    for i in range(nb):
+        g = torch.Generator("cpu").manual_seed(500 + i)
+        out.append((torch.randn(b, 3, size, size, generator=g), torch.randn(b, 3, size, size, generator=g)))
+    return out

@@ -29,6 +29,10 @@ Fixtures written:
                       spatial), dense taps (:427-456), ViT_from_MAE + DPT depth fwd + SSI loss + grad norms
   g12_resnet_dec.npz  reference ResNet_from_Any(dense="depth"): decode() (:16-60,128-135) on seeded stage
                       maps fwd + grads, and the whole model on top of oracle/torchvision_restatement.py
+  g13_depth_curve.npz 60-step loss curve of the reference ViT_from_MAE(dense="depth") + SSI loss + AdamW(1e-4),
+                      the statement sequence of train_depth.py:35-48 (BASELINE.json configs[3]), B = 2
+  g14_moco_curve.npz  50-step loss curve of the reference MoCo_ResNet + LARS (builder.py:75-96, main_moco.py),
+                      128 x 128 views, B = 16, 1-process gloo (BASELINE.json configs[2])
 """
 from __future__ import annotations
 
@@ -686,6 +690,86 @@ def g8_moco():
     print(f"g8 moco: contrastive loss={float(out['cl/loss']):.6f}")
 
 
+def g13_depth_curve(steps=60):
+    """BASELINE.json configs[3]: the reference's own ViT_from_MAE(dense="depth") (models.py:458-475) trained with
+    its own ScaleAndShiftInvariantLoss(alpha=0.1) and AdamW(lr 2e-5) exactly as train_depth.py:35-48,230,280 does
+    (zero_grad / forward / loss / backward / step; fp32 on the CPU, no autocast), B = 2, four seeded batches in
+    rotation.  Weights: the keyed set of G11's depth model (seed 44)."""
+    rm = import_reference_models()
+    ref_loss = _load_by_path("ref_losses", os.path.join(REF, "Depth_estimation", "Metrics", "losses.py"))
+    m = rm.ViT_from_MAE(None, False, 1, False, "depth", False, None, 768, 12, 12, "cls")
+    shapes, digest = load_keyed(m, seed=44, keep=("pos_embed", "decoder_pos_embed"))
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-5)      # train_depth.py:230 (--learning-rate; at the default 1e-4
+    # this random-weight model saturates its Sigmoid head within three steps and the curve degenerates)
+    loss_fn = ref_loss.ScaleAndShiftInvariantLoss(alpha=0.1)  # train_depth.py:280
+    batches = synth.depth_batches()
+    losses = []
+    for it in range(steps):
+        data, target = batches[it % len(batches)]
+        opt.zero_grad()
+        loss = loss_fn(m(data), target)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        if it % 10 == 0:
+            print(f"  g13 step {it}: {losses[-1]:.6f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "g13_depth_curve.npz"), losses=np.array(losses, dtype=np.float64),
+                        keys=np.array(sorted(shapes)), digest=np.array(digest), lr=np.array(2e-5),
+                        batch=np.array(2), steps=np.array(steps), n_batches=np.array(len(batches)))
+    print("g13 first/last", losses[0], losses[-1])
+
+
+def g14_moco_curve(steps=50):
+    """BASELINE.json configs[2]: the reference's own MoCo_ResNet (moco/builder.py:11-110; torchvision's resnet50
+    through oracle/torchvision_restatement.py, zero_init_residual as main_moco.py builds it) trained with its own
+    LARS (moco/optimizer.py), momentum 0.99, T = 1.0, 128 x 128 views, B = 16 (at 64 x 64 / B = 8 the random-init
+    network is chaotic: 1e-4 relative weight differences move the loss by 2 %), in a 1-process gloo group (the only
+    shim: Tensor.cuda -> identity, no GPU here).  Weights: keyed set (seed 61) with the momentum encoder copied
+    from the base encoder as MoCo.__init__ does."""
+    import torch.distributed as dist
+    from functools import partial
+    import_reference_models()  # installs the torchvision restatement
+    import torchvision.models as tvm
+    ref_b = _load_by_path("ref_builder", os.path.join(REF, "Models", "moco_v3", "moco", "builder.py"))
+    ref_o = _load_by_path("ref_lars", os.path.join(REF, "Models", "moco_v3", "moco", "optimizer.py"))
+    torch.manual_seed(0)
+    m = ref_b.MoCo_ResNet(partial(tvm.resnet50, zero_init_residual=True), 256, 1024, 1.0)
+    shapes, digest = load_keyed(m, seed=61)
+    with torch.no_grad():
+        for pb, pm in zip(m.base_encoder.parameters(), m.momentum_encoder.parameters()):
+            pm.copy_(pb)
+    digest = synth.state_dict_digest(m.state_dict())
+    m.train()
+    opt = ref_o.LARS(m.parameters(), lr=0.02, weight_decay=1e-6, momentum=0.9)  # main_moco.py:213-216
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    views = synth.moco_views(b=16, size=128)
+    losses, extra = [], {}
+    try:
+        for it in range(steps):
+            x1, x2 = views[it % len(views)]
+            loss = m(x1, x2, 0.99)          # main_moco.py:336
+            opt.zero_grad()
+            loss.backward()
+            if it == 0:  # every gradient of the first step (norms; small ones in full, slices of the large ones)
+                pack_grads(extra, "step0/", [(k, p) for k, p in m.named_parameters() if p.requires_grad])
+            opt.step()
+            losses.append(float(loss))
+            if it % 10 == 0:
+                print(f"  g14 step {it}: {losses[-1]:.6f}", flush=True)
+    finally:
+        torch.Tensor.cuda = real_cuda
+        dist.destroy_process_group()
+    np.savez_compressed(os.path.join(HERE, "g14_moco_curve.npz"), losses=np.array(losses, dtype=np.float64),
+                        keys=np.array(sorted(shapes)), digest=np.array(digest), lr=np.array(0.02),
+                        batch=np.array(16), steps=np.array(steps), size=np.array(128), n_batches=np.array(len(views)),
+                        **extra)
+    print("g14 first/last", losses[0], losses[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-curve", action="store_true")
@@ -699,6 +783,7 @@ def main():
         "g5tiny": lambda: g5_tiny(ref_mae), "g5vitb": lambda: g5_vitb(ref_mae),
         "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi, "g8": g8_moco, "g9": g9_dpt_seg,
         "g3b": g3b_moco_sincos, "g10": g10_det, "g11": g11_vit_api, "g12": g12_resnet_dec,
+        "g13": g13_depth_curve, "g14": g14_moco_curve,
         "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
             **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
             "g5_curve_tiny.npz"),

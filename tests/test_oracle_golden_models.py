@@ -188,3 +188,56 @@ def test_g12_resnet_decoder_oracle_matches_reference_fixture():
                                           imgs.double())
         logits = feat @ sd2["lin_head.weight"].double().T + sd2["lin_head.bias"].double()
     assert rel_err(logits.float(), g["cls/logits"]) < 2e-3
+
+
+def test_g13_depth_curve_first_step_oracle():
+    """the first value of the reference's depth curve (tests/golden/make_golden.py g13) from the oracle: ViT-B
+    trunk with taps + DPT decoder + SSI loss on the same keyed weights and the first seeded batch"""
+    g = load_golden("g13_depth_curve.npz")
+    cfg = mae_ref.VIT_B
+    shapes = None
+    # key -> shape of the reference's ViT_from_MAE(dense="depth") state_dict: the build's module has the same schema
+    from ssl4gie_amd.Models import models
+    m = models.ViT_from_MAE(None, False, 1, False, "depth", False, None, 768, 12, 12, "cls")
+    sd = keyed_weights(m, 44, g["keys"], g["digest"], keep=("pos_embed", "decoder_pos_embed"))
+    imgs, target = synth.depth_batches()[0]
+    with torch.no_grad():
+        taps = mae_ref.vit_trunk(sd, cfg, imgs, True)
+        pred = dpt_ref.dpt_forward({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, taps)
+        loss = dpt_ref.ssi_loss(pred, target, alpha=0.1)
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-4 * float(g["losses"][0])
+
+
+def test_g14_moco_curve_first_step_oracle_fp64():
+    """the first value of the reference's MoCo-R50 curve (g14) from the fp64 oracle composition (ResNet50 trunk,
+    MLP heads, InfoNCE) — the forward is well-conditioned (1.7e-6), unlike its gradients (test_gpu_curves.py)"""
+    from oracle import moco_ref
+    g = load_golden("g14_moco_curve.npz")
+    from functools import partial
+    from ssl4gie_amd.Models.moco_v3.moco import builder
+    from ssl4gie_amd.Models.resnet import resnet50
+    torch.manual_seed(0)
+    m = builder.MoCo_ResNet(partial(resnet50, zero_init_residual=True), 256, 1024, 1.0)
+    own = m.state_dict()
+    assert sorted(own) == sorted(g["keys"].tolist())
+    sd32 = synth.keyed_state_dict({k: tuple(v.shape) for k, v in own.items()}, 61)
+    for k in list(sd32):
+        kb = "base_encoder." + k[len("momentum_encoder."):]
+        if k.startswith("momentum_encoder.") and "running" not in k and "num_batches" not in k:
+            sd32[k] = sd32[kb].clone()
+    assert synth.state_dict_digest(sd32) == str(g["digest"])
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}
+    x1, x2 = synth.moco_views(b=16, size=128)[0]
+    x1, x2 = x1.double(), x2.double()
+
+    def enc(prefix, x):
+        sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        return moco_ref.mlp_forward(sub, "fc.", resnet_ref.resnet50_pooled(sub, x))
+
+    with torch.no_grad():
+        pred = {k[len("predictor."):]: v for k, v in sd.items() if k.startswith("predictor.")}
+        q1 = moco_ref.mlp_forward(pred, "", enc("base_encoder.", x1))
+        q2 = moco_ref.mlp_forward(pred, "", enc("base_encoder.", x2))
+        k1, k2 = enc("momentum_encoder.", x1), enc("momentum_encoder.", x2)
+        loss = moco_ref.contrastive_loss(q1, k2, 1.0) + moco_ref.contrastive_loss(q2, k1, 1.0)
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-5 * float(g["losses"][0])
