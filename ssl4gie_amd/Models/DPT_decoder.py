@@ -21,7 +21,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..dpt_engine import (AddFn, Conv3x3Fn, ConvTransposeFn, DepthHeadFn, SegHeadFn, TokensToMapFn,
+from ..dpt_engine import (AddFn, Conv3x3Fn, ForkFn, ConvTransposeFn, DepthHeadFn, SegHeadFn, TokensToMapFn,
                           Upsample2xFn)
 from ..engine import EngineModule, LinearFn
 from ..resnet_engine import BatchNormFn
@@ -122,14 +122,15 @@ class DPT_decoder(EngineModule):
 
     def _rcu(self, x, rcu: _RCU):
         """out = [bn2](conv2(relu([bn1](conv1(relu(x)))))) + x  (reference :212-233)"""
+        x, skip = ForkFn.apply(x)  # two consumers: the gradients meet in the library's add kernel, not autograd's
         if rcu.bn:
             out, st = self._c3_stats(x, rcu.conv1, relu_in=True)
             out = self._bn(out, rcu.bn1, relu=True, stats=st)
             out, st = self._c3_stats(out, rcu.conv2)
-            return self._bn(out, rcu.bn2, res=x, stats=st)  # the skip add rides on bn2
+            return self._bn(out, rcu.bn2, res=skip, stats=st)  # the skip add rides on bn2
         out = self._c3(x, rcu.conv1, relu_in=True)
         out = self._c3(out, rcu.conv2, relu_in=True)
-        return AddFn.apply(out, x)
+        return AddFn.apply(out, skip)
 
     def _fusion(self, blk: _Fusion, x0, x1=None):
         """reference :281-301; refinenet4 gets one input, so its resConfUnit1 never runs"""

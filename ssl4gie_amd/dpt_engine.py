@@ -258,6 +258,22 @@ class Upsample2xFn(torch.autograd.Function):
         return ops.bilinear2x_bwd(dy.contiguous())
 
 
+class ForkFn(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (the input of a residual unit feeds its first convolution AND
+    its skip add, DPT_decoder.py:212-233): autograd would otherwise sum the two incoming gradients itself, with a
+    torch clone + add kernel per fork (7 per depth step); here the sum is the library's element-wise kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        return ops.eltwise_add(ga.contiguous(), gb.contiguous())
+
+
 class AddFn(torch.autograd.Function):
     """skip_add.add (:233, :290): FloatFunctional in float mode is a plain add."""
 
