@@ -47,6 +47,7 @@
 #include <type_traits>
 
 #define NT256_DEFAULT_ROLE 0
+#define NT256_DEFAULT_PH2 true
 
 // Diagnostics (SSL4GIE_NT256_NOEPI=4): wave 0 of every 16th workgroup stamps s_memrealtime (100 MHz) at five
 // points of every output tile — K-loop start, epilogue start, epilogue end (last store issued), end of the
@@ -79,7 +80,7 @@ extern "C" int ssl4gie_debug_nt256_stamps(void*, size_t) { return ARG_ERR; }
 //       M = 12800: 150 tiles on 240 CUs -> 200 tiles of 3/4 the work).  Same four phases, barriers and LDS-DMA
 //       placement; the second B half-tile shrinks to 64 rows (one piece per wave, columns 48 wc + 32 .. 47) and
 //       the phases that use it run 8 MFMAs instead of 16.
-template <typename TC, int MODE, int CONV, bool STATS = false, int ROLE = 0, int NJ = 4>
+template <typename TC, int MODE, int CONV, bool STATS = false, int ROLE = 0, int NJ = 4, bool PH2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
     TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e,
@@ -394,53 +395,108 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             stamp(c_ti, 0);
             if (dbg != 7) issue_bias(c_ti);
         }
+        if constexpr (PH2) {
+            // Two phases per K-tile (32 MFMAs per MMA segment, 4 barriers per K-tile instead of 8): the interval
+            // is set by the MMA segment plus a fixed ~100 cycles of barrier / wait / issue overhead, so halving
+            // the number of intervals per K-tile removes half of that overhead.  Register-neutral: Pa holds
+            // A_h0 + B_h0 + B_h1 (quadrants (0,0), (0,1)), Pb replaces A_h0 by A_h1 (quadrants (1,1), (1,0)).
+            // Hazards (interval I_n between barriers n-1 and n; the wr = 0 group runs LOAD(p) in I_2p, MMA(p) in
+            // I_2p+1 with p = 2 T + {0: Pa, 1: Pb}; the wr = 1 group one interval later):
+            //   WAR  every LOAD segment ends with s_waitcnt lgkmcnt(0) BEFORE its barrier, so a group's fragment
+            //        reads are complete when the next interval starts.  Pb issues B_h0, A_h0, B_h1 of K-tile
+            //        T + 2 over the slots read in Pa (wr = 0: two intervals earlier; wr = 1: one interval earlier,
+            //        complete at that interval's barrier); Pa issues A_h1 of K-tile T + 1 over the slot read in
+            //        Pb of K-tile T - 1 (same distances).
+            //   RAW  one counted wait per K-tile at the end of LOAD(Pb): all but the three half-tiles just issued
+            //        (K-tile T + 2) have landed, i.e. the whole of K-tile T + 1; it is read from LOAD(Pa(T + 1)),
+            //        two barriers later for the waiting group and at least one barrier later for the other one.
+            // ---------------- Pa
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = ldB(cb, 0, ni, ks);
+#pragma unroll
+            for (int ni = 0; ni < NI1; ++ni)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = ldB(cb, 1, ni, ks);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 0, mi, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(I3{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            mma(I0{});
+            mma(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- Pb
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 1, mi, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(I0{});
+            issue(I1{});
+            issue(I2{});
+            stream_wait(T + 2 < total_kt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            mma(I2{});
+            mma(I3{});
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         // ---------------- P0
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = ldB(cb, 0, ni, ks);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 0, mi, ks);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(I3{});
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // B_h0 reads retired (WAR, see header)
-        __builtin_amdgcn_s_barrier();
-        mma(I0{});
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- P1
-#pragma unroll
-        for (int ni = 0; ni < NI1; ++ni)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = ldB(cb, 1, ni, ks);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(I0{});
-        __builtin_amdgcn_s_barrier();
-        mma(I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- P2
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 1, mi, ks);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(I1{});
-        __builtin_amdgcn_s_barrier();
-        mma(I2{});
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- P3
-        issue(I2{});
-        // K-tile T+1 must have landed before the next phase reads it; the three half-tiles issued
-        // in P1..P3 (of K-tile T+2) may stay in flight
-        stream_wait(T + 2 < total_kt);
-        __builtin_amdgcn_s_barrier();
-        mma(I3{});
-        __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = ldB(cb, 0, ni, ks);
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 0, mi, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(I3{});
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // B_h0 reads retired (WAR, see header)
+            __builtin_amdgcn_s_barrier();
+            mma(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- P1
+    #pragma unroll
+            for (int ni = 0; ni < NI1; ++ni)
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = ldB(cb, 1, ni, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(I0{});
+            __builtin_amdgcn_s_barrier();
+            mma(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- P2
+    #pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[mi][ks] = ldA(cb, 1, mi, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(I1{});
+            __builtin_amdgcn_s_barrier();
+            mma(I2{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- P3
+            issue(I2{});
+            // K-tile T+1 must have landed before the next phase reads it; the three half-tiles issued
+            // in P1..P3 (of K-tile T+2) may stay in flight
+            stream_wait(T + 2 < total_kt);
+            __builtin_amdgcn_s_barrier();
+            mma(I3{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (c_ti > 0 && c_kt == 0) stamp(c_ti - 1, 3);
         if (c_ti > 0 && c_kt == 1) stamp(c_ti - 1, 4);
         if (++c_kt == nk) {
@@ -589,23 +645,27 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
               d->colstats};
     int skip_epi = 0;
     [[maybe_unused]] int role = NT256_DEFAULT_ROLE;
+    [[maybe_unused]] bool ph2 = NT256_DEFAULT_PH2;
 #ifdef SSL4GIE_DEBUG_KNOBS
     // debug library only (make DEBUG_KNOBS=1 -> libssl4gie_hip_dbg.so, loaded with SSL4GIE_DEBUG_LIB=1):
     // SSL4GIE_NT256_NOEPI=1..7 ablations (the kernel's `dbg`; all but 4 leave garbage outputs),
     // SSL4GIE_NT256_ROLE=0/1 the LDS-DMA ownership
     {
-        static int k_epi = -1, k_role = -1;
+        static int k_epi = -1, k_role = -1, k_ph2 = 0;
         if (k_epi < 0) {
             const char* s = getenv("SSL4GIE_NT256_NOEPI");
             k_epi = s ? (atoi(s) & 15) : 0;
             s = getenv("SSL4GIE_NT256_ROLE");
             k_role = s ? (s[0] - '0') : NT256_DEFAULT_ROLE;
             if (k_epi || s) fprintf(stderr, "ssl4gie: DEBUG KNOBS active: NT256_NOEPI=%d NT256_ROLE=%d\n", k_epi, k_role);
+            s = getenv("SSL4GIE_NT256_PH2");
+            k_ph2 = s ? atoi(s) : (NT256_DEFAULT_PH2 ? 1 : 0);
             s = getenv("SSL4GIE_NT256_PRIO");
             k_epi |= (s ? atoi(s) : P_EPI_PRIO_MODE) << 4;
         }
         skip_epi = k_epi;
         role = k_role;
+        ph2 = k_ph2 != 0;
     }
 #endif
     ConvK ck{};
@@ -615,24 +675,26 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     }
     ProfScope prof(PROF_GEMM_NT, 2.0 * d->M * d->N * d->K, st);
 #ifdef SSL4GIE_DEBUG_KNOBS
-#define P_LAUNCH(TC_, MODE_)                                       \
-    do {                                                            \
-        if (nj == 3) P_LAUNCH_R(TC_, MODE_, 0, false, 0, 3);        \
-        else if (role == 1) P_LAUNCH_R(TC_, MODE_, 0, false, 1, 4); \
-        else P_LAUNCH_R(TC_, MODE_, 0, false, 0, 4);                \
-    } while (0)
-#else
 #define P_LAUNCH(TC_, MODE_)                                                   \
     do {                                                                        \
-        if (nj == 3) P_LAUNCH_R(TC_, MODE_, 0, false, 0, 3);                    \
-        else P_LAUNCH_R(TC_, MODE_, 0, false, NT256_DEFAULT_ROLE, 4);           \
+        if (nj == 3 && ph2) P_LAUNCH_R(TC_, MODE_, 0, false, 0, 3, true);       \
+        else if (nj == 3) P_LAUNCH_R(TC_, MODE_, 0, false, 0, 3, false);        \
+        else if (role == 1) P_LAUNCH_R(TC_, MODE_, 0, false, 1, 4, false);      \
+        else if (ph2) P_LAUNCH_R(TC_, MODE_, 0, false, 0, 4, true);             \
+        else P_LAUNCH_R(TC_, MODE_, 0, false, 0, 4, false);                     \
+    } while (0)
+#else
+#define P_LAUNCH(TC_, MODE_)                                                              \
+    do {                                                                                   \
+        if (nj == 3) P_LAUNCH_R(TC_, MODE_, 0, false, 0, 3, NT256_DEFAULT_PH2);            \
+        else P_LAUNCH_R(TC_, MODE_, 0, false, NT256_DEFAULT_ROLE, 4, NT256_DEFAULT_PH2);   \
     } while (0)
 #endif
 #define P_LAUNCH_C(TC_, MODE_, CONV_) P_LAUNCH_S(TC_, MODE_, CONV_, false)
-#define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_) P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, 0, 4)
-#define P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_)                                          \
+#define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_) P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, 0, 4, false)
+#define P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_)                                        \
     do {                                                                                           \
-        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_, ROLE_, NJ_>;                  \
+        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_>;            \
         static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
         if (!attr_set) {                                                                           \
             HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
