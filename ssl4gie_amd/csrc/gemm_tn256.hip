@@ -4,8 +4,10 @@
 // (K = T = 12 800 / 50 432 in the MAE step) while M, N are the small layer widths, so the work is
 // split along K across workgroups (fp32 slabs + deterministic slab reduction, no atomics).
 //
-// Same schedule as gemm_nt256.hip (4 phases per K-tile, two staggered wave rows, LDS-DMA half-tile
-// stream 7 ahead behind a counted vmcnt) — see the header there for the hazard bookkeeping.  What
+// The four-phase schedule gemm_nt256.hip had until round 4 (4 phases per K-tile of 16 MFMAs, two staggered wave
+// rows, LDS-DMA half-tile stream 7 ahead behind a counted vmcnt; hazard bookkeeping in that file's header).  The
+// two-phase form that made the NT K-loop 8 % faster was measured here too and is 4-5 % SLOWER (dec.dWfc1 104 ->
+// 116 us, profiles/r04t_tn_two_phase.log): a phase would issue 32 transposed reads against the 4-bit lgkmcnt.  What
 // differs is the operand image: both operands are k-major in memory, so a half-tile is 64 k-rows x
 // 256 B (128 m- or n-values), staged by 4-row LDS-DMA pieces, and MFMA fragments are gathered
 // with ds_read_b64_tr_b16 (hardware transpose, two reads per fragment).  Image: 16-B chunk c of
