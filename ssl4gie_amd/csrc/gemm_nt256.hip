@@ -691,7 +691,15 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     } while (0)
 #endif
 #define P_LAUNCH_C(TC_, MODE_, CONV_) P_LAUNCH_S(TC_, MODE_, CONV_, false)
-#define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_) P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, 0, 4, false)
+#ifdef SSL4GIE_DEBUG_KNOBS
+#define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_)                            \
+    do {                                                                  \
+        if (ph2) P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, 0, 4, true);       \
+        else P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, 0, 4, false);          \
+    } while (0)
+#else
+#define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_) P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, 0, 4, NT256_DEFAULT_PH2)
+#endif
 #define P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_)                                        \
     do {                                                                                           \
         auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_>;            \
