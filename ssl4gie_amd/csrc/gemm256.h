@@ -464,6 +464,9 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
             }
         }
     } else {
+        // (Round 4, measured and dropped: fp32 outputs straight from the accumulator layout — 16 rows x 64 B per
+        // wave instruction, no LDS — are SLOWER than the transposed 4 rows x 256 B stores: dec.proj 101 -> 114 us,
+        // epilogue issue 5.1 / 8.4 -> 9.8 / 12.9 us (wave 0 / wave 4); profiles/r04v_nt_f32_direct_vs_lds.log.)
         p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL, NJ>(
             acc, stg, alpha, bias_t, residual, ldr, MODE == SSL4GIE_EPI_NONE && accumulate, (float*)C,
             ldc, rbase, cbase, M, N, lane);
