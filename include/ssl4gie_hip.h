@@ -575,7 +575,7 @@ int ssl4gie_dice_loss(const float* logits, const float* target, float* loss, flo
  *            synchronisation).  Every rank must enqueue the same sequence of sizes; sums run in rank
  *            order on every rank, so all ranks end with bitwise identical values;
  *   error    the handle's sticky error word: 0, or (sequence number << 8 | 1 + peer rank) of the first
- *            bucket in which a waiting kernel gave up on a peer (bounded poll: ~30 s, SSL4GIE_AR_TIMEOUT_S
+ *            bucket in which a waiting kernel gave up on a peer (bounded poll: 10 min by default, SSL4GIE_AR_TIMEOUT_S
  *            or set_timeout).  Such a kernel writes NaN instead of stale sums; from then on enqueue
  *            returns SSL4GIE_EPEER (1001) and ssl4gie_amd.parallel.DataParallel raises.  Read without
  *            synchronising (mapped host memory);

@@ -62,7 +62,10 @@ def load_file(path, map_location="cpu", trusted=None):
     try:
         with torch.serialization.safe_globals(_reference_payload_globals()):
             return torch.load(path, map_location=map_location, weights_only=True)
-    except (pickle.UnpicklingError, RuntimeError) as e:
+    except (pickle.UnpicklingError, RuntimeError, AttributeError, TypeError) as e:
+        # AttributeError / TypeError: torch < 2.6 has no `safe_globals` or rejects the (callable, "module.path")
+        # entries of the allow-list — the same refusal / opt-in path applies there (torch >= 2.6 is the supported
+        # floor for the restricted load)
         if trusted is None:
             trusted = os.environ.get("SSL4GIE_TRUSTED_CHECKPOINTS", "0") == "1"
         if not trusted:

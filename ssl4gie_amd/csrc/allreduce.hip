@@ -217,12 +217,13 @@ extern "C" int ssl4gie_allreduce_direct_init(int rank, int world, size_t max_ele
     void* p = nullptr;
     hipError_t e = hipExtMallocWithFlags(&p, L.total, hipDeviceMallocFinegrained);
     if (e != hipSuccess) { (void)hipGetLastError(); free(h); return (int)e; }
-    // ~30 s by default (SSL4GIE_AR_TIMEOUT_S): long enough for a rank that writes a checkpoint or
-    // evaluates between two steps, short enough not to look like a hung device
+    // 10 minutes by default, NCCL's own watchdog scale (SSL4GIE_AR_TIMEOUT_S; ssl4gie_allreduce_direct_set_timeout
+    // for tests): the reference's loops let rank 0 write a multi-GB checkpoint or evaluate with no barrier while
+    // the other ranks already sit in the next step's exchange — a healthy run must survive that.
     {
         const char* ev = getenv("SSL4GIE_AR_TIMEOUT_S");
-        double secs = ev ? atof(ev) : 30.0;
-        if (!(secs > 0)) secs = 30.0;
+        double secs = ev ? atof(ev) : 600.0;
+        if (!(secs > 0)) secs = 600.0;
         h->max_spins = (long long)(secs * 3.0e6);
         if (h->max_spins < 1) h->max_spins = 1;
     }

@@ -498,7 +498,7 @@ class DirectAllReduce:
                     "allgather_direct_enqueue")
 
     def set_timeout(self, seconds: float):
-        """bound of one in-kernel wait for a peer (default 30 s / SSL4GIE_AR_TIMEOUT_S)"""
+        """bound of one in-kernel wait for a peer (default 600 s / SSL4GIE_AR_TIMEOUT_S)"""
         self._check(self.L.ssl4gie_allreduce_direct_set_timeout(self.h, float(seconds)), "allreduce_direct_set_timeout")
 
     def all_reduce_(self, t: torch.Tensor, scale: float, stream=None):

@@ -231,6 +231,19 @@ def test_checkpoint_files_with_non_tensor_payload_load(tmp_path):
         checkpoints.load_file(str(f3))
     with pytest.warns(UserWarning):
         assert checkpoints.load_file(str(f3), trusted=True)["extra"]["a"] == 1
+    # an `args` Namespace that carries a pathlib.Path (output_dir=Path(...)) or a list is a realistic MAE payload
+    # outside the allow-list: refused with the same message, loadable with the explicit opt-in
+    import pathlib
+    f4 = tmp_path / "mae_path.pth"
+    torch.save({"model": sd, "args": argparse.Namespace(output_dir=pathlib.Path("/tmp/out"), blr=[1e-3, 2e-3])}, f4)
+    try:
+        ck = checkpoints.load_file(str(f4))           # lists are plain pickle; Path needs the opt-in
+        assert ck["args"].blr == [1e-3, 2e-3]
+    except RuntimeError as e:
+        assert "trusted" in str(e)
+        with pytest.warns(UserWarning):
+            ck = checkpoints.load_file(str(f4), trusted=True)
+        assert ck["args"].output_dir == pathlib.Path("/tmp/out")
 
 
 def test_augreg_npz_loader_round_trip(tmp_path, monkeypatch):
