@@ -120,7 +120,7 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
     const bool mine = NJ == 4 || Cc < 4 * NJ;  // this lane's 4 columns exist in the wave tile
     // the residual rows are fetched PF blocks ahead (a ring of PF x 4 row segments in the registers
     // that held the operand fragments): one exposed HBM round trip per tile instead of one per block
-    constexpr int PF = 2;  // (+ the 16 registers of the pipelined block: 48 in all, the dead operand fragments)
+    constexpr int PF = NJ == 3 ? 3 : 2;  // row blocks ahead (+ the 16 registers of the pipelined block); 3 spills at NJ = 4
     f32x4 rs[PF][4];
     auto fetch = [&](int mt, f32x4 (&dst)[4]) {
 #pragma unroll
