@@ -8,6 +8,9 @@ from ssl4gie_amd import ops
 torch.manual_seed(0)
 CASES = [("mae.enc", 256, 50, 12, 64), ("mae.dec", 256, 197, 16, 32), ("vitb.full", 256, 197, 12, 64),
          ("det.window", 64, 256, 12, 64), ("det.global", 4, 4096, 12, 64)]
+if os.environ.get("ATTN_SMALL"):  # the same heads at a batch whose tensors stay cache-resident: compute-bound time
+    CASES = [("mae.dec/8", 32, 197, 16, 32), ("mae.dec", 256, 197, 16, 32), ("mae.dec/4", 64, 197, 16, 32),
+             ("vitb/8", 32, 197, 12, 64), ("vitb.full", 256, 197, 12, 64)]
 
 
 def timeit(fn, iters=20):
