@@ -14,10 +14,12 @@
  *   - returns 0 on success, SSL4GIE_EARG (1000) for an invalid argument, otherwise a hipError_t;
  *   - callable from any host thread; the only mutable process-wide settings are the execution
  *     options ssl4gie_set_wgrad_stream / ssl4gie_set_compute_cus and the profiler;
- *   - ssl4gie_abi_version() = 4 (1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`; 2: before
+ *   - ssl4gie_abi_version() = 5 (1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`; 2: before
  *     ssl4gie_block_bwd's `accumulate` became a flag word and the grouped / deferred weight-gradient
  *     entry points existed; 3: before the direct transport's error word / time-out / all-gather,
- *     ssl4gie_bn_combine_stats and ssl4gie_debug_nt256_stamps existed — additions only);
+ *     ssl4gie_bn_combine_stats and ssl4gie_debug_nt256_stamps existed — additions only; 4: before
+ *     ssl4gie_gemm_desc gained `scale` / `relu` (appended; SSL4GIE_EPI_AFFINE_AUX_RELU and the
+ *     statistics-only product with C == NULL) and ssl4gie_bn_bwd_xmask / ssl4gie_bn_coef_partials existed);
  *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
  *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
  */
@@ -78,9 +80,16 @@ enum {
     SSL4GIE_EPI_RELU_MASK_AUX = 7,  /* C = aux[m,n] > 0 ? acc : 0: gradient through the ReLU in front of a
                                        convolution (aux = the convolution's input); implicit-conv NT
                                        products with bf16 output only */
-    SSL4GIE_EPI_ADD_AUX = 8         /* C = acc + aux[m,n]: a second gradient contribution of the same
+    SSL4GIE_EPI_ADD_AUX = 8,        /* C = acc + aux[m,n]: a second gradient contribution of the same
                                        tensor (residual branch) joined in the data-gradient GEMM;
                                        256x256 NT kernel, bf16 output only */
+    SSL4GIE_EPI_AFFINE_AUX_RELU = 9 /* C = act(acc * scale[n] + bias[n] (+ aux[m,n])), act = ReLU if `relu`:
+                                       the training-mode BatchNorm after a 1x1 convolution (scale = rstd gamma,
+                                       bias = beta - mean scale, from a statistics-only first product: colstats
+                                       with C == NULL), the bottleneck's residual add and ReLU, applied to the
+                                       fp32 accumulators — the raw convolution output is never written or re-read
+                                       (torchvision Bottleneck conv3 / bn3 / downsample under torch.no_grad();
+                                       256x256 NT kernel, bf16 output only; aux may be NULL) */
 };
 /* Implicit patch-matrix operand of a 3x3 / pad-1 convolution over a channels-last bf16 map
  * x [B, H, W, C] (ssl4gie_gemm_desc::conv).  The patch matrix
@@ -132,8 +141,12 @@ typedef struct ssl4gie_gemm_desc {
     /* optional fp32 [ceil(M / 128)][2][N]: per 128-row block, the column sums ([0]) and sums of
      * squares ([1]) of the STORED outputs — the batch statistics of the BatchNorm that follows a
      * convolution, produced by the GEMM's epilogue (see ssl4gie_bn_fwd_partials).  NT products with
-     * bf16 C, EPI_NONE, no accumulate, N % 8 == 0 only; anything else is SSL4GIE_EARG. */
+     * bf16 C, EPI_NONE, no accumulate, N % 8 == 0 only; anything else is SSL4GIE_EARG.  With C == NULL the
+     * product only produces these statistics (of the values it WOULD store, bf16-rounded): nothing is written
+     * to C — the first half of the BatchNorm-fused 1x1 convolution (SSL4GIE_EPI_AFFINE_AUX_RELU). */
     float* colstats;
+    const float* scale; /* [N], SSL4GIE_EPI_AFFINE_AUX_RELU only */
+    int relu;           /* SSL4GIE_EPI_AFFINE_AUX_RELU only */
 } ssl4gie_gemm_desc;
 size_t ssl4gie_gemm_workspace_bytes(const ssl4gie_gemm_desc* d);
 int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t workspace_bytes,
@@ -432,6 +445,14 @@ int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, const float* ga
                    const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
                    float* dbeta, int accumulate, int relu, float* workspace, int dtype,
                    long long rows, int C, void* stream);
+/* The same backward for BatchNorm + ReLU WITHOUT a residual input (bn1 / bn2 of a torchvision Bottleneck, the
+ * stem's bn1): the ReLU mask is rebuilt as x a + b > 0 from the forward's own coefficients (a = rstd gamma,
+ * b = beta - mean a: gamma / beta must be the forward's) instead of read from the ReLU output — the two passes
+ * stream 5 tensors instead of 7.  The results equal ssl4gie_bn_bwd(relu = 1, dres = NULL) exactly unless the
+ * forward rounded a positive pre-activation below the operand type's smallest subnormal to zero. */
+int ssl4gie_bn_bwd_xmask(const void* dy, const void* x, const float* gamma, const float* beta,
+                         const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                         int accumulate, float* workspace, int dtype, long long rows, int C, void* stream);
 /* SyncBatchNorm (convert_sync_batchnorm: Depth_estimation/train_depth.py:225,
  * Models/moco_v3/main_moco.py:196) = the same kernels with the exchange step between them:
  *   forward : ssl4gie_bn_stats (LOCAL mean / biased var) -> caller combines over ranks ->
@@ -467,6 +488,15 @@ int ssl4gie_bn_fwd_partials(const void* x, const float* partial, int parts, cons
                             float* running_mean, float* running_var, float momentum, float eps,
                             int relu, float* workspace, int dtype, long long rows, int C,
                             void* stream);
+/* The statistics half of ssl4gie_bn_fwd_partials alone: mean / rstd / running statistics and coef [2][C] with
+ * y = x coef[0][c] + coef[1][c], for a consumer that applies the normalisation itself — the
+ * SSL4GIE_EPI_AFFINE_AUX_RELU epilogue of the 1x1 convolution recomputed after its statistics-only product
+ * (torchvision Bottleneck conv3 + bn3 (+ identity, ReLU) and downsample under torch.no_grad(): MoCo's momentum
+ * encoder, moco/builder.py:127-135). */
+int ssl4gie_bn_coef_partials(const float* partial, int parts, const float* gamma, const float* beta,
+                             float* mean, float* rstd, float* running_mean, float* running_var,
+                             float momentum, float eps, float* coef, float* workspace, long long rows, int C,
+                             void* stream);
 int ssl4gie_bn_stats_partials(const float* partial, int parts, float* mean, float* var,
                               float* workspace, long long rows, int C, void* stream);
 int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* arg, int dtype, int B, int H,

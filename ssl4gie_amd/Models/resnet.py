@@ -22,8 +22,11 @@ from ..dpt_engine import Conv3x3Fn
 _GRAD_JOIN = os.environ.get("SSL4GIE_GRAD_JOIN", "1") != "0"
 # SSL4GIE_BN_STATS_FUSED=0: BatchNorm statistics by their own pass over the map (A/B measurements)
 _BN_STATS = os.environ.get("SSL4GIE_BN_STATS_FUSED", "1") != "0"
+# SSL4GIE_BN_RECOMPUTE=0: the 1x1 convolutions that widen a map 4x (conv3, downsample) write their raw output and
+# a BatchNorm pass re-reads it under torch.no_grad() too (A/B measurements)
+_BN_RECOMPUTE = os.environ.get("SSL4GIE_BN_RECOMPUTE", "1") != "0"
 from ..engine import EngineModule, GradJoin, LinearFn
-from ..resnet_engine import AvgPoolFn, BatchNormFn, MaxPoolFn, StemConvFn, Subsample2Fn
+from ..resnet_engine import AvgPoolFn, BatchNormFn, MaxPoolFn, StemConvFn, Subsample2Fn, _count_batch, _sync_group
 
 
 class Bottleneck(nn.Module):
@@ -96,6 +99,42 @@ class ResNet50(EngineModule):
         y, st = r if _BN_STATS else (r, None)
         return y.view(B, H, W, -1), st
 
+    def _c1_bn_nograd(self, x, conv, bn, relu, res=None):
+        """1x1 convolution + training-mode BatchNorm (+ residual) (+ ReLU) when nothing is kept for a backward pass
+        (torch.no_grad(): MoCo's momentum encoder, moco/builder.py:127-135) and the map gets WIDER (conv3,
+        downsample: C -> 4C): the product runs twice — first for the batch statistics alone (colstats with C == NULL:
+        nothing written), then with the normalisation, the residual add and the ReLU in its epilogue — instead of
+        writing the raw 4C-wide map and re-reading it in a BatchNorm pass: 2.5 instead of 4.25 passes over that map.
+        The statistics are those of the bf16-rounded raw outputs, as on the other path; the affine map is applied to
+        the fp32 accumulators (one rounding less).  Returns None when the shapes do not qualify."""
+        from .. import ops
+        if conv.stride[0] == 2:
+            x = ops.subsample2(x.contiguous())
+        B, H, W, C = x.shape
+        n_out = conv.weight.shape[0]
+        x2 = x.reshape(-1, C)
+        w, _ = self.lp_cache.get(conv.weight, self.dtype_)
+        stats = ops.linear_colstats_only(x2, w)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        coef, _, _ = ops.bn_coef_partials(stats, x2.shape[0], bn.weight.detach() if bn.weight is not None else None,
+                                          bn.bias.detach() if bn.bias is not None else None, bn.running_mean,
+                                          bn.running_var, mom, bn.eps)
+        if bn.num_batches_tracked is not None:
+            _count_batch(bn)
+        r2 = res.contiguous().view(-1, n_out) if res is not None else None
+        return ops.linear_affine_fwd(x2, w, coef[0], coef[1], r2, relu).view(B, H, W, n_out)
+
+    def _recompute_ok(self, x, conv, bn):
+        from .. import ops
+        if not _BN_RECOMPUTE or torch.is_grad_enabled() or self.dtype_ != torch.bfloat16:
+            return False
+        if not (bn.training or bn.running_mean is None) or _sync_group(bn)[0]:
+            return False
+        st = conv.stride[0]
+        rows = x.shape[0] * ((x.shape[1] - 1) // st + 1) * ((x.shape[2] - 1) // st + 1)
+        return conv.weight.shape[0] > conv.weight.shape[1] and \
+            ops.colstats_ok(rows, conv.weight.shape[0], conv.weight.shape[1], self.dtype_)
+
     def _block(self, x, blk: Bottleneck):
         # every convolution hands the batch statistics of its output to the BatchNorm that follows
         # (column sums from the GEMM epilogue): no separate statistics pass over the maps
@@ -107,12 +146,17 @@ class ResNet50(EngineModule):
                             self.lp_cache, _BN_STATS)
         out, st = r if _BN_STATS else (r, None)
         out = self._bn(out, blk.bn2, True, stats=st)
-        out, st = self._c1(out, blk.conv3)
         identity = x
         if blk.downsample is not None:
-            idn, sti = self._c1(x, blk.downsample[0], join)
-            identity = self._bn(idn, blk.downsample[1], False, stats=sti)
+            if self._recompute_ok(x, blk.downsample[0], blk.downsample[1]):
+                identity = self._c1_bn_nograd(x, blk.downsample[0], blk.downsample[1], False)
+            else:
+                idn, sti = self._c1(x, blk.downsample[0], join)
+                identity = self._bn(idn, blk.downsample[1], False, stats=sti)
             join = None  # bn3's residual input is the downsample branch, not x
+        if self._recompute_ok(out, blk.conv3, blk.bn3):
+            return self._c1_bn_nograd(out, blk.conv3, blk.bn3, True, res=identity)
+        out, st = self._c1(out, blk.conv3)
         return self._bn(out, blk.bn3, True, res=identity, stats=st, join=join)  # relu(bn3(out) + identity)
 
     def prepare_inputs(self, imgs):

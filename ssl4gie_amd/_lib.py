@@ -20,12 +20,12 @@ if os.environ.get("SSL4GIE_DEBUG_LIB") == "1":
 
 # the one copy of the ABI revision on the Python side: build(), the tests and load() compare the
 # library's ssl4gie_abi_version() with it (include/ssl4gie_hip.h documents the history)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F32, BF16 = 0, 1
 BWD_ACCUMULATE, BWD_DEFER_WGRAD = 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX, \
-    EPI_RELU_MASK_AUX, EPI_ADD_AUX = range(9)
+    EPI_RELU_MASK_AUX, EPI_ADD_AUX, EPI_AFFINE_AUX_RELU = range(10)
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
@@ -44,7 +44,7 @@ class GemmDesc(C.Structure):
         ("dtype_ab", i32), ("dtype_c", i32), ("alpha", f32), ("epilogue", i32),
         ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("out2", vp),
         ("accumulate", i32), ("colsum_a", vp), ("conv", C.POINTER(Conv3x3Geom)),
-        ("colstats", vp),
+        ("colstats", vp), ("scale", vp), ("relu", i32),
     ]
 
 
@@ -127,6 +127,7 @@ PROTOTYPES = {
     "ssl4gie_bn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_stats": (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
+    "ssl4gie_bn_bwd_xmask": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_reduce": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_ema_update": (i32, [vp, vp, f32, i64, vp]),
@@ -134,6 +135,7 @@ PROTOTYPES = {
     "ssl4gie_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ssl4gie_bn_coef_partials": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, i64, i32, vp]),
     "ssl4gie_bn_fwd_partials": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, i64,
                                       i32, vp]),
     "ssl4gie_bn_stats_partials": (i32, [vp, i32, vp, vp, vp, i64, i32, vp]),

@@ -720,7 +720,7 @@ static bool nt_ok(const ssl4gie_gemm_desc* d) {
            d->sBk == 1 && d->K % BT_K == 0 && d->K >= BT_K && d->sAm % 8 == 0 &&
            d->sBn % 8 == 0 && d->N % 4 == 0 && d->ldc % 4 == 0 && is16(d->A) && is16(d->B) &&
            is16(d->C) && (!d->residual || (d->ldr % 4 == 0 && is16(d->residual))) &&
-           (!d->bias || is16(d->bias)) && (!d->aux || is16(d->aux)) &&
+           (!d->bias || is16(d->bias)) && (!d->aux || is16(d->aux)) && (!d->scale || is16(d->scale)) &&
            (!d->out2 || is16(d->out2)) && d->M > 0 && d->N > 0 &&
            // bf16 outputs leave through the LDS-staged 16-byte row stores
            (d->dtype_c == SSL4GIE_F32 || d->epilogue == SSL4GIE_EPI_BIAS_RESIDUAL ||
@@ -833,11 +833,16 @@ extern "C" size_t ssl4gie_gemm_workspace_bytes(const ssl4gie_gemm_desc* d) {
 
 extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t workspace_bytes,
                             void* stream) {
-    REQUIRE(d && d->A && d->B && d->C && d->M >= 0 && d->N >= 0 && d->K >= 0);
+    REQUIRE(d && d->A && d->B && d->M >= 0 && d->N >= 0 && d->K >= 0);
+    // C == NULL: the statistics-only product of ssl4gie_gemm_desc::colstats (256x256 NT kernel only)
+    REQUIRE(d->C || (d->colstats && d->dtype_ab == SSL4GIE_BF16 && nt_ok(d) && ssl4gie_internal_nt256_ok(d)));
     REQUIRE(d->batch1 >= 1 && d->batch2 >= 1);
     REQUIRE(d->dtype_ab == SSL4GIE_F32 || d->dtype_ab == SSL4GIE_BF16);
     REQUIRE(d->dtype_c == SSL4GIE_F32 || d->dtype_c == SSL4GIE_BF16);
-    REQUIRE(d->epilogue >= SSL4GIE_EPI_NONE && d->epilogue <= SSL4GIE_EPI_ADD_AUX);
+    REQUIRE(d->epilogue >= SSL4GIE_EPI_NONE && d->epilogue <= SSL4GIE_EPI_AFFINE_AUX_RELU);
+    REQUIRE(d->epilogue != SSL4GIE_EPI_AFFINE_AUX_RELU ||  // 256x256 NT kernel only
+            (d->scale && d->bias && d->batch1 * d->batch2 == 1 && d->dtype_ab == SSL4GIE_BF16 && nt_ok(d) &&
+             ssl4gie_internal_nt256_ok(d)));
     REQUIRE(d->epilogue != SSL4GIE_EPI_ADD_AUX ||
             (d->aux && !d->conv && nt_ok(d) && ssl4gie_internal_nt256_ok(d)));  // 256x256 NT kernel only
     REQUIRE(d->epilogue != SSL4GIE_EPI_RELU_MASK_AUX || (d->conv && d->aux));  // implicit conv only

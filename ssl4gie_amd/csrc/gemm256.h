@@ -179,23 +179,32 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
 // bf16 outputs multiplied by a bf16 auxiliary tile (the saved GELU derivative): same transposition,
 // fp32 through the staging area, the aux rows requested 6 row blocks ahead (48 VGPRs, the registers of the
 // dead operand fragments) in the coalesced row layout.
-// AUXF: 1 multiply by aux, 2 multiply by gelu'(aux), 3 zero where aux <= 0 (ReLU mask), 4 add aux.
+// AUXF: 1 multiply by aux, 2 multiply by gelu'(aux), 3 zero where aux <= 0 (ReLU mask), 4 add aux,
+// 5 per-column affine, optional aux, optional ReLU: act(acc scale[n] + shift[n] (+ aux)) — the BatchNorm that
+// follows a 1x1 convolution (+ the bottleneck's residual add and ReLU) applied to the fp32 accumulators.
 template <bool FULL, int AUXF, int NJ = 4>
 DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
                            const bf16_t* __restrict__ aux, bf16_t* __restrict__ C,
-                           const long long ldc, int rbase, int cbase, int M, int N, int lane) {
+                           const long long ldc, int rbase, int cbase, int M, int N, int lane,
+                           const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr,
+                           const int relu = 0) {
     const int r16 = lane & 15, g4 = lane >> 4;
     const int R0 = lane >> 4, Cc = lane & 15;
     const int gn = cbase + 4 * Cc;
     const bool mine = NJ == 4 || Cc < 4 * NJ;
-    constexpr int PF = 4;  // ring of 4 of the 8 row blocks (32 VGPRs) + the 16 of the pipelined block
+    [[maybe_unused]] f32x4 sc4 = {1, 1, 1, 1}, sh4 = {0, 0, 0, 0};
+    [[maybe_unused]] const bool has_aux = AUXF != 5 || aux != nullptr;
+    if constexpr (AUXF == 5) {
+        if (mine && (FULL || gn < N)) { sc4 = ld4(scale + gn); sh4 = ld4(shift + gn); }
+    }
+    constexpr int PF = AUXF == 5 ? 2 : 4;  // ring of 4 of the 8 row blocks (32 VGPRs; 2 beside the affine quads) + the 16 of the pipelined block
     u32x2 ax[PF][4];
     auto fetch = [&](int mt, u32x2 (&dst)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int gm = rbase + 16 * mt + R0 + 4 * q;
-            dst[q] = (mine && (FULL || (gm < M && gn < N))) ? *(const u32x2*)(aux + (size_t)gm * ldc + gn)
-                                                            : u32x2{0, 0};
+            dst[q] = (has_aux && mine && (FULL || (gm < M && gn < N))) ? *(const u32x2*)(aux + (size_t)gm * ldc + gn)
+                                                                       : u32x2{0, 0};
         }
     };
 #pragma unroll
@@ -236,6 +245,12 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
                 for (int j = 0; j < 4; ++j) w[q][j] = u[j] > 0.f ? w[q][j] : 0.f;
             } else if constexpr (AUXF == 4) {
                 w[q] += u;
+            } else if constexpr (AUXF == 5) {
+                w[q] = w[q] * sc4 + sh4 + u;  // u = 0 without aux
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[q][j] = w[q][j] > 0.f ? w[q][j] : 0.f;
+                }
             } else {
                 w[q] *= u;
             }
@@ -266,6 +281,8 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                      unsigned long long* tstamp = nullptr /* debug library: per-row-block time stamps */,
                      const int prio_mode = P_EPI_PRIO_MODE /* debug library: s_setprio policy of the GELU epilogues */,
                      const bool xpose_swap = P_EPI_XPOSE_SWAP /* GELU pair: lane exchange instead of the LDS transposition */) {
+    // EPI_AFFINE_AUX_RELU borrows two slots: `residual` carries scale[N], `accumulate` the ReLU flag (EpiArgs
+    // is filled that way by the launcher)
     const int r16 = lane & 15, g4 = lane >> 4;
     constexpr bool HAS_BIAS = MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
                               MODE == SSL4GIE_EPI_BIAS_RESIDUAL || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD;
@@ -297,7 +314,10 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
         }
     }
     if constexpr (BIAS_LDS) __builtin_amdgcn_sched_barrier(0);  // the reads above come before any write to `stg`
-    if constexpr (sizeof(TC) == 2 && (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
+    if constexpr (sizeof(TC) == 2 && MODE == SSL4GIE_EPI_AFFINE_AUX_RELU) {
+        p_store_bf16_aux<FULL, 5, NJ>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane,
+                                      residual /* scale */, bias /* shift */, accumulate /* relu */);
+    } else if constexpr (sizeof(TC) == 2 && (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
                                       MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX)) {
         constexpr int AUXF = MODE == SSL4GIE_EPI_DGELU ? 2
                            : (MODE == SSL4GIE_EPI_RELU_MASK_AUX ? 3 : (MODE == SSL4GIE_EPI_ADD_AUX ? 4 : 1));
@@ -355,7 +375,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                 const int R = R0 + 8 * hh;
                 const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
                 if (mine && (FULL || (gm < M && gn < N))) {
-                    *(u32x4*)(dst + (size_t)gm * ldc + gn) = w[hh];
+                    if (!STATS || dst) *(u32x4*)(dst + (size_t)gm * ldc + gn) = w[hh];  // STATS with C == NULL: statistics only
                     if constexpr (STATS) {
                         if (stats) {
 #pragma unroll

@@ -596,6 +596,9 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
     if (d->colstats && !(d->dtype_c == SSL4GIE_BF16 && ep == SSL4GIE_EPI_NONE && !d->accumulate &&
                          d->N % 8 == 0))
         return false;
+    if (!d->C && !d->colstats) return false;  // C == NULL: the statistics-only product
+    if (ep == SSL4GIE_EPI_AFFINE_AUX_RELU)    // exists in this kernel only
+        return !d->conv && d->dtype_c == SSL4GIE_BF16 && d->scale && d->bias && !d->accumulate && d->C;
     if (d->conv)  // gathered A: bf16 outputs with bias / plain only, whole K-tiles inside a tap
         return ssl4gie_internal_conv_geom_ok(d->conv) && d->conv->C % P_BK == 0 &&
                d->K == 9 * d->conv->C && (long long)d->M == conv_rows(d->conv) &&
@@ -643,6 +646,10 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     dim3 grid(ntiles < cus ? ntiles : cus), block(512);
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate,
               d->colstats};
+    if (d->epilogue == SSL4GIE_EPI_AFFINE_AUX_RELU) {  // two borrowed slots (gemm256.h p_epilogue)
+        e.residual = d->scale;
+        e.accumulate = d->relu;
+    }
     int skip_epi = 0;
     [[maybe_unused]] int role = NT256_DEFAULT_ROLE;
     [[maybe_unused]] bool ph2 = NT256_DEFAULT_PH2;
@@ -733,6 +740,7 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
             case SSL4GIE_EPI_BIAS_GELU_GRAD: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU_GRAD); break;
             case SSL4GIE_EPI_MUL_AUX: P_LAUNCH(bf16_t, SSL4GIE_EPI_MUL_AUX); break;
             case SSL4GIE_EPI_ADD_AUX: P_LAUNCH(bf16_t, SSL4GIE_EPI_ADD_AUX); break;
+            case SSL4GIE_EPI_AFFINE_AUX_RELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_AFFINE_AUX_RELU); break;
             case SSL4GIE_EPI_NONE: P_LAUNCH(bf16_t, SSL4GIE_EPI_NONE); break;
             default: return ARG_ERR;
         }

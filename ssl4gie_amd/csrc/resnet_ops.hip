@@ -278,6 +278,12 @@ DEVI bool bn_sum_partials(const float* __restrict__ partial, int parts, int C, f
     for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
     return true;
 }
+// the forward's normalisation coefficients y = x a + b; ONE definition, because the backward kernels that rebuild
+// the ReLU mask from x (xmask) must reproduce the forward's sign decisions
+DEVI void bn_affine(float gamma, float beta, float mean, float rstd, float& a, float& b) {
+    a = rstd * gamma;
+    b = beta - mean * a;
+}
 __global__ __launch_bounds__(256) void bn_fwd_tail_kernel(
     const float* __restrict__ partial, int parts, const float* __restrict__ pivot,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
@@ -298,19 +304,26 @@ __global__ __launch_bounds__(256) void bn_fwd_tail_kernel(
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
-    const float a = r * (gamma ? gamma[c] : 1.f);
+    float a, b;
+    bn_affine(gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f, m, r, a, b);
     coef[c] = a;
-    coef[C + c] = (beta ? beta[c] : 0.f) - m * a;
+    coef[C + c] = b;
 }
 __global__ __launch_bounds__(256) void bn_bwd_tail_kernel(
     const float* __restrict__ partial, int parts, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, float inv_n,
     float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    int accumulate, int C) {
+    int accumulate, int C, const float* __restrict__ beta, float* __restrict__ mcoef) {
     __shared__ float red[3][2][64];
     float s, q;
     if (!bn_sum_partials(partial, parts, C, s, q, red)) return;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (mcoef) {  // the forward's y = x a + b, for the apply pass's ReLU mask
+        float ma, mb;
+        bn_affine(gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f, mean[c], rstd[c], ma, mb);
+        mcoef[c] = ma;
+        mcoef[C + c] = mb;
+    }
     const float r = rstd[c], a = r * (gamma ? gamma[c] : 1.f);
     const float s1 = s * inv_n, s2 = q * inv_n;
     coef[c] = a;
@@ -347,11 +360,14 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
 // g = relu ? (y > 0 ? dy : 0) : dy;  partial[blk][0][c] = sum g, [1][c] = sum g * xhat; when the block
 // had a residual input its gradient is g itself (dres, optional).  Lane mapping as bn_stats_kernel,
 // two rows (x 2-3 streams) in flight per lane.
-template <typename T>
+// XMASK (BatchNorm + ReLU without a residual input): the mask is rebuilt as x a + b > 0 from the forward's own
+// coefficients instead of read from the ReLU output — two streams instead of three.
+template <typename T, bool XMASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dres,
-    float* __restrict__ partial, int relu, long long rows, int C) {
+    float* __restrict__ partial, int relu, long long rows, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta) {
     constexpr int V = V16<T>::N;
     typedef typename V16<T>::raw raw_t;
     __shared__ float red[3][2][64][V];
@@ -362,13 +378,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int j = 0; j < V; ++j) s[j] = q[j] = 0.f;
     if (m.c < C) {
         float mu[V], rs[V];
+        [[maybe_unused]] float ma[V], mb[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) { mu[j] = mean[m.c + j]; rs[j] = rstd[m.c + j]; }
+        if constexpr (XMASK) {
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+                bn_affine(gamma ? gamma[m.c + j] : 1.f, beta ? beta[m.c + j] : 0.f, mu[j], rs[j], ma[j], mb[j]);
+        }
         auto acc = [&](const raw_t& gv, const raw_t& yv, const raw_t& xv, size_t o) {
             float g[V], xx[V];
             un<T>(gv, g);
             un<T>(xv, xx);
-            if (relu) {
+            if constexpr (XMASK) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) g[j] = xx[j] * ma[j] + mb[j] > 0.f ? g[j] : 0.f;
+            } else if (relu) {
                 float yy[V];
                 un<T>(yv, yy);
 #pragma unroll
@@ -383,20 +408,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         };
         const long long step = (long long)gridDim.y * 4 * m.rpw;
         long long r = ((long long)blockIdx.y * 4 + wave) * m.rpw + m.rsub;
-        for (; r + step < rows; r += 2 * step) {
-            const size_t o0 = (size_t)r * C + m.c, o1 = (size_t)(r + step) * C + m.c;
-            const raw_t g0 = *(const raw_t*)(dy + o0), g1 = *(const raw_t*)(dy + o1);
-            const raw_t x0 = *(const raw_t*)(x + o0), x1 = *(const raw_t*)(x + o1);
-            raw_t y0 = g0, y1 = g1;
-            if (relu) { y0 = *(const raw_t*)(y + o0); y1 = *(const raw_t*)(y + o1); }
-            acc(g0, y0, x0, o0);
-            acc(g1, y1, x1, o1);
+        constexpr int NR = XMASK ? 4 : 2;  // rows in flight per lane: ~8 16-B loads outstanding either way
+        for (; r + (NR - 1) * step < rows; r += NR * step) {
+            size_t o[NR];
+            raw_t gv[NR], xv[NR], yv[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                o[i] = (size_t)(r + i * step) * C + m.c;
+                gv[i] = *(const raw_t*)(dy + o[i]);
+                xv[i] = *(const raw_t*)(x + o[i]);
+                yv[i] = gv[i];
+                if (!XMASK && relu) yv[i] = *(const raw_t*)(y + o[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) acc(gv[i], yv[i], xv[i], o[i]);
         }
         for (; r < rows; r += step) {
             const size_t o0 = (size_t)r * C + m.c;
             const raw_t g0 = *(const raw_t*)(dy + o0), x0 = *(const raw_t*)(x + o0);
             raw_t y0 = g0;
-            if (relu) y0 = *(const raw_t*)(y + o0);
+            if (!XMASK && relu) y0 = *(const raw_t*)(y + o0);
             acc(g0, y0, x0, o0);
         }
     }
@@ -410,11 +441,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         }
     }
 }
-// dx = coef[c] g + coef[C + c] x + coef[2C + c]
+// dx = coef[c] g + coef[C + c] x + coef[2C + c];  mcoef (optional, [2][C]): g = x mcoef[c] + mcoef[C + c] > 0 ? dy : 0
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                     const T* __restrict__ x, const float* __restrict__ coef,
-                                    T* __restrict__ dx, int relu, int C, long long total) {
+                                    T* __restrict__ dx, int relu, int C, long long total,
+                                    const float* __restrict__ mcoef) {
     constexpr int V = V16<T>::N;
     const long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (idx >= total) return;
@@ -422,7 +454,16 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     float g[V], xv[V], yy[V], a[V], b[V], d[V];
     un<T>(*(const typename V16<T>::raw*)(dy + idx), g);
     un<T>(*(const typename V16<T>::raw*)(x + idx), xv);
-    if (relu) un<T>(*(const typename V16<T>::raw*)(y + idx), yy);
+    if (mcoef) {  // the forward's pre-activation, sign only
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+            const f32x4 ma = ld4(mcoef + c + j), mb = ld4(mcoef + C + c + j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yy[j + i] = xv[j + i] * ma[i] + mb[i];
+        }
+    } else if (relu) {
+        un<T>(*(const typename V16<T>::raw*)(y + idx), yy);
+    }
 #pragma unroll
     for (int j = 0; j < V; j += 4) {
         *(f32x4*)(a + j) = ld4(coef + c + j);
@@ -725,26 +766,24 @@ extern "C" int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* be
               C, total);
     return 0;
 }
-// backward: dgamma / dbeta (overwritten or accumulated), dx, and (optional) the residual gradient
-extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, const float* gamma,
-                              const float* mean, const float* rstd, void* dx, void* dres,
-                              float* dgamma, float* dbeta, int accumulate, int relu,
-                              float* workspace, int dtype, long long rows, int C, void* stream) {
-    REQUIRE(dy && x && mean && rstd && dx && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
-    REQUIRE(!relu || y);
-    hipStream_t st = (hipStream_t)stream;
+// backward: dgamma / dbeta (overwritten or accumulated), dx, and (optional) the residual gradient.
+// xmask: BatchNorm + ReLU without a residual input — the ReLU mask is rebuilt from x and the forward's
+// coefficients (gamma, beta, mean, rstd) instead of read from the ReLU output: 5 instead of 7 tensor passes.
+static int bn_bwd_impl(const void* dy, const void* y, const void* x, const float* gamma, const float* beta,
+                       const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
+                       float* dbeta, int accumulate, int relu, bool xmask, float* workspace, int dtype,
+                       long long rows, int C, hipStream_t st) {
     const int parts = bn_parts(rows, C);
     dim3 grid(bn_strips(C, dtype), parts), block(256);
     float* coef = workspace;
     float* partial = workspace + 3 * (size_t)C;
-    if (dtype == SSL4GIE_BF16)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy,
-                           (const bf16_t*)y, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, partial,
-                           relu, rows, C);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)dy,
-                           (const float*)y, (const float*)x, mean, rstd, (float*)dres, partial, relu,
-                           rows, C);
+    float* mcoef = xmask ? partial + (size_t)parts * 2 * C : nullptr;  // the forward's `sums` slot: free here
+#define BN_REDUCE(T_, XM_)                                                                              \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, XM_>), grid, block, 0, st, (const T_*)dy, (const T_*)y, \
+                       (const T_*)x, mean, rstd, (T_*)dres, partial, relu, rows, C, gamma, beta)
+    if (dtype == SSL4GIE_BF16) { if (xmask) BN_REDUCE(bf16_t, true); else BN_REDUCE(bf16_t, false); }
+    else { if (xmask) BN_REDUCE(float, true); else BN_REDUCE(float, false); }
+#undef BN_REDUCE
     LAUNCH_CHECK();
     // dbeta = sum g, dgamma = sum g xhat, and the dx coefficients, in one launch (after a 64-way
     // fold when the reduction left hundreds of partials: the tail's blocks are few and sequential)
@@ -753,7 +792,7 @@ extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, cons
     int rc = bn_fold(partial, parts, fold_scratch, C, st, &pp, &np);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_tail_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pp, np, mean,
-                       rstd, gamma, 1.0f / (float)rows, coef, dgamma, dbeta, accumulate, C);
+                       rstd, gamma, 1.0f / (float)rows, coef, dgamma, dbeta, accumulate, C, beta, mcoef);
     LAUNCH_CHECK();
     const long long total = rows * C;
     // with a residual branch the reduction pass has just written dres = the MASKED gradient (dy or 0, no
@@ -764,8 +803,25 @@ extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, cons
     const void* ysrc = masked ? nullptr : y;
     const int relu_apply = masked ? 0 : relu;
     RN_LAUNCH(dtype, bn_bwd_apply_kernel, total / rvn(dtype), (const T*)gsrc, (const T*)ysrc, (const T*)x,
-              coef, (T*)dx, relu_apply, C, total);
+              coef, (T*)dx, relu_apply, C, total, (const float*)mcoef);
     return 0;
+}
+extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, const float* gamma,
+                              const float* mean, const float* rstd, void* dx, void* dres,
+                              float* dgamma, float* dbeta, int accumulate, int relu,
+                              float* workspace, int dtype, long long rows, int C, void* stream) {
+    REQUIRE(dy && x && mean && rstd && dx && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
+    REQUIRE(!relu || y);
+    return bn_bwd_impl(dy, y, x, gamma, nullptr, mean, rstd, dx, dres, dgamma, dbeta, accumulate, relu, false,
+                       workspace, dtype, rows, C, (hipStream_t)stream);
+}
+extern "C" int ssl4gie_bn_bwd_xmask(const void* dy, const void* x, const float* gamma, const float* beta,
+                                    const float* mean, const float* rstd, void* dx, float* dgamma,
+                                    float* dbeta, int accumulate, float* workspace, int dtype,
+                                    long long rows, int C, void* stream) {
+    REQUIRE(dy && x && mean && rstd && dx && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
+    return bn_bwd_impl(dy, nullptr, x, gamma, beta, mean, rstd, dx, nullptr, dgamma, dbeta, accumulate, 1, true,
+                       workspace, dtype, rows, C, (hipStream_t)stream);
 }
 extern "C" int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* arg, int dtype, int B,
                                         int H, int W, int C, void* stream) {
@@ -897,6 +953,25 @@ extern "C" int ssl4gie_bn_fwd_partials(const void* x, const float* partial, int 
               C, total);
     return 0;
 }
+// the statistics half of ssl4gie_bn_fwd_partials alone: mean / rstd / running statistics and the normalisation
+// coefficients coef [2][C] (y = x coef[0][c] + coef[1][c]) for a consumer that applies them itself — the
+// SSL4GIE_EPI_AFFINE_AUX_RELU epilogue of the 1x1 convolution recomputed after its statistics-only product
+extern "C" int ssl4gie_bn_coef_partials(const float* partial, int parts, const float* gamma, const float* beta,
+                                        float* mean, float* rstd, float* running_mean, float* running_var,
+                                        float momentum, float eps, float* coef, float* workspace,
+                                        long long rows, int C, void* stream) {
+    REQUIRE(partial && parts > 0 && mean && rstd && coef && workspace && rows > 0 && C > 0 && C % 8 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    float* scratch = workspace + 3 * (size_t)C;
+    const float* pp; int np;
+    int rc = bn_fold(partial, parts, scratch, C, st, &pp, &np);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_fwd_tail_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pp, np,
+                       (const float*)nullptr, gamma, beta, mean, rstd, running_mean, running_var, coef,
+                       (float)rows, eps, momentum, C);
+    LAUNCH_CHECK();
+    return 0;
+}
 // SyncBatchNorm's local (mean, biased var) from the same partials
 extern "C" int ssl4gie_bn_stats_partials(const float* partial, int parts, float* mean, float* var,
                                          float* workspace, long long rows, int C, void* stream) {
@@ -927,13 +1002,13 @@ extern "C" int ssl4gie_bn_bwd_reduce(const void* dy, const void* y, const void* 
     dim3 grid(bn_strips(C, dtype), parts), block(256);
     float* partial = workspace + 3 * (size_t)C;
     if (dtype == SSL4GIE_BF16)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy,
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)dy,
                            (const bf16_t*)y, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, partial,
-                           relu, rows, C);
+                           relu, rows, C, (const float*)nullptr, (const float*)nullptr);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)dy,
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), grid, block, 0, st, (const float*)dy,
                            (const float*)y, (const float*)x, mean, rstd, (float*)dres, partial, relu,
-                           rows, C);
+                           rows, C, (const float*)nullptr, (const float*)nullptr);
     LAUNCH_CHECK();
     return ssl4gie_internal_reduce_partials(partial, sums, parts, 2 * C, (size_t)2 * C, 0, st);
 }
@@ -950,7 +1025,7 @@ extern "C" int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x
     LAUNCH_CHECK();
     const long long total = rows * C;
     RN_LAUNCH(dtype, bn_bwd_apply_kernel, total / rvn(dtype), (const T*)dy, (const T*)y, (const T*)x,
-              workspace, (T*)dx, relu, C, total);
+              workspace, (T*)dx, relu, C, total, (const float*)nullptr);
     return 0;
 }
 

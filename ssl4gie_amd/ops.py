@@ -167,6 +167,65 @@ def linear_fwd(x2d, w, bias=None, out_dtype=None, epilogue=None, residual=None, 
     return (y, out2) if out2 is not None else y
 
 
+def linear_colstats_only(x2d, w):
+    """the BatchNorm partial statistics [ceil(T/128), 2, n_out] of y = x2d @ w^T (of its bf16-rounded values, as
+    linear_fwd(colstats=True) returns them) WITHOUT writing y: the first half of the BatchNorm-fused 1x1
+    convolution (linear_affine_fwd is the second)"""
+    _dev(x2d, w)
+    T, k_in = x2d.shape
+    n_out = w.shape[0]
+    assert w.shape[1] == k_in and x2d.dtype == w.dtype and colstats_ok(T, n_out, k_in, x2d.dtype)
+    d = _desc(T, n_out, k_in, code(x2d.dtype), code(x2d.dtype))
+    d.A, d.sAm, d.sAk = ptr(x2d), k_in, 1
+    d.B, d.sBk, d.sBn = ptr(w), 1, k_in
+    d.C, d.ldc = None, n_out
+    d.epilogue = _lib.EPI_NONE
+    stats = torch.empty((T + 127) // 128, 2, n_out, dtype=torch.float32, device=x2d.device)
+    d.colstats = ptr(stats)
+    gemm_raw(d, x2d.device)
+    return stats
+
+
+def linear_affine_fwd(x2d, w, scale, shift, aux=None, relu=False):
+    """act((x2d @ w^T) * scale[n] + shift[n] (+ aux)), act = ReLU if `relu` (EPI_AFFINE_AUX_RELU): bf16 operands
+    and output, the affine map applied to the fp32 accumulators"""
+    _dev(x2d, w, scale, shift, aux)
+    _f32(scale); _f32(shift)
+    T, k_in = x2d.shape
+    n_out = w.shape[0]
+    assert w.shape[1] == k_in and x2d.dtype == w.dtype == torch.bfloat16
+    assert scale.numel() == n_out and shift.numel() == n_out and scale.is_contiguous() and shift.is_contiguous()
+    d = _desc(T, n_out, k_in, code(x2d.dtype), code(x2d.dtype))
+    d.A, d.sAm, d.sAk = ptr(x2d), k_in, 1
+    d.B, d.sBk, d.sBn = ptr(w), 1, k_in
+    y = torch.empty(T, n_out, dtype=x2d.dtype, device=x2d.device)
+    d.C, d.ldc = ptr(y), n_out
+    d.epilogue, d.scale, d.bias, d.relu = _lib.EPI_AFFINE_AUX_RELU, ptr(scale), ptr(shift), int(bool(relu))
+    if aux is not None:
+        assert aux.shape == (T, n_out) and aux.dtype == x2d.dtype and aux.is_contiguous()
+        d.aux = ptr(aux)
+    gemm_raw(d, x2d.device)
+    return y
+
+
+def bn_coef_partials(partials, rows, gamma, beta, running_mean, running_var, momentum, eps):
+    """training-mode BatchNorm statistics from GEMM-epilogue partials -> (coef [2, C]: y = x coef[0] + coef[1],
+    mean, rstd); running statistics updated (ssl4gie_bn_coef_partials)"""
+    _dev(partials, gamma, beta, running_mean, running_var)
+    C = partials.shape[2]
+    assert partials.dtype == torch.float32 and partials.shape[1] == 2 and partials.is_contiguous()
+    L = _lib.load()
+    dev = partials.device
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    rstd = torch.empty(C, dtype=torch.float32, device=dev)
+    coef = torch.empty(2, C, dtype=torch.float32, device=dev)
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=dev)
+    _lib.check(L.ssl4gie_bn_coef_partials(ptr(partials), partials.shape[0], ptr(gamma), ptr(beta), ptr(mean),
+                                          ptr(rstd), ptr(running_mean), ptr(running_var), float(momentum),
+                                          float(eps), ptr(coef), ptr(ws), rows, C, stream()), "bn_coef_partials")
+    return coef, mean, rstd
+
+
 def add_aux_ok(T, k_in, n_out, dtype, has_wt):
     """whether linear_bwd_data can join a second gradient contribution in its epilogue"""
     return dtype == torch.bfloat16 and has_wt and n_out % 64 == 0 and k_in % 8 == 0 and T > 0
@@ -911,6 +970,20 @@ def bn_bwd(dy2d, y2d, x2d, gamma, mean, rstd, relu, want_dres, dgamma, dbeta, ac
                                 ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate), int(relu), ptr(ws),
                                 code(x2d.dtype), rows, C, stream()), "bn_bwd")
     return dx, dres
+
+
+def bn_bwd_xmask(dy2d, x2d, gamma, beta, mean, rstd, dgamma, dbeta, accumulate):
+    """BatchNorm + ReLU without a residual input: the mask is rebuilt from x and the forward's coefficients, the
+    ReLU output is not read (ssl4gie_bn_bwd_xmask)"""
+    _dev(dy2d, x2d, gamma, beta, mean, rstd, dgamma, dbeta)
+    rows, C = x2d.shape
+    L = _lib.load()
+    dx = torch.empty_like(x2d)
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_bwd_xmask(ptr(dy2d), ptr(x2d), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx),
+                                      ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), code(x2d.dtype),
+                                      rows, C, stream()), "bn_bwd_xmask")
+    return dx
 
 
 def maxpool3x3s2_fwd(x):

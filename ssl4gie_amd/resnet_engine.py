@@ -259,6 +259,10 @@ def flush_batch_counts(model):
             _flush_one(m)
 
 
+# SSL4GIE_BN_XMASK=0: read the ReLU output for the mask of residual-free BatchNorm + ReLU layers again (A/B)
+_XMASK = __import__("os").environ.get("SSL4GIE_BN_XMASK", "1") != "0"
+
+
 class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d / BatchNorm1d / SyncBatchNorm over the rows of a [..., C] tensor, (+ residual)
     (+ ReLU).  With an nn.SyncBatchNorm holder and world_size > 1 the statistics are global: local
@@ -309,7 +313,11 @@ class BatchNormFn(torch.autograd.Function):
         (tg, tb), acc, rets = sink.plan([gamma, beta])
         dy2 = dy.contiguous().view(-1, C)
         gd = gamma.detach() if gamma is not None else None
-        if not sync:
+        if not sync and relu and not has_res and _XMASK:
+            # the ReLU mask from x and the forward's coefficients: the ReLU output is not read again
+            dx, dres = ops.bn_bwd_xmask(dy2, x2, gd, beta.detach() if beta is not None else None, mean, rstd,
+                                        tg, tb, acc), None
+        elif not sync:
             dx, dres = ops.bn_bwd(dy2, y, x2, gd, mean, rstd, relu, has_res, tg, tb, acc)
         else:
             import torch.distributed as dist

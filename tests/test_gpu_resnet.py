@@ -70,6 +70,33 @@ def test_batchnorm_fwd_bwd_fp32(relu, with_res):
     assert int(bn.state_dict()["num_batches_tracked"]) == 1  # host-side count, written at state_dict()
 
 
+@pytest.mark.parametrize("dtype", [F32, BF])
+@pytest.mark.parametrize("rows,C", [(1531, 64), (4099, 24), (777, 1024)])
+def test_batchnorm_relu_backward_mask_from_x_equals_mask_from_output(rows, C, dtype):
+    """ssl4gie_bn_bwd_xmask (mask rebuilt from x and the forward's coefficients) against ssl4gie_bn_bwd reading
+    the ReLU output: dx, dgamma and dbeta bit-identical, negative gammas and exact-zero pre-activations included"""
+    from ssl4gie_amd import ops
+    g = G(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 1).to(dtype).to(DEV)
+    gamma = torch.randn(C, generator=g).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    gamma[1] = 0.0                       # y = beta exactly: the whole channel on one side of the mask
+    beta[1] = 0.0                        # ... at exactly zero: masked off on both paths
+    gamma[2], beta[2] = 0.0, 0.25
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y, mean, rstd = ops.bn_fwd(x, gamma, beta, None, rm, rv, 0.1, 1e-5, True, True)
+    assert float((y[:, 1].float() != 0).sum()) == 0 and float((y[:, 2].float() <= 0).sum()) == 0
+    dy = torch.randn(rows, C, generator=g).to(dtype).to(DEV)
+    dg0, db0 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dg1, db1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dx0, _ = ops.bn_bwd(dy, y, x, gamma, mean, rstd, True, False, dg0, db0, False)
+    dx1 = ops.bn_bwd_xmask(dy, x, gamma, beta, mean, rstd, dg1, db1, False)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    # accumulate
+    dx2 = ops.bn_bwd_xmask(dy, x, gamma, beta, mean, rstd, dg1, db1, True)
+    assert torch.equal(dx2, dx1) and torch.equal(dg1, 2 * dg0) and torch.equal(db1, 2 * db0)
+
+
 def test_maxpool_avgpool_subsample():
     from ssl4gie_amd.resnet_engine import AvgPoolFn, MaxPoolFn, Subsample2Fn
     x = torch.relu(torch.randn(2, 16, 12, 10, generator=G(6)))  # ReLU output: many tied zeros
@@ -252,6 +279,79 @@ def test_gemm_colstats_match_the_stored_outputs(T, K, N):
     m2, v2 = ops.bn_stats(y, partials=st)   # the SyncBatchNorm half
     m1, v1 = ops.bn_stats(y)
     assert rel_err(m2, m1) < 1e-4 and rel_err(v2, v1) < 1e-4
+
+
+@pytest.mark.parametrize("T,K,N,aux,relu", [(1000, 64, 256, True, True), (12544, 256, 1024, True, True),
+                                            (300, 128, 264, False, False), (12800, 64, 768, True, False),
+                                            (256, 64, 8, False, True), (4099, 512, 2048, True, True)])
+def test_gemm_statistics_only_and_affine_epilogue(T, K, N, aux, relu):
+    """the BatchNorm-fused 1x1 convolution's two products: (1) colstats with C == NULL == the statistics of the
+    storing product, bit for bit, and nothing written; (2) EPI_AFFINE_AUX_RELU == act(acc scale + shift (+ aux))
+    on the fp32 accumulators, rounded once (ragged rows, 192-wide tiles at N = 768, N not a multiple of 64)"""
+    from ssl4gie_amd import ops
+    g = torch.Generator().manual_seed(51 + T)
+    x = torch.randn(T, K, generator=g).to(BF).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(BF).to(DEV)
+    _, st = ops.linear_fwd(x, w, None, colstats=True)
+    st2 = ops.linear_colstats_only(x, w)
+    assert torch.equal(st, st2)
+    scale = (1 + 0.3 * torch.randn(N, generator=g)).to(DEV)
+    scale[0] = -scale[0]
+    shift = (0.2 * torch.randn(N, generator=g)).to(DEV)
+    a = torch.randn(T, N, generator=g).to(BF).to(DEV) if aux else None
+    y = ops.linear_affine_fwd(x, w, scale, shift, a, relu)
+    ref = (x.double() @ w.double().t()) * scale.double() + shift.double()
+    if aux:
+        ref = ref + a.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert y.dtype == BF and y.shape == (T, N)
+    err = (y.double() - ref).abs()
+    # one bf16 rounding of the exact value (2^-9 relative) + fp32 accumulation noise
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-5).all()), float((err / (ref.abs() + 1e-3)).max())
+    if relu:
+        assert float(y.float().min()) >= 0.0
+
+
+def test_resnet50_no_grad_forward_recomputes_the_wide_products():
+    """under torch.no_grad() (MoCo's momentum encoder) conv3 / downsample + BatchNorm (+ identity, ReLU) run as a
+    statistics-only product and a product with the normalisation in its epilogue: the pooled features track the
+    storing path (same statistics, one rounding less), the running statistics and batch counts agree"""
+    import copy
+    from ssl4gie_amd.Models import resnet as R
+    m, _ = _resnet_pair(3)
+    m.to(DEV).set_precision("bf16")
+    m.train()
+    m2 = copy.deepcopy(m)
+    imgs = torch.randn(8, 3, 128, 128, generator=G(12)).to(DEV)
+    calls = {"n": 0}
+    orig = R.ResNet50._c1_bn_nograd
+
+    def counted(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+    R.ResNet50._c1_bn_nograd = counted
+    try:
+        with torch.no_grad():
+            a = m(imgs)
+    finally:
+        R.ResNet50._c1_bn_nograd = orig
+    assert calls["n"] == 20          # 16 conv3 + 4 downsample
+    b = m2(imgs)                      # gradients enabled: the storing path
+    e = _l2(a, b.detach())
+    print(f"pooled features, recomputing vs storing path: relative L2 {e:.3e}")
+    sa, sb = m.state_dict(), m2.state_dict()
+    for k in sa:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            # the first block's inputs are identical on both paths, and so are the statistics (same partial sums)
+            tol = 1e-6 if k.startswith(("layer1.0.downsample", "layer1.0.bn")) else 0.3
+            assert rel_err(sa[k].float().cpu(), sb[k].float().cpu()) < tol, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sb[k]) == 1, k
+    # 16 random-init bottlenecks of bf16 roundings apart at batch 8: ill-conditioned (the bf16-vs-fp64 test above
+    # allows 0.3 for the same reason; measured 0.12) — the arithmetic itself is held to one bf16 rounding by
+    # test_gemm_statistics_only_and_affine_epilogue and to 1e-6 on the first block's statistics above
+    assert e < 0.3
 
 
 # bf16 engine on the same well-conditioned blocks: measured worst errors over the three blocks (round 3,
