@@ -291,7 +291,6 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
     f32x4 bias4[4], bias_t = {0, 0, 0, 0};
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) bias4[nt] = f32x4{0, 0, 0, 0};
-    static_assert(NJ == 4 || !STATS, "column statistics ride on the 64-column wave tile only");
     if constexpr (HAS_BIAS && sizeof(TC) == 2) {
 #pragma unroll
         for (int nt = 0; nt < NJ; ++nt) {
@@ -377,7 +376,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                 if (mine && (FULL || (gm < M && gn < N))) {
                     if (!STATS || dst) *(u32x4*)(dst + (size_t)gm * ldc + gn) = w[hh];  // STATS with C == NULL: statistics only
                     if constexpr (STATS) {
-                        if (stats) {
+                        if (stats && !(prio_mode & 8)) {  // (bit 3: debug-library ablation)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const float lo = __uint_as_float(w[hh][j] << 16), hi = __uint_as_float(w[hh][j] & 0xffff0000u);
@@ -441,9 +440,10 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
         // blocks; 3 alternate per block, wr = 0 ahead on even blocks
         auto prio = [&](int blk) {
             if constexpr (PAIR) {
-                const bool hi = prio_mode == 1 ? wrow == 1
-                              : prio_mode == 2 ? ((blk & 1) == 0) == (wrow == 1)
-                              : prio_mode == 3 ? ((blk & 1) == 0) == (wrow == 0) : false;
+                const int pm = prio_mode & 3;
+                const bool hi = pm == 1 ? wrow == 1
+                              : pm == 2 ? ((blk & 1) == 0) == (wrow == 1)
+                              : pm == 3 ? ((blk & 1) == 0) == (wrow == 0) : false;
                 if (hi) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
             }
@@ -466,6 +466,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
         if constexpr (PAIR) __builtin_amdgcn_s_setprio(0);
         if constexpr (STATS) {
             // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row groups
+            if (!(prio_mode & 16))  // (bit 4: debug-library ablation)
 #pragma unroll
             for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
@@ -475,7 +476,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                 }
             const int gn = cbase + 8 * Cc;
             // a 128-row block that starts past M has no row in colstats (ceil(M / 128) blocks)
-            if (lane < 8 && (FULL || (gn < N && rbase < M))) {
+            if (lane < 8 && mine && (FULL || (gn < N && rbase < M))) {
                 float* p = colstats + (size_t)(rbase >> 7) * 2 * N + gn;
                 st4(p, f32x4{cs[0], cs[1], cs[2], cs[3]});
                 st4(p + 4, f32x4{cs[4], cs[5], cs[6], cs[7]});

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     ConvK cg) {
 #ifdef SSL4GIE_DEBUG_KNOBS
     const int dbg = dbg_arg & 15;
-    const int dbg_prio = dbg_arg >> 4;  // SSL4GIE_NT256_PRIO: bits 0-1 s_setprio policy of the GELU epilogues, bit 2 = LDS transposition instead of the lane exchange (gemm256.h)
+    const int dbg_prio = dbg_arg >> 4;  // SSL4GIE_NT256_PRIO: bits 0-1 s_setprio policy of the GELU epilogues, bit 2 = LDS transposition instead of the lane exchange, bits 3 / 4 = STATS ablations (no accumulation / no final fold; gemm256.h)
 #else
     constexpr int dbg = 0;
 #endif
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     // pixel, chunk included, and yo[0][*] / yo[1][*] its coordinates (y0 << 16 | x0 & 0xffff)
     unsigned yo[2][2];
     static_assert(CONV == 0 || ROLE == 0, "the gathered operand keeps the two-piece ownership");
-    static_assert(NJ == 4 || (NJ == 3 && ROLE == 0 && CONV == 0 && !STATS), "256 x 192: plain operands, ROLE 0");
+    static_assert(NJ == 4 || (NJ == 3 && ROLE == 0 && CONV == 0), "256 x 192: plain operands, ROLE 0");
     constexpr int WN = 16 * NJ;   // columns per wave
     constexpr int BN = 4 * WN;    // columns per tile
 #pragma unroll
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
                                                       n0 + wc * WN, x_M, N, lane, e_colstats,
                                                       (stamping && c_ti - 1 < NT256_STAMP_TILES)
                                                           ? &g_nt256_stamps[blockIdx.x >> 4][c_ti - 1][5] : nullptr,
-                                                      dbg_prio & 3, !(dbg_prio & 4));
+                                                      dbg_prio & 27, !(dbg_prio & 4));
             } else {
                 p_epilogue<TC, MODE, false, STATS, true, NJ>(acc, stg, e_alpha, e_bias, x_res, x_ldr, x_aux, x_out2,
                                                    e_accumulate, x_C, ldc, x_rbase, n0 + wc * WN, x_M, N, lane,
@@ -626,11 +626,14 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
 // little worse; tools/gemm_bench.py).  N = 768 at M = 12800 (ViT-B proj / fc2 and their data gradients):
 // 150 tiles = one round at 62 % of the chip  ->  200 tiles = one round of 0.78.
 static int nt256_pick_nj(const ssl4gie_gemm_desc* d, int cus) {
-    if (d->conv || d->colstats) return 4;
+    if (d->conv) return 4;
 #ifdef SSL4GIE_DEBUG_KNOBS
     static int forced = -1;
     if (forced < 0) { const char* s = getenv("SSL4GIE_NT256_NJ"); forced = s ? atoi(s) : 0; }
     if (forced == 3 || forced == 4) return forced;
+    static int stats4 = -1;  // SSL4GIE_NT256_STATS_NJ4=1: products with column statistics on 256-wide tiles only (A/B)
+    if (stats4 < 0) { const char* s = getenv("SSL4GIE_NT256_STATS_NJ4"); stats4 = s ? atoi(s) : 0; }
+    if (stats4 && d->colstats) return 4;
 #endif
     const long long tm = (d->M + P_BM - 1) / P_BM;
     const long long r256 = (tm * ((d->N + 255) / 256) + cus - 1) / cus;
@@ -722,7 +725,8 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     } while (0)
     if (d->colstats) {  // bf16, plain epilogue (checked by nt256_ok)
         const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
-        if (cv == 0) P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 0, true);
+        if (cv == 0 && nj == 3) P_LAUNCH_R(bf16_t, SSL4GIE_EPI_NONE, 0, true, 0, 3, NT256_DEFAULT_PH2);
+        else if (cv == 0) P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 0, true);
         else if (cv == 1) P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 1, true);
         else P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 2, true);
     } else if (d->conv) {
