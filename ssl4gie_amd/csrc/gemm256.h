@@ -260,6 +260,20 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
     }
 }
 
+// sum over the 8 lanes l, l ^ 8, l ^ 16, ... of a wave that share (l & 7), in that pairing order (the values equal
+// three __shfl_xor rounds bit for bit): a DPP rotation inside the 16-lane rows and the two row / half swaps of
+// gfx950 — VALU only, where 48 ds_bpermute round trips with their lgkmcnt waits cost ~1 us per output tile
+DEVI float p_fold_lanes8(float v) {
+    const unsigned b0 = __float_as_uint(v);
+    v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)b0, 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    const unsigned b1 = __float_as_uint(v);
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(b1, b1, false, false);
+    v = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
+    const unsigned b2 = __float_as_uint(v);
+    const u32x2 s2 = __builtin_amdgcn_permlane32_swap(b2, b2, false, false);
+    return __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
+}
+
 // ---- epilogue of one wave's 128 x 64 sub-tile ---------------------------------------------------
 // acc[mt][nt]: rows rbase + 16 mt + (l & 15), columns cbase + 16 nt + 4 (l >> 4) + 0..3
 // STATS (bf16 C, plain epilogue): per-column sums and sums of squares of the STORED (bf16-rounded)
@@ -332,10 +346,10 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
             const int c = nt * 2 + (g4 >> 1);
             *(u32x2*)(stg + base + r16 * 128 + ((c ^ (r16 & 7)) << 4) + ((g4 & 1) << 3)) = pk;
         };
-        float cs[8], cq[8];  // STATS: this lane's 8 columns, summed over the rows it flushes
+        f32x2 cs[4], cq[4];  // STATS: this lane's 8 columns (pairs), summed over the rows it flushes
         if constexpr (STATS) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
+            for (int j = 0; j < 4; ++j) cs[j] = cq[j] = f32x2{0.f, 0.f};
         }
         constexpr bool PAIR = MODE == SSL4GIE_EPI_BIAS_GELU_GRAD || MODE == SSL4GIE_EPI_BIAS_GELU;
         // scale / activate block mt and stage it (PAIR: first output at 0, the GELU output at 2048)
@@ -378,10 +392,10 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                     if constexpr (STATS) {
                         if (stats && !(prio_mode & 8)) {  // (bit 3: debug-library ablation)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float lo = __uint_as_float(w[hh][j] << 16), hi = __uint_as_float(w[hh][j] & 0xffff0000u);
-                                cs[2 * j] += lo; cq[2 * j] += lo * lo;
-                                cs[2 * j + 1] += hi; cq[2 * j + 1] += hi * hi;
+                            for (int j = 0; j < 4; ++j) {  // one v_pk_add_f32 + one v_pk_fma_f32 per column pair
+                                const f32x2 v = {__uint_as_float(w[hh][j] << 16), __uint_as_float(w[hh][j] & 0xffff0000u)};
+                                cs[j] += v;
+                                cq[j] = v * v + cq[j];
                             }
                         }
                     }
@@ -467,21 +481,21 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
         if constexpr (STATS) {
             // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row groups
             if (!(prio_mode & 16))  // (bit 4: debug-library ablation)
+            {
 #pragma unroll
-            for (int o = 8; o < 64; o <<= 1)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    cs[j] += __shfl_xor(cs[j], o, 64);
-                    cq[j] += __shfl_xor(cq[j], o, 64);
+                for (int j = 0; j < 4; ++j) {
+                    cs[j] = f32x2{p_fold_lanes8(cs[j][0]), p_fold_lanes8(cs[j][1])};
+                    cq[j] = f32x2{p_fold_lanes8(cq[j][0]), p_fold_lanes8(cq[j][1])};
                 }
+            }
             const int gn = cbase + 8 * Cc;
             // a 128-row block that starts past M has no row in colstats (ceil(M / 128) blocks)
-            if (lane < 8 && mine && (FULL || (gn < N && rbase < M))) {
+            if (lane < 8 && mine && !(prio_mode & 32) && (FULL || (gn < N && rbase < M))) {
                 float* p = colstats + (size_t)(rbase >> 7) * 2 * N + gn;
-                st4(p, f32x4{cs[0], cs[1], cs[2], cs[3]});
-                st4(p + 4, f32x4{cs[4], cs[5], cs[6], cs[7]});
-                st4(p + N, f32x4{cq[0], cq[1], cq[2], cq[3]});
-                st4(p + N + 4, f32x4{cq[4], cq[5], cq[6], cq[7]});
+                st4(p, f32x4{cs[0][0], cs[0][1], cs[1][0], cs[1][1]});
+                st4(p + 4, f32x4{cs[2][0], cs[2][1], cs[3][0], cs[3][1]});
+                st4(p + N, f32x4{cq[0][0], cq[0][1], cq[1][0], cq[1][1]});
+                st4(p + N + 4, f32x4{cq[2][0], cq[2][1], cq[3][0], cq[3][1]});
             }
         }
     } else {

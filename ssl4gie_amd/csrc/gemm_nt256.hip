@@ -543,11 +543,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
                                                       n0 + wc * WN, x_M, N, lane, e_colstats,
                                                       (stamping && c_ti - 1 < NT256_STAMP_TILES)
                                                           ? &g_nt256_stamps[blockIdx.x >> 4][c_ti - 1][5] : nullptr,
-                                                      dbg_prio & 27, !(dbg_prio & 4));
+                                                      dbg_prio & 59, !(dbg_prio & 4));
             } else {
                 p_epilogue<TC, MODE, false, STATS, true, NJ>(acc, stg, e_alpha, e_bias, x_res, x_ldr, x_aux, x_out2,
                                                    e_accumulate, x_C, ldc, x_rbase, n0 + wc * WN, x_M, N, lane,
-                                                   e_colstats);
+                                                   e_colstats, nullptr, dbg_prio & 59, !(dbg_prio & 4));
             }
 #else
             if (full)
