@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ....engine import EngineModule, LinearFn, bump_weights_epoch
+from ....engine import EngineModule, LinearFn, MatmulNTFn, bump_weights_epoch
 from ....resnet_engine import BatchNormFn
 from .... import ops
 
@@ -89,7 +89,7 @@ class MoCo(EngineModule):
             rank, world = dist.get_rank(), dist.get_world_size()
         if world > 1:
             k = concat_all_gather(k)
-        logits = q @ k.t() / self.T
+        logits = (MatmulNTFn.apply(q, k) if q.is_cuda else q @ k.t()) / self.T  # einsum('nc,mc->nm') of builder.py:83
         n = logits.shape[0]  # batch size per GPU
         labels = torch.arange(n, dtype=torch.long, device=logits.device) + n * rank
         return nn.functional.cross_entropy(logits, labels) * (2 * self.T)

@@ -605,6 +605,25 @@ class LinearFn(torch.autograd.Function):
         return dx, rets[0], rets[1], None, None, None, None, None, None
 
 
+class MatmulNTFn(torch.autograd.Function):
+    """a @ b^T for two fp32 [rows, C] matrices on the library's GEMM (torch.einsum('nc,mc->nm', [q, k]) of
+    MoCo's InfoNCE, moco/builder.py:83; `q @ k.t()` would be two hipBLASLt launches per call and direction)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a2, b2 = a.contiguous().float(), b.contiguous().float()
+        ctx.save_for_backward(a2, b2)
+        return ops.linear_fwd(a2, b2, None, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, b2 = ctx.saved_tensors
+        dy2 = dy.contiguous().float()
+        da = ops.linear_bwd_data(dy2, b2, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        db = ops.linear_bwd_weight(dy2, a2) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
 class PatchEmbedFn(torch.autograd.Function):
     """PatchEmbed conv (k=s=p) as gather + GEMM, + pos-embed add + cls concat, computed ONLY for the
     patches that survive masking (`ids[:, :nsel]`): identical per-row arithmetic to embedding all

@@ -47,6 +47,24 @@ def test_mlp_head_matches_reference_fixture(tag, dims):
         assert rel_err(p.grad, g[f"{tag}/grad/{k}"]) < 1e-3, k
 
 
+def test_infonce_logits_on_the_library_gemm():
+    """MatmulNTFn (q @ k^T of moco/builder.py:83 on ssl4gie_gemm) against torch in fp64: value and both gradients"""
+    from ssl4gie_amd.engine import MatmulNTFn
+    g = torch.Generator().manual_seed(7)
+    for n, m, c in ((256, 256, 256), (48, 96, 256), (5, 7, 24)):
+        q = torch.randn(n, c, generator=g).to(DEV).requires_grad_(True)
+        k = torch.randn(m, c, generator=g).to(DEV).requires_grad_(True)
+        w = torch.randn(n, m, generator=g).to(DEV)
+        y = MatmulNTFn.apply(q, k)
+        (y * w).sum().backward()
+        q64, k64 = q.detach().double().requires_grad_(True), k.detach().double().requires_grad_(True)
+        y64 = q64 @ k64.t()
+        (y64 * w.double()).sum().backward()
+        assert rel_err(y.detach().cpu(), y64.detach().float().cpu()) < 1e-5
+        assert rel_err(q.grad.cpu(), q64.grad.float().cpu()) < 1e-5
+        assert rel_err(k.grad.cpu(), k64.grad.float().cpu()) < 1e-5
+
+
 def test_momentum_update_is_exact_axpby():
     m = _moco().to(DEV)
     m._prepare()
