@@ -156,6 +156,18 @@ def depth_batches(nb=4, b=2):
     return out
 
 
+def det_batches(nb=2, size=512, dim=768):
+    """the seeded (image, target tokens) batches of the G15 curve (detection trunk at size x size, B = 1): the
+    target is a fixed random token map the trunk's output is regressed on"""
+    out = []
+    for i in range(nb):
+        g = torch.Generator("cpu").manual_seed(600 + i)
+        imgs = torch.randn(1, 3, size, size, generator=g)
+        tgt = 0.5 * torch.randn(1, (size // 16) ** 2, dim, generator=g)
+        out.append((imgs, tgt))
+    return out
+
+
 def moco_views(nb=4, b=8, size=64):
     """the seeded view pairs of the G14 curve"""
     out = []

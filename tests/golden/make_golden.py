@@ -770,6 +770,34 @@ def g14_moco_curve(steps=50):
     print("g14 first/last", losses[0], losses[-1])
 
 
+def g15_det_curve(steps=30):
+    """the reference's own VisionTransformer_from_Any(det=True) trunk (models.py:155-210 windowed
+    blocks, :310-338) at 512 x 512 (1024 tokens, four 256-token windows), B = 1, trained for 30 steps: tokens
+    regressed on a fixed random target (the reference trains this trunk inside detectron2, which is not in its
+    tree: the loop is zero_grad / forward_features / mean squared error / backward / AdamW(lr 2e-5).step()), two
+    seeded batches in rotation.  Weights: the keyed set of G10 (seed 31)."""
+    rm = import_reference_models()
+    m = rm.VisionTransformer_from_Any(False, 0, False, None, True, 512, 768, 12, 12, "cls")
+    shapes, digest = load_keyed(m, seed=31)
+    m.train()
+    opt = torch.optim.AdamW([p for k, p in m.named_parameters() if not k.startswith("fpn.")], lr=2e-5)
+    batches = synth.det_batches()
+    losses = []
+    for it in range(steps):
+        imgs, tgt = batches[it % len(batches)]
+        opt.zero_grad()
+        loss = ((m.forward_features(imgs) - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        if it % 5 == 0:
+            print(f"  g15 step {it}: {losses[-1]:.6f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "g15_det_curve.npz"), losses=np.array(losses, dtype=np.float64),
+                        keys=np.array(sorted(shapes)), digest=np.array(digest), lr=np.array(2e-5),
+                        batch=np.array(1), steps=np.array(steps), size=np.array(512), n_batches=np.array(len(batches)))
+    print("g15 first/last", losses[0], losses[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-curve", action="store_true")
@@ -783,7 +811,7 @@ def main():
         "g5tiny": lambda: g5_tiny(ref_mae), "g5vitb": lambda: g5_vitb(ref_mae),
         "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi, "g8": g8_moco, "g9": g9_dpt_seg,
         "g3b": g3b_moco_sincos, "g10": g10_det, "g11": g11_vit_api, "g12": g12_resnet_dec,
-        "g13": g13_depth_curve, "g14": g14_moco_curve,
+        "g13": g13_depth_curve, "g14": g14_moco_curve, "g15": g15_det_curve,
         "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
             **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
             "g5_curve_tiny.npz"),

@@ -6,6 +6,9 @@ within 1e-3 over 100 steps" — the MAE curves of configs[1] live in test_gpu_ma
        Depth_estimation/train_depth.py:35-48 (models.py:458-475), B = 2, 60 steps, four batches in rotation;
   G14  MoCo_ResNet + LARS (moco/builder.py:75-96, moco/optimizer.py), 128 x 128 views, B = 16, 50 steps.
 
+  G15   VisionTransformer_from_Any(det=True) trunk at 512 x 512, tokens regressed on a fixed target,
+       AdamW(2e-5), B = 1, 30 steps (the reference trains this trunk inside detectron2; the loop is the generator's).
+
 The fp32 engine is held to the north_star's 1e-3 per step; the bf16 production engine (with the arena optimizers
 bench.py runs) to 1.5 x its measured deviation.  Weights are oracle.synth.keyed_tensor on both sides, proven equal
 by the SHA-256 in the fixture."""
@@ -180,3 +183,51 @@ def test_g14_step0_gradients_fp32_within_the_reference_own_fp32_noise():
         assert e < 1.5 * G14_REF_FP32_VS_FP64, (k, float(e))
     print(f"G14 step-0 gradients, fp32 engine vs reference fp32: worst relative L2 error {worst:.3e} "
           f"(reference fp32 vs fp64: {G14_REF_FP32_VS_FP64:.1e})")
+
+
+def _det_curve(prec, optim, steps):
+    from oracle import synth
+    from ssl4gie_amd.Models import models
+    g = load_golden("g15_det_curve.npz")
+    m = models.VisionTransformer_from_Any(False, 0, False, None, True, 1024, 768, 12, 12, "cls")
+    keyed_weights(m, 31, g["keys"], g["digest"])
+    m.fixed_size = 512          # same module, smaller grid (as test_gpu_models_golden.py does for G10)
+    m.patch_embed.img_size = (512, 512)
+    m.to(DEV).set_precision(prec)
+    m.train()
+    trunk = [p for k, p in m.named_parameters() if not k.startswith("fpn.")]
+    if optim == "arena":
+        from ssl4gie_amd.optim import ArenaAdamW
+        opt = ArenaAdamW(m, trunk, lr=2e-5)
+    else:
+        opt = torch.optim.AdamW(trunk, lr=2e-5)
+    batches = [(x.to(DEV), t.to(DEV)) for x, t in synth.det_batches()]
+    losses = []
+    for it in range(steps):
+        imgs, tgt = batches[it % len(batches)]
+        opt.zero_grad()
+        loss = ((m.forward_features(imgs) - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    return np.array(losses), g["losses"][:steps]
+
+
+# measured on MI355X (round 4, profiles/r04ar_g15_curve.log)
+G15_BF16_MEASURED = {"torch": 8.2e-5, "arena": 8.1e-5}   # fp32: 1.4e-7 / 4.2e-7
+
+
+@pytest.mark.parametrize("optim", ["torch", "arena"])
+def test_g15_det_curve_fp32(optim):
+    losses, ref = _det_curve("fp32", optim, 30)
+    err = np.abs(losses - ref) / np.abs(ref)
+    print(f"G15 det-trunk curve fp32 [{optim}]: max rel deviation {err.max():.3e} at step {int(err.argmax())}, mean {err.mean():.3e}")
+    assert err.max() < 1e-3, (int(err.argmax()), float(err.max()))
+
+
+@pytest.mark.parametrize("optim", ["torch", "arena"])
+def test_g15_det_curve_bf16(optim):
+    losses, ref = _det_curve("bf16", optim, 30)
+    err = np.abs(losses - ref) / np.abs(ref)
+    print(f"G15 det-trunk curve bf16 [{optim}]: max rel deviation {err.max():.3e} at step {int(err.argmax())}, mean {err.mean():.3e}")
+    assert err.max() < 1.5 * G15_BF16_MEASURED[optim], (int(err.argmax()), float(err.max()))

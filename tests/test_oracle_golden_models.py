@@ -241,3 +241,18 @@ def test_g14_moco_curve_first_step_oracle_fp64():
         k1, k2 = enc("momentum_encoder.", x1), enc("momentum_encoder.", x2)
         loss = moco_ref.contrastive_loss(q1, k2, 1.0) + moco_ref.contrastive_loss(q2, k1, 1.0)
     assert abs(float(loss) - float(g["losses"][0])) < 1e-5 * float(g["losses"][0])
+
+
+def test_g15_det_curve_first_step_oracle():
+    """the first value of the reference's detection-trunk curve (g15: VisionTransformer_from_Any(det=True) at
+    512 x 512, tokens regressed on a fixed target) from the oracle's trunk on the same keyed weights and batch"""
+    from oracle import det_ref
+    from ssl4gie_amd.Models import models
+    g = load_golden("g15_det_curve.npz")
+    m = models.VisionTransformer_from_Any(False, 0, False, None, True, 1024, 768, 12, 12, "cls")
+    sd = keyed_weights(m, 31, g["keys"], g["digest"])
+    imgs, tgt = synth.det_batches()[0]
+    with torch.no_grad():
+        tok = det_ref.det_trunk(sd, imgs, 512)
+        loss = ((tok - tgt) ** 2).mean()
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-4 * float(g["losses"][0])
