@@ -19,7 +19,7 @@
  *     entry points existed; 3: before the direct transport's error word / time-out / all-gather,
  *     ssl4gie_bn_combine_stats and ssl4gie_debug_nt256_stamps existed — additions only; 4: before
  *     ssl4gie_gemm_desc gained `scale` / `relu` (appended; SSL4GIE_EPI_AFFINE_AUX_RELU and the
- *     statistics-only product with C == NULL) and ssl4gie_bn_bwd_xmask / ssl4gie_bn_coef_partials existed);
+ *     statistics-only product with C == NULL) and ssl4gie_bn_bwd_xmask / ssl4gie_bn_coef_partials / ssl4gie_bn_maxpool3x3s2_fwd existed);
  *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
  *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
  */
@@ -503,6 +503,13 @@ int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* arg, int dty
                              int W, int C, void* stream);
 int ssl4gie_maxpool3x3s2_bwd(const void* dy, const unsigned char* arg, void* dx, int dtype, int B,
                              int H, int W, int C, void* stream);
+/* The same pool over act(x coef[0][c] + coef[1][c]), act = ReLU if `relu` (coef [2][C] as ssl4gie_bn_coef_partials
+ * writes it): torchvision ResNet's bn1 -> relu -> maxpool behind the stem convolution in ONE pass over the
+ * convolution's output — the normalised map is never written (the backward rebuilds its ReLU mask from the
+ * convolution output: ssl4gie_bn_bwd_xmask).  Values and argmax equal ssl4gie_bn_fwd_partials followed by
+ * ssl4gie_maxpool3x3s2_fwd bit for bit.  C % 8 == 0 (bf16) / C % 4 == 0 (fp32). */
+int ssl4gie_bn_maxpool3x3s2_fwd(const void* x, const float* coef, int relu, void* y, unsigned char* arg,
+                                int dtype, int B, int H, int W, int C, void* stream);
 int ssl4gie_avgpool_fwd(const void* x, float* y, int dtype, int B, int HW, int C, void* stream);
 int ssl4gie_avgpool_bwd(const float* dy, void* dx, int dtype, int B, int HW, int C, void* stream);
 

@@ -26,7 +26,8 @@ _BN_STATS = os.environ.get("SSL4GIE_BN_STATS_FUSED", "1") != "0"
 # a BatchNorm pass re-reads it under torch.no_grad() too (A/B measurements)
 _BN_RECOMPUTE = os.environ.get("SSL4GIE_BN_RECOMPUTE", "1") != "0"
 from ..engine import EngineModule, GradJoin, LinearFn
-from ..resnet_engine import AvgPoolFn, BatchNormFn, MaxPoolFn, StemConvFn, Subsample2Fn, _count_batch, _sync_group
+from ..resnet_engine import (AvgPoolFn, BatchNormFn, BnReluMaxPoolFn, MaxPoolFn, StemConvFn, Subsample2Fn, _count_batch,
+                             _sync_group, bn_relu_maxpool_ok)
 
 
 class Bottleneck(nn.Module):
@@ -175,8 +176,11 @@ class ResNet50(EngineModule):
         self._prepare()
         r = StemConvFn.apply(imgs, self.conv1.weight, self.dtype_, self.sink(), self.lp_cache, _BN_STATS)
         x, st = r if _BN_STATS else (r, None)
-        x = self._bn(x, self.bn1, True, stats=st)
-        x = MaxPoolFn.apply(x)
+        if bn_relu_maxpool_ok(x, self.bn1, st):   # bn1 -> relu -> maxpool in one pass over the convolution output
+            x = BnReluMaxPoolFn.apply(x, self.bn1.weight, self.bn1.bias, self.bn1, self.sink(), st)
+        else:
+            x = self._bn(x, self.bn1, True, stats=st)
+            x = MaxPoolFn.apply(x)
         maps = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:

@@ -132,6 +132,7 @@ PROTOTYPES = {
     "ssl4gie_bn_bwd_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_ema_update": (i32, [vp, vp, f32, i64, vp]),
     "ssl4gie_maxpool3x3s2_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_bn_maxpool3x3s2_fwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_maxpool3x3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ssl4gie_avgpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),

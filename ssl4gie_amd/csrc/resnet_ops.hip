@@ -540,10 +540,14 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char
 
 // the same with a thread owning V = 16 B / sizeof(T) channels of a pixel (C % V == 0): 16-byte
 // loads / stores, V argmax bytes per store
+// coef (optional, [2][C]): the window runs over act(x coef[0][c] + coef[1][c]) rounded to T — the training-mode
+// BatchNorm (+ ReLU) between the stem convolution and the pool, applied on the way in: its output map is never
+// written or re-read (values and argmax equal the two-kernel form bit for bit: same arithmetic, same rounding
+// before the comparisons, so the many ties at 0 behind the ReLU resolve the same way)
 template <typename T>
 __global__ void maxpool_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ y,
                                        unsigned char* __restrict__ arg, int H, int W, int C, int Ho,
-                                       int Wo, long long total) {
+                                       int Wo, long long total, const float* __restrict__ coef, int relu) {
     constexpr int V = V16<T>::N;
     typedef typename V16<T>::raw raw_t;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -557,6 +561,14 @@ __global__ void maxpool_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ 
     unsigned char bi[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    float ca[V], cb[V];
+    if (coef) {
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+            *(f32x4*)(ca + j) = ld4(coef + c + j);
+            *(f32x4*)(cb + j) = ld4(coef + C + c + j);
+        }
+    }
     bool found = false;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -568,6 +580,14 @@ __global__ void maxpool_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ 
             if (ix < 0 || ix >= W) continue;
             float v[V];
             un<T>(*(const raw_t*)(x + ((b * H + iy) * W + ix) * C + c), v);
+            if (coef) {  // as bn_apply_kernel, then through T's rounding
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float u = v[j] * ca[j] + cb[j];
+                    v[j] = (relu && u < 0.f) ? 0.f : u;
+                }
+                un<T>(pk<T>(v), v);
+            }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 if (!found || v[j] > best[j]) {  // first maximum in scan order
@@ -830,11 +850,24 @@ extern "C" int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* a
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if (C % rvn(dtype) == 0) {
         const long long total = (long long)B * Ho * Wo * (C / rvn(dtype));
-        RN_LAUNCH(dtype, maxpool_fwd_vec_kernel, total, (const T*)x, (T*)y, arg, H, W, C, Ho, Wo, total);
+        RN_LAUNCH(dtype, maxpool_fwd_vec_kernel, total, (const T*)x, (T*)y, arg, H, W, C, Ho, Wo, total,
+                  (const float*)nullptr, 0);
         return 0;
     }
     const long long total = (long long)B * Ho * Wo * C;
     RN_LAUNCH(dtype, maxpool_fwd_kernel, total, (const T*)x, (T*)y, arg, H, W, C, Ho, Wo, total);
+    return 0;
+}
+// MaxPool2d(3, 2, 1) over act(x coef[0][c] + coef[1][c]) (coef [2][C] from ssl4gie_bn_coef_partials): BatchNorm
+// + ReLU + pool of the ResNet stem in one pass over the convolution's output
+extern "C" int ssl4gie_bn_maxpool3x3s2_fwd(const void* x, const float* coef, int relu, void* y,
+                                           unsigned char* arg, int dtype, int B, int H, int W, int C,
+                                           void* stream) {
+    REQUIRE(x && coef && y && arg && rdt(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && C % rvn(dtype) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)B * Ho * Wo * (C / rvn(dtype));
+    RN_LAUNCH(dtype, maxpool_fwd_vec_kernel, total, (const T*)x, (T*)y, arg, H, W, C, Ho, Wo, total, coef, relu);
     return 0;
 }
 extern "C" int ssl4gie_maxpool3x3s2_bwd(const void* dy, const unsigned char* arg, void* dx, int dtype,

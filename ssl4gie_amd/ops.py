@@ -986,11 +986,19 @@ def bn_bwd_xmask(dy2d, x2d, gamma, beta, mean, rstd, dgamma, dbeta, accumulate):
     return dx
 
 
-def maxpool3x3s2_fwd(x):
+def maxpool3x3s2_fwd(x, coef=None, relu=False):
+    """coef [2, C] (ops.bn_coef_partials): the pool runs over act(x coef[0] + coef[1]) — BatchNorm (+ ReLU) applied
+    on the way in (ssl4gie_bn_maxpool3x3s2_fwd)"""
     B, H, W, C = _nhwc(x)
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(B, Ho, Wo, C, dtype=x.dtype, device=x.device)
     arg = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+    if coef is not None:
+        _dev(coef); _f32(coef)
+        assert coef.shape == (2, C) and coef.is_contiguous()
+        _lib.check(_lib.load().ssl4gie_bn_maxpool3x3s2_fwd(ptr(x), ptr(coef), int(bool(relu)), ptr(y), ptr(arg),
+                                                           code(x.dtype), B, H, W, C, stream()), "bn_maxpool_fwd")
+        return y, arg
     _lib.check(_lib.load().ssl4gie_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(arg), code(x.dtype), B, H, W, C,
                                                     stream()), "maxpool_fwd")
     return y, arg

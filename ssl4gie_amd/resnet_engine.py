@@ -355,6 +355,49 @@ class MaxPoolFn(torch.autograd.Function):
         return ops.maxpool3x3s2_bwd(dy.contiguous(), arg, *ctx.hw)
 
 
+class BnReluMaxPoolFn(torch.autograd.Function):
+    """torchvision ResNet's bn1 -> relu -> maxpool(3, 2, 1) behind the stem convolution (`ResNet._forward_impl`)
+    as ONE pass over the convolution's output: the training-mode statistics come from the convolution's epilogue
+    partials, the normalisation + ReLU are applied inside the pool's window reads — the normalised map
+    (0.4 GB per view at 256 x 112 x 112 x 64) is never written.  Backward: pool gradient by the saved argmax,
+    BatchNorm + ReLU backward with the mask rebuilt from the convolution output (ops.bn_bwd_xmask)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, sink: GradSink, stats):
+        B, H, W, C = x.shape
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        coef, mean, rstd = ops.bn_coef_partials(stats, B * H * W, gamma.detach() if gamma is not None else None,
+                                                beta.detach() if beta is not None else None, bn.running_mean,
+                                                bn.running_var, mom, bn.eps)
+        if bn.num_batches_tracked is not None:
+            _count_batch(bn)
+        y, arg = ops.maxpool3x3s2_fwd(x.contiguous(), coef, True)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, arg)
+        ctx.sink = sink
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd, arg = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dz = ops.maxpool3x3s2_bwd(dy.contiguous(), arg, H, W)
+        (tg, tb), acc, rets = ctx.sink.plan([gamma, beta])
+        dx = ops.bn_bwd_xmask(dz.view(-1, C), x.contiguous().view(-1, C), gamma.detach() if gamma is not None else None,
+                              beta.detach() if beta is not None else None, mean, rstd, tg, tb, acc)
+        return dx.view(B, H, W, C), rets[0], rets[1], None, None, None
+
+
+def bn_relu_maxpool_ok(x, bn, stats):
+    """whether BnReluMaxPoolFn applies: training-mode statistics from the convolution's partials, one process
+    (SyncBatchNorm exchanges between the statistics and the apply), vector-width channels"""
+    return (_STEM_POOL_FUSED and stats is not None and (bn.training or bn.running_mean is None)
+            and not _sync_group(bn)[0] and x.shape[-1] % (8 if x.dtype == torch.bfloat16 else 4) == 0)
+
+
+# SSL4GIE_STEM_POOL_FUSED=0: bn1 / relu / maxpool of the ResNet stem as separate passes again (A/B)
+_STEM_POOL_FUSED = __import__("os").environ.get("SSL4GIE_STEM_POOL_FUSED", "1") != "0"
+
+
 class AvgPoolFn(torch.autograd.Function):
     """AdaptiveAvgPool2d(1) + flatten -> fp32 [B, C]"""
 

@@ -97,6 +97,39 @@ def test_batchnorm_relu_backward_mask_from_x_equals_mask_from_output(rows, C, dt
     assert torch.equal(dx2, dx1) and torch.equal(dg1, 2 * dg0) and torch.equal(db1, 2 * db0)
 
 
+@pytest.mark.parametrize("dtype", [F32, BF])
+def test_stem_bn_relu_maxpool_in_one_pass_equals_the_three_kernels(dtype):
+    """BnReluMaxPoolFn (statistics from the convolution's partials, normalisation + ReLU inside the pool's window
+    reads) against BatchNormFn + MaxPoolFn: pooled map, input gradient, dgamma / dbeta and running statistics
+    bit-identical (odd map sizes: clipped windows; ReLU ties at 0)"""
+    from ssl4gie_amd.engine import GradSink
+    from ssl4gie_amd.resnet_engine import BatchNormFn, BnReluMaxPoolFn, MaxPoolFn
+    B, H, W, C = 3, 17, 19, 64
+    g = G(77)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3).to(dtype).to(DEV)
+    x2 = x.view(-1, C).float()
+    pad = (-x2.shape[0]) % 128
+    xp = torch.cat([x2, x2.new_zeros(pad, C)]).view(-1, 128, C)
+    st = torch.stack([xp.sum(1), (xp * xp).sum(1)], 1).contiguous()     # what the stem convolution's epilogue emits
+    outs = []
+    for fused in (False, True):
+        bn = torch.nn.BatchNorm2d(C).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(torch.randn(C, generator=G(78)).to(DEV))
+            bn.bias.copy_((0.3 * torch.randn(C, generator=G(79))).to(DEV))
+        xi = x.clone().requires_grad_(True)
+        if fused:
+            y = BnReluMaxPoolFn.apply(xi, bn.weight, bn.bias, bn, GradSink(None), st)
+        else:
+            y = MaxPoolFn.apply(BatchNormFn.apply(xi, bn.weight, bn.bias, None, bn, True, GradSink(None), st))
+        dy = torch.randn(y.shape, generator=G(80)).to(dtype).to(DEV)
+        y.backward(dy)
+        outs.append((y.detach(), xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][0].shape == (B, 9, 10, C)
+
+
 def test_maxpool_avgpool_subsample():
     from ssl4gie_amd.resnet_engine import AvgPoolFn, MaxPoolFn, Subsample2Fn
     x = torch.relu(torch.randn(2, 16, 12, 10, generator=G(6)))  # ReLU output: many tied zeros
