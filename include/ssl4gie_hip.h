@@ -19,7 +19,8 @@
  *     entry points existed; 3: before the direct transport's error word / time-out / all-gather,
  *     ssl4gie_bn_combine_stats and ssl4gie_debug_nt256_stamps existed — additions only; 4: before
  *     ssl4gie_gemm_desc gained `scale` / `relu` (appended; SSL4GIE_EPI_AFFINE_AUX_RELU and the
- *     statistics-only product with C == NULL) and ssl4gie_bn_bwd_xmask / ssl4gie_bn_coef_partials / ssl4gie_bn_maxpool3x3s2_fwd existed);
+ *     statistics-only product with C == NULL) and ssl4gie_bn_bwd_xmask / ssl4gie_bn_coef_partials / ssl4gie_bn_maxpool3x3s2_fwd /
+ *     ssl4gie_conv3x3_direct_{fwd,wgrad}_affine existed);
  *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
  *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
  */
@@ -370,6 +371,17 @@ size_t ssl4gie_conv3x3_direct_wgrad_workspace_bytes(int B, int H, int W, int Cin
 int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float* dw2, float* dbias,
                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin,
                                  int Cout, int relu_in, int accumulate, void* stream);
+/* The same two kernels with a training-mode BatchNorm (+ ReLU) applied to their input on the way in: the operand
+ * is act(x in_coef[0][ci] + in_coef[1][ci]) rounded to bf16 (in_coef [2][Cin] as ssl4gie_bn_coef_partials writes
+ * it; act = ReLU if relu_in), zero-padded AFTER the normalisation — torchvision Bottleneck bn1 -> relu -> conv2
+ * without a BatchNorm pass or a normalised map in memory (its backward: ssl4gie_bn_bwd_xmask on the data gradient).
+ * Values equal ssl4gie_bn_fwd_partials followed by the plain kernels bit for bit. */
+int ssl4gie_conv3x3_direct_fwd_affine(const void* x, const float* in_coef, const void* w2, const float* bias,
+                                      void* y, float* colstats, int B, int H, int W, int Cin, int Cout,
+                                      int relu_in, void* stream);
+int ssl4gie_conv3x3_direct_wgrad_affine(const void* dy, const void* x, const float* in_coef, float* dw2,
+                                        float* dbias, void* workspace, size_t workspace_bytes, int B, int H,
+                                        int W, int Cin, int Cout, int relu_in, int accumulate, void* stream);
 /* torchvision ResNet.conv1 = nn.Conv2d(3, 64, 7, stride 2, pad 3, bias=False) (reference
  * Models/models.py:63-69) WITHOUT a patch matrix (ssl4gie_stem_im2col7x7 + GEMM remain for fp32).
  *   pack:  img fp32 [B,3,H,W] -> packed bf16 [B, 2 Ho + 6, 2 Wo + 6, 4] (three channels + a zero,

@@ -26,8 +26,8 @@ _BN_STATS = os.environ.get("SSL4GIE_BN_STATS_FUSED", "1") != "0"
 # a BatchNorm pass re-reads it under torch.no_grad() too (A/B measurements)
 _BN_RECOMPUTE = os.environ.get("SSL4GIE_BN_RECOMPUTE", "1") != "0"
 from ..engine import EngineModule, GradJoin, LinearFn
-from ..resnet_engine import (AvgPoolFn, BatchNormFn, BnReluMaxPoolFn, MaxPoolFn, StemConvFn, Subsample2Fn, _count_batch,
-                             _sync_group, bn_relu_maxpool_ok)
+from ..resnet_engine import (AvgPoolFn, BatchNormFn, BnReluConv3x3Fn, BnReluMaxPoolFn, MaxPoolFn, StemConvFn,
+                             Subsample2Fn, _count_batch, _sync_group, bn_relu_conv3x3_ok, bn_relu_maxpool_ok)
 
 
 class Bottleneck(nn.Module):
@@ -142,10 +142,15 @@ class ResNet50(EngineModule):
         # x feeds conv1 and the identity (or downsample) branch: one GradJoin, conv1 is the adder
         join = GradJoin.for_tensor(x) if _GRAD_JOIN else None
         out, st = self._c1(x, blk.conv1, join)
-        out = self._bn(out, blk.bn1, True, stats=st)
-        r = Conv3x3Fn.apply(out, blk.conv2.weight, None, blk.conv2.stride[0], False, self.sink(),
-                            self.lp_cache, _BN_STATS)
-        out, st = r if _BN_STATS else (r, None)
+        if bn_relu_conv3x3_ok(out, blk.bn1, st, blk.conv2, torch.is_grad_enabled()):
+            # bn1 -> relu applied inside the 3x3 convolution's halo staging: no BatchNorm pass, no normalised map
+            out, st = BnReluConv3x3Fn.apply(out, blk.bn1.weight, blk.bn1.bias, blk.bn1, st, blk.conv2.weight,
+                                            self.sink(), self.lp_cache, _BN_STATS)
+        else:
+            out = self._bn(out, blk.bn1, True, stats=st)
+            r = Conv3x3Fn.apply(out, blk.conv2.weight, None, blk.conv2.stride[0], False, self.sink(),
+                                self.lp_cache, _BN_STATS)
+            out, st = r if _BN_STATS else (r, None)
         out = self._bn(out, blk.bn2, True, stats=st)
         identity = x
         if blk.downsample is not None:

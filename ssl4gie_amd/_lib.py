@@ -105,6 +105,8 @@ PROTOTYPES = {
     "ssl4gie_conv3x3_direct_wgrad_ok": (i32, [i32, i32, i32, i32, i32]),
     "ssl4gie_conv3x3_direct_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "ssl4gie_conv3x3_direct_wgrad": (i32, [vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_conv3x3_direct_wgrad_affine": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ssl4gie_conv3x3_direct_fwd_affine": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_stem7x7_packed_bytes": (sz, [i32, i32, i32]),
     "ssl4gie_stem7x7_pack": (i32, [vp, vp, i32, i32, i32, vp]),
     "ssl4gie_stem7x7_tiles": (i32, [i32, i32, i32]),

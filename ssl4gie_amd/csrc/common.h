@@ -58,6 +58,23 @@ DEVI void st4(bf16_t* p, f32x4 v) {
     *(u32x2*)p = r;
 }
 
+// eight bf16 values through y = act(x a + b) and back to bf16 — EXACTLY bn_apply_kernel's arithmetic (one fused
+// multiply-add, the select, one round-to-nearest-even), so that a consumer applying a BatchNorm on the way in
+// sees the values the separate pass would have stored
+DEVI u32x4 bn_affine_act8(const u32x4 x, const f32x4 (&a)[2], const f32x4 (&b)[2], const int relu) {
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float lo = __uint_as_float(x[j] << 16), hi = __uint_as_float(x[j] & 0xffff0000u);
+        float u = lo * a[j >> 1][(2 * j) & 3] + b[j >> 1][(2 * j) & 3];
+        float v = hi * a[j >> 1][(2 * j + 1) & 3] + b[j >> 1][(2 * j + 1) & 3];
+        u = (relu && u < 0.f) ? 0.f : u;
+        v = (relu && v < 0.f) ? 0.f : v;
+        r[j] = pack_bf2(u, v);
+    }
+    return r;
+}
+
 // ---- wave reductions (64 lanes) -------------------------------------------------------
 DEVI float wave_sum(float v) {
 #pragma unroll

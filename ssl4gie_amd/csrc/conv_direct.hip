@@ -176,11 +176,16 @@ DEVI void dc_epilogue(f32x16 (&acc)[2][NCB], char* smem, const TilePos tp, const
 // y[b, oy, ox, co] = sum_{tap, ci} act(x)[b, oy + dy - 1, ox + dx - 1, ci] w2[co, tap * Cin + ci]
 // (+ bias[co]) (masked by relu_mask > 0); colstats [tiles][2][Cout]: per-tile sums / sums of squares
 // of y.  grid = tiles * ngroups, ngroups = ceil(Cout / (32 NCB)).
-template <int NCB, typename G>
-__global__ __launch_bounds__(DC_THREADS, NCB == 1 ? 3 : 2) void conv3x3_direct_kernel(
+// AFF: act(x) = act(x in_coef[0][ci] + in_coef[1][ci]) rounded to bf16 (act = ReLU if relu_in), applied to the
+// in-image halo pixels between their global load and their LDS write — the training-mode BatchNorm (+ ReLU) in
+// front of the convolution (torchvision Bottleneck bn1 -> relu -> conv2) without a pass of its own: the
+// normalised map is never written.  Padding stays zero (it pads the NORMALISED map).
+template <int NCB, typename G, bool AFF = false>
+__global__ __launch_bounds__(DC_THREADS, (NCB == 1 && !AFF) ? 3 : 2) void conv3x3_direct_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w2, const float* __restrict__ bias,
     const bf16_t* __restrict__ relu_mask, bf16_t* __restrict__ y, float* __restrict__ colstats, int Bn,
-    int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y, int ngroups) {
+    int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y, int ngroups,
+    const float* __restrict__ in_coef) {
     constexpr int CPP = DC_CPP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xs = smem;
@@ -212,17 +217,27 @@ __global__ __launch_bounds__(DC_THREADS, NCB == 1 ? 3 : 2) void conv3x3_direct_k
 
     constexpr int NX = G::NH * CPP, IX = (NX + DC_THREADS - 1) / DC_THREADS;
     constexpr int NW = NCB * 32 * 9 * CPP, IW = (NW + DC_THREADS - 1) / DC_THREADS;
+    // AFF: the coefficient table [2][Cin] sits in LDS behind the operand images for the whole kernel (a global
+    // fetch per channel slice between the barrier and the halo writes would expose an L2 round trip per slice)
+    [[maybe_unused]] float* Cs = (float*)(smem + G::NH * DC_PS + NCB * 32 * DC_WROW);
+    if constexpr (AFF) {
+        for (int i = tid; i < 2 * Cin; i += DC_THREADS) Cs[i] = in_coef[i];
+        // (visible after the first __syncthreads below: every thread passes one before its first halo write)
+    }
     for (int cin0 = 0; cin0 < Cin; cin0 += DC_CK) {
         // ---- stage the halo and the weight slice: all global loads first, then the LDS writes
         u32x4 xv[IX], wv[IW];
+        [[maybe_unused]] unsigned inimg = 0;  // AFF: which of this thread's halo chunks lie inside the image
 #pragma unroll
         for (int i = 0; i < IX; ++i) {
             const int idx = tid + i * DC_THREADS, pi = idx / CPP, c = idx % CPP;
             const int im = pi / (G::HH * G::HW), hy = (pi / G::HW) % G::HH, hx = pi % G::HW;
             const int gy = tp.ty0 + hy - 1, gx = tp.tx0 + hx - 1, gb = tp.b0 + im;
             xv[i] = u32x4{0, 0, 0, 0};
-            if (idx < NX && gb < Bn && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+            if (idx < NX && gb < Bn && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
                 xv[i] = *(const u32x4*)(x + (((size_t)gb * H + gy) * W + gx) * Cin + cin0 + c * 8);
+                if constexpr (AFF) inimg |= 1u << i;
+            }
         }
 #pragma unroll
         for (int i = 0; i < IW; ++i) {
@@ -232,13 +247,29 @@ __global__ __launch_bounds__(DC_THREADS, NCB == 1 ? 3 : 2) void conv3x3_direct_k
             if (idx < NW && co0 + row < Cout)
                 wv[i] = *(const u32x4*)(w2 + (size_t)(co0 + row) * 9 * Cin + tap * Cin + cin0 + c * 8);
         }
-        if (cin0) __syncthreads();  // the previous channel slice has been consumed
+        if (cin0 || AFF) __syncthreads();  // the previous channel slice has been consumed (AFF: the table is in place)
+        if constexpr (AFF) {
+            // this thread's chunk index is the same for all its halo chunks (DC_THREADS % CPP == 0): one
+            // coefficient set per channel slice, read here so that it is live only across the x writes
+            static_assert(DC_THREADS % CPP == 0, "one channel chunk per thread");
+            const float* ca = Cs + cin0 + (tid % CPP) * 8;
+            const f32x4 a8[2] = {*(const f32x4*)ca, *(const f32x4*)(ca + 4)};
+            const f32x4 b8[2] = {*(const f32x4*)(ca + Cin), *(const f32x4*)(ca + Cin + 4)};
 #pragma unroll
-        for (int i = 0; i < IX; ++i) {
-            const int idx = tid + i * DC_THREADS, pi = idx / CPP, c = idx % CPP;
-            if (idx < NX)
-                *(u32x4*)(Xs + dc_x_off<G>(pi, (pi / G::HW) % G::HH, pi % G::HW, c)) =
-                    relu_in ? relu_bf16x8(xv[i]) : xv[i];
+            for (int i = 0; i < IX; ++i) {
+                const int idx = tid + i * DC_THREADS, pi = idx / CPP, c = idx % CPP;
+                if (idx < NX)
+                    *(u32x4*)(Xs + dc_x_off<G>(pi, (pi / G::HW) % G::HH, pi % G::HW, c)) =
+                        ((inimg >> i) & 1) ? bn_affine_act8(xv[i], a8, b8, relu_in) : xv[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < IX; ++i) {
+                const int idx = tid + i * DC_THREADS, pi = idx / CPP, c = idx % CPP;
+                if (idx < NX)
+                    *(u32x4*)(Xs + dc_x_off<G>(pi, (pi / G::HW) % G::HH, pi % G::HW, c)) =
+                        relu_in ? relu_bf16x8(xv[i]) : xv[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < IW; ++i) {
@@ -321,12 +352,12 @@ DEVI void wgrad_tile(f32x16 (&acc)[5], const char* dbase, const char* const (&xb
 // partial[wg][co 32][tap 9][ci 64] fp32, then partial_b[wg][co 32] (written by the workgroups of
 // slice 0 only); wg = the workgroup's logical id (xcd_remap of blockIdx.x): combo = wg % (nslice * ngroups) = group * nslice + slice picks the
 // 64 input channels and the 32 couts, wg / ncombo the share of the tiles
-template <typename G>
+template <typename G, bool AFF = false>
 __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
     float* __restrict__ partial_b,
     int Bn, int H, int W, int Cin, int Cout, int relu_in, int tiles_x, int tiles_y, int ntiles,
-    int nslice, int ncombo) {
+    int nslice, int ncombo, const float* __restrict__ in_coef) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xs = smem;
     char* Ds = smem + G::NH * 128;
@@ -358,17 +389,24 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
                                   Xs + wg_x_off(G::lin(0, kr, kc + 2), kc + 2, cb * 32) + colb};
     constexpr int NX = G::NH * 8, IX = (NX + DC_THREADS - 1) / DC_THREADS;  // 16-byte chunks
     constexpr int ND = DC_PIX * 4, ID = ND / DC_THREADS;
+    [[maybe_unused]] float* Cs = (float*)(smem + G::NH * 128 + WG_DY_BYTES);  // AFF: this slice's [2][64] coefficients
+    if constexpr (AFF) {
+        if (tid < 128) Cs[tid] = in_coef[(tid >> 6) * Cin + cin0 + (tid & 63)];
+    }
     for (int tile = me; tile < ntiles; tile += wgs_per_combo) {
         const TilePos tp = tile_pos(tile, tiles_x, tiles_y, G::TB, G::TH, G::TW);
         u32x4 xv[IX], dv[ID];
+        [[maybe_unused]] unsigned inimg = 0;
 #pragma unroll
         for (int i = 0; i < IX; ++i) {
             const int idx = tid + i * DC_THREADS, pi = idx >> 3, c = idx & 7;
             const int im = pi / (G::HH * G::HW), hy = (pi / G::HW) % G::HH, hx = pi % G::HW;
             const int gy = tp.ty0 + hy - 1, gx = tp.tx0 + hx - 1, gb = tp.b0 + im;
             xv[i] = u32x4{0, 0, 0, 0};
-            if (idx < NX && gb < Bn && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+            if (idx < NX && gb < Bn && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
                 xv[i] = *(const u32x4*)(x + (((size_t)gb * H + gy) * W + gx) * Cin + cin0 + c * 8);
+                if constexpr (AFF) inimg |= 1u << i;
+            }
         }
 #pragma unroll
         for (int i = 0; i < ID; ++i) {  // dy tile in tile-pixel order, 4 chunks of 8 couts
@@ -379,11 +417,24 @@ __global__ __launch_bounds__(DC_THREADS, 2) void conv3x3_wgrad_direct_kernel(
                 dv[i] = *(const u32x4*)(dy + (((size_t)gb * H + gy) * W + gx) * Cout + co0 + c * 8);
         }
         __syncthreads();  // the previous tile has been consumed
+        if constexpr (AFF) {  // as conv3x3_direct_kernel<.., AFF>: the operand is the normalised map, rebuilt on the way in
+            const float* ca = Cs + (tid & 7) * 8;
+            const f32x4 a8[2] = {*(const f32x4*)ca, *(const f32x4*)(ca + 4)};
+            const f32x4 b8[2] = {*(const f32x4*)(ca + 64), *(const f32x4*)(ca + 68)};
 #pragma unroll
-        for (int i = 0; i < IX; ++i) {
-            const int idx = tid + i * DC_THREADS, pi = idx >> 3, c = idx & 7;
-            if (idx < NX)
-                *(u32x4*)(Xs + wg_x_off(pi, pi % G::HW, c * 8)) = relu_in ? relu_bf16x8(xv[i]) : xv[i];
+            for (int i = 0; i < IX; ++i) {
+                const int idx = tid + i * DC_THREADS, pi = idx >> 3, c = idx & 7;
+                if (idx < NX)
+                    *(u32x4*)(Xs + wg_x_off(pi, pi % G::HW, c * 8)) =
+                        ((inimg >> i) & 1) ? bn_affine_act8(xv[i], a8, b8, relu_in) : xv[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < IX; ++i) {
+                const int idx = tid + i * DC_THREADS, pi = idx >> 3, c = idx & 7;
+                if (idx < NX)
+                    *(u32x4*)(Xs + wg_x_off(pi, pi % G::HW, c * 8)) = relu_in ? relu_bf16x8(xv[i]) : xv[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < ID; ++i) {
@@ -641,26 +692,51 @@ extern "C" int ssl4gie_conv3x3_direct_tiles(int B, int H, int W) {
     return (B > 0 && H > 0 && W > 0) ? pick_geom(B, H, W).tiles : 0;
 }
 
-template <int NCB, typename G>
+template <int NCB, typename G, bool AFF = false>
 static int launch_direct(const Geom& g, const void* x, const void* w2, const float* bias,
                          const void* relu_mask, void* y, float* colstats, int B, int H, int W, int Cin,
-                         int Cout, int relu_in, hipStream_t st) {
-    auto k = conv3x3_direct_kernel<NCB, G>;
-    int lds = G::NH * DC_PS + NCB * 32 * DC_WROW;
+                         int Cout, int relu_in, hipStream_t st, const float* in_coef = nullptr) {
+    auto k = conv3x3_direct_kernel<NCB, G, AFF>;
+    // AFF: + the coefficient table [2][Cin] (Cin <= 2048 by the REQUIRE of the entry point: 16 KiB)
+    constexpr int lds_max = G::NH * DC_PS + NCB * 32 * DC_WROW + (AFF ? 2 * 2048 * (int)sizeof(float) : 0);
+    int lds = G::NH * DC_PS + NCB * 32 * DC_WROW + (AFF ? 2 * Cin * (int)sizeof(float) : 0);
     const int lds_out = DC_PIX * NCB * 64 + 2 * DC_THREADS * (int)sizeof(float);
     if (lds < lds_out) lds = lds_out;
     static bool attr = false;  // one per instantiation
     if (!attr) {
-        HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds_max > lds_out ? lds_max : lds_out));
         attr = true;
     }
     const int ngroups = (Cout + 32 * NCB - 1) / (32 * NCB);
     REQUIRE((long long)g.tiles * ngroups < (1LL << 31));
     hipLaunchKernelGGL(k, dim3((unsigned)(g.tiles * ngroups)), dim3(DC_THREADS), lds, st, (const bf16_t*)x,
                        (const bf16_t*)w2, bias, (const bf16_t*)relu_mask, (bf16_t*)y, colstats, B, H, W, Cin,
-                       Cout, relu_in, g.tiles_x, g.tiles_y, ngroups);
+                       Cout, relu_in, g.tiles_x, g.tiles_y, ngroups, in_coef);
     LAUNCH_CHECK();
     return 0;
+}
+
+// the same convolution over act(x in_coef[0][ci] + in_coef[1][ci]) (in_coef [2][Cin] as ssl4gie_bn_coef_partials
+// writes it; act = ReLU if relu_in; zero padding of the NORMALISED map): Bottleneck bn1 -> relu -> conv2 with no
+// BatchNorm pass of its own
+extern "C" int ssl4gie_conv3x3_direct_fwd_affine(const void* x, const float* in_coef, const void* w2,
+                                                 const float* bias, void* y, float* colstats, int B, int H,
+                                                 int W, int Cin, int Cout, int relu_in, void* stream) {
+    REQUIRE(x && in_coef && w2 && y && ssl4gie_conv3x3_direct_ok(B, H, W, Cin, Cout) && Cin <= 2048);
+    hipStream_t st = (hipStream_t)stream;
+    const Geom g = pick_geom(B, H, W);
+    ProfScope prof(PROF_GEMM_NT, 2.0 * B * H * (double)W * Cout * 9 * Cin, st);
+#define DC_ARGS g, x, w2, bias, nullptr, y, colstats, B, H, W, Cin, Cout, relu_in, st, in_coef
+    if (Cout > 32) {
+        if (g.id == 0) return launch_direct<2, G32, true>(DC_ARGS);
+        if (g.id == 1) return launch_direct<2, G16, true>(DC_ARGS);
+        return launch_direct<2, G8, true>(DC_ARGS);
+    }
+    if (g.id == 0) return launch_direct<1, G32, true>(DC_ARGS);
+    if (g.id == 1) return launch_direct<1, G16, true>(DC_ARGS);
+    return launch_direct<1, G8, true>(DC_ARGS);
+#undef DC_ARGS
 }
 
 extern "C" int ssl4gie_conv3x3_direct_fwd(const void* x, const void* w2, const float* bias,
@@ -704,27 +780,45 @@ extern "C" size_t ssl4gie_conv3x3_direct_wgrad_workspace_bytes(int B, int H, int
     return (size_t)wgrad_grid(pick_geom(B, H, W), Cin, Cout, &ns, &nc, &per) * (32 * 9 * 64 + 32) * sizeof(float);
 }
 
-template <typename G>
+template <typename G, bool AFF = false>
 static int launch_wgrad(const Geom& g, int grid, const void* dy, const void* x, float* part, float* part_b,
                         int B, int H, int W, int Cin, int Cout, int relu_in, int ns, int nc,
-                        hipStream_t st) {
-    auto k = conv3x3_wgrad_direct_kernel<G>;
-    const int lds = G::NH * 128 + WG_DY_BYTES;
+                        hipStream_t st, const float* in_coef = nullptr) {
+    auto k = conv3x3_wgrad_direct_kernel<G, AFF>;
+    const int lds = G::NH * 128 + WG_DY_BYTES + (AFF ? 128 * (int)sizeof(float) : 0);
     static bool attr = false;
     if (!attr) {
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(DC_THREADS), lds, st, (const bf16_t*)dy, (const bf16_t*)x, part,
-                       part_b, B, H, W, Cin, Cout, relu_in, g.tiles_x, g.tiles_y, g.tiles, ns, nc);
+                       part_b, B, H, W, Cin, Cout, relu_in, g.tiles_x, g.tiles_y, g.tiles, ns, nc, in_coef);
     LAUNCH_CHECK();
     return 0;
 }
 
+static int wgrad_impl(const void* dy, const void* x, const float* in_coef, float* dw2, float* dbias,
+                      void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
+                      int relu_in, int accumulate, void* stream);
 extern "C" int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float* dw2, float* dbias,
                                             void* workspace, size_t workspace_bytes, int B, int H,
                                             int W, int Cin, int Cout, int relu_in, int accumulate,
                                             void* stream) {
+    return wgrad_impl(dy, x, nullptr, dw2, dbias, workspace, workspace_bytes, B, H, W, Cin, Cout, relu_in,
+                      accumulate, stream);
+}
+// weight gradient against the operand of ssl4gie_conv3x3_direct_fwd_affine: act(x in_coef[0] + in_coef[1])
+extern "C" int ssl4gie_conv3x3_direct_wgrad_affine(const void* dy, const void* x, const float* in_coef,
+                                                   float* dw2, float* dbias, void* workspace,
+                                                   size_t workspace_bytes, int B, int H, int W, int Cin,
+                                                   int Cout, int relu_in, int accumulate, void* stream) {
+    REQUIRE(in_coef);
+    return wgrad_impl(dy, x, in_coef, dw2, dbias, workspace, workspace_bytes, B, H, W, Cin, Cout, relu_in,
+                      accumulate, stream);
+}
+static int wgrad_impl(const void* dy, const void* x, const float* in_coef, float* dw2, float* dbias,
+                      void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
+                      int relu_in, int accumulate, void* stream) {
     REQUIRE(dy && x && dw2 && workspace && ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, Cout));
     REQUIRE(workspace_bytes >= ssl4gie_conv3x3_direct_wgrad_workspace_bytes(B, H, W, Cin, Cout));
     hipStream_t st = (hipStream_t)stream;
@@ -735,8 +829,12 @@ extern "C" int ssl4gie_conv3x3_direct_wgrad(const void* dy, const void* x, float
     {
         ProfScope prof(PROF_GEMM_TN, 2.0 * B * H * (double)W * Cout * 9 * Cin, st);
         int rc;
-#define WG_ARGS g, grid, dy, x, (float*)workspace, part_b, B, H, W, Cin, Cout, relu_in, ns, nc, st
-        if (g.id == 0) rc = launch_wgrad<G32>(WG_ARGS);
+#define WG_ARGS g, grid, dy, x, (float*)workspace, part_b, B, H, W, Cin, Cout, relu_in, ns, nc, st, in_coef
+        if (in_coef) {
+            if (g.id == 0) rc = launch_wgrad<G32, true>(WG_ARGS);
+            else if (g.id == 1) rc = launch_wgrad<G16, true>(WG_ARGS);
+            else rc = launch_wgrad<G8, true>(WG_ARGS);
+        } else if (g.id == 0) rc = launch_wgrad<G32>(WG_ARGS);
         else if (g.id == 1) rc = launch_wgrad<G16>(WG_ARGS);
         else rc = launch_wgrad<G8>(WG_ARGS);
 #undef WG_ARGS

@@ -673,11 +673,13 @@ def conv3x3_direct_ok(x, n_out):
         bool(_lib.load().ssl4gie_conv3x3_direct_ok(B, H, W, Cin, n_out))
 
 
-def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None, colstats=False):
+def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None, colstats=False, in_coef=None):
     """stride-1 3x3 convolution of the bf16 map x [B,H,W,Cin] with w2 [Cout, 9 Cin] on the direct
     kernel; semantics of conv3x3_fwd (bias and relu_mask may be combined with relu here).
-    colstats: also return the BatchNorm partial statistics [tiles, 2, Cout] of y."""
-    _dev(x, w2, bias, relu_mask)
+    colstats: also return the BatchNorm partial statistics [tiles, 2, Cout] of y.
+    in_coef [2, Cin] (ops.bn_coef_partials): the operand is act(x in_coef[0] + in_coef[1]) — a BatchNorm (+ ReLU)
+    applied on the way in, zero padding after it (ssl4gie_conv3x3_direct_fwd_affine)."""
+    _dev(x, w2, bias, relu_mask, in_coef)
     B, H, W, Cin = _nhwc(x)
     Cout, K = w2.shape
     assert K == 9 * Cin and w2.dtype == x.dtype == torch.bfloat16 and w2.is_contiguous() and x.is_contiguous()
@@ -692,6 +694,13 @@ def conv3x3_direct_fwd(x, w2, bias=None, relu=False, relu_mask=None, colstats=Fa
     if colstats:
         assert relu_mask is None
         stats = torch.empty(L.ssl4gie_conv3x3_direct_tiles(B, H, W), 2, Cout, dtype=torch.float32, device=x.device)
+    if in_coef is not None:
+        _f32(in_coef)
+        assert relu_mask is None and in_coef.shape == (2, Cin) and in_coef.is_contiguous()
+        _lib.check(L.ssl4gie_conv3x3_direct_fwd_affine(ptr(x), ptr(in_coef), ptr(w2), ptr(bias), ptr(y), ptr(stats),
+                                                       B, H, W, Cin, Cout, int(relu), stream()),
+                   "conv3x3_direct_fwd_affine")
+        return (y, stats) if colstats else y
     _lib.check(L.ssl4gie_conv3x3_direct_fwd(ptr(x), ptr(w2), ptr(bias), ptr(relu_mask), ptr(y), ptr(stats),
                                             B, H, W, Cin, Cout, int(relu), stream()), "conv3x3_direct_fwd")
     return (y, stats) if colstats else y
@@ -705,10 +714,11 @@ def conv3x3_direct_wgrad_ok(x, n_out):
     return n_out <= 128 and bool(_lib.load().ssl4gie_conv3x3_direct_wgrad_ok(B, H, W, Cin, n_out))
 
 
-def conv3x3_direct_wgrad(dy, x, relu=False, bias_out=None):
+def conv3x3_direct_wgrad(dy, x, relu=False, bias_out=None, in_coef=None):
     """dW2 [Cout, 9 Cin] fp32 of the direct convolution: dy [B,H,W,Cout] (or [B*H*W, Cout], Cout % 32 == 0),
-    x [B,H,W,Cin]; with `bias_out` [Cout] fp32 the bias gradient is produced by the same kernel"""
-    _dev(dy, x, bias_out)
+    x [B,H,W,Cin]; with `bias_out` [Cout] fp32 the bias gradient is produced by the same kernel;
+    in_coef: as conv3x3_direct_fwd (the operand of the forward is rebuilt on the way in)"""
+    _dev(dy, x, bias_out, in_coef)
     if bias_out is not None:
         assert bias_out.dtype == torch.float32 and bias_out.numel() == dy.shape[-1]
     B, H, W, Cin = _nhwc(x)
@@ -719,6 +729,13 @@ def conv3x3_direct_wgrad(dy, x, relu=False, bias_out=None):
     assert nbytes > 0, "conv3x3_direct_wgrad: unsupported geometry"
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     out = torch.empty(Cout, 9 * Cin, dtype=torch.float32, device=x.device)
+    if in_coef is not None:
+        _f32(in_coef)
+        assert in_coef.shape == (2, Cin) and in_coef.is_contiguous()
+        _lib.check(lib.ssl4gie_conv3x3_direct_wgrad_affine(ptr(dy), ptr(x), ptr(in_coef), ptr(out), ptr(bias_out), ptr(ws),
+                                                           nbytes, B, H, W, Cin, Cout, int(relu), 0, stream()),
+                   "conv3x3_direct_wgrad_affine")
+        return out
     _lib.check(lib.ssl4gie_conv3x3_direct_wgrad(ptr(dy), ptr(x), ptr(out), ptr(bias_out), ptr(ws), nbytes, B, H, W, Cin,
                                                 Cout, int(relu), 0, stream()), "conv3x3_direct_wgrad")
     return out

@@ -398,6 +398,93 @@ def bn_relu_maxpool_ok(x, bn, stats):
 _STEM_POOL_FUSED = __import__("os").environ.get("SSL4GIE_STEM_POOL_FUSED", "1") != "0"
 
 
+class BnReluConv3x3Fn(torch.autograd.Function):
+    """torchvision Bottleneck's bn1 -> relu -> conv2 (3x3, stride 1, no bias) with the BatchNorm applied inside the
+    direct convolution kernels: the statistics come from conv1's epilogue partials, the forward and the weight
+    gradient normalise (+ ReLU) their halo between its global load and its LDS write, the normalised map is never
+    written; the data gradient of conv2 goes through BatchNorm + ReLU backward with the mask rebuilt from the
+    BatchNorm input (ops.bn_bwd_xmask).  Values equal BatchNormFn + Conv3x3Fn bit for bit.
+    Returns (y, statistics of y or None)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, in_stats, weight, sink: GradSink, lp: LPCache, want_stats):
+        from .dpt_engine import _derived
+        B, H, W, Cin = x.shape
+        dt = x.dtype
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        coef, mean, rstd = ops.bn_coef_partials(in_stats, B * H * W, gamma.detach() if gamma is not None else None,
+                                                beta.detach() if beta is not None else None, bn.running_mean,
+                                                bn.running_var, mom, bn.eps)
+        if bn.num_batches_tracked is not None:
+            _count_batch(bn)
+        w2 = _derived(lp, weight, f"c3:{9 * Cin}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 0, 9 * Cin))
+        x = x.contiguous()
+        r = ops.conv3x3_direct_fwd(x, w2, None, True, colstats=want_stats, in_coef=coef)
+        y, stats = r if want_stats else (r, None)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, coef, weight)
+        ctx.cfg = (sink, lp)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        if dy is None:
+            return (None,) * 9
+        from .dpt_engine import _derived, _write_grad
+        x, gamma, beta, mean, rstd, coef, weight = ctx.saved_tensors
+        sink, lp = ctx.cfg
+        B, H, W, Cin = x.shape
+        Cout = weight.shape[0]
+        dt = x.dtype
+        dy = dy.contiguous()
+        (tw, tg, tb), acc, rets = sink.plan([weight, gamma, beta])
+        if tw is not None:  # dW against the normalised operand, rebuilt on the way in
+            dw2 = ops.conv3x3_direct_wgrad(dy.view(-1, Cout), x, True, in_coef=coef)
+            if tw.is_contiguous():
+                ops.conv3x3_wgrad_unpack(dw2, tw, acc)
+            else:
+                _write_grad(tw, dw2.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), acc)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wdd = _derived(lp, weight, "c3dd", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1))
+            dz = ops.conv3x3_direct_fwd(dy.view(B, H, W, Cout), wdd, None)   # gradient at the ReLU's output
+            dx = ops.bn_bwd_xmask(dz.view(-1, Cin), x.view(-1, Cin), gamma.detach() if gamma is not None else None,
+                                  beta.detach() if beta is not None else None, mean, rstd, tg, tb, acc).view(B, H, W, Cin)
+        return dx, rets[1], rets[2], None, None, rets[0], None, None, None
+
+
+def bn_relu_conv3x3_ok(x, bn, in_stats, conv, need_grad):
+    """whether BnReluConv3x3Fn applies: bf16 map on the direct kernels (forward, data gradient and — when a
+    backward pass will run — weight gradient), stride 1, no bias, training-mode statistics from the producing
+    GEMM's partials, one process (SyncBatchNorm exchanges between statistics and apply)"""
+    from .dpt_engine import _DIRECT
+    if not (_BN_CONV_FUSED and _DIRECT and in_stats is not None and conv.bias is None and conv.stride[0] == 1):
+        return False
+    if not (bn.training or bn.running_mean is None) or _sync_group(bn)[0]:
+        return False
+    Cout, Cin = conv.weight.shape[:2]
+    # Cout <= 128 (layer1 / layer2): a workgroup of the direct kernel owns 64 couts and stages the whole halo, so
+    # Cout / 64 workgroups would each normalise the same halo again — measured at 256 / 512 couts the kernels lose
+    # more (+20 us per launch) than the BatchNorm pass costs (profiles/r04at)
+    if x.dtype != torch.bfloat16 or Cin % 64 != 0 or Cout > 128 or not ops.conv3x3_direct_ok(x.contiguous(), Cout):
+        return False
+    if need_grad:
+        B, H, W, _ = x.shape
+        dy_like = torch.empty((B, H, W, Cout), dtype=x.dtype, device="meta")  # shape / dtype only
+        return ops.conv3x3_direct_wgrad_ok(x.contiguous(), Cout) and ops.conv3x3_direct_ok(dy_like, Cin)
+    return True
+
+
+# SSL4GIE_BN_CONV_FUSED=1 (opt-in): bn1 / relu applied inside the Bottleneck's 3x3 convolution.  Correct (bit-identical,
+# tests/test_gpu_resnet.py) and measured NULL on the MoCo-R50 step (62.02 vs 61.96 ms, profiles/r04av): the
+# BatchNorm pass it removes is pure HBM streaming (19 us per launch on these narrow maps), while the normalisation
+# inside the halo staging is VALU work serialised with the MFMA phases of a kernel that is LDS- / issue-bound
+# (+11 .. +21 us per launch, forward and weight gradient) — so the default stays the separate pass.
+_BN_CONV_FUSED = __import__("os").environ.get("SSL4GIE_BN_CONV_FUSED", "0") == "1"
+
+
 class AvgPoolFn(torch.autograd.Function):
     """AdaptiveAvgPool2d(1) + flatten -> fp32 [B, C]"""
 

@@ -130,6 +130,52 @@ def test_stem_bn_relu_maxpool_in_one_pass_equals_the_three_kernels(dtype):
     assert outs[0][0].shape == (B, 9, 10, C)
 
 
+@pytest.mark.parametrize("B,H,W,C,grad", [(2, 24, 40, 64, True), (3, 28, 28, 128, True), (5, 14, 14, 256, False),
+                                           (6, 7, 7, 512, False), (1, 9, 33, 64, True)])
+def test_bn_relu_inside_the_direct_convolution_equals_the_separate_pass(B, H, W, C, grad):
+    """BnReluConv3x3Fn (bn1 -> relu applied in the 3x3 direct kernels' halo staging, forward and weight gradient;
+    mask-from-x BatchNorm backward) against BatchNormFn + Conv3x3Fn: output, its BatchNorm statistics, input
+    gradient, dW, dgamma, dbeta, running statistics — bit-identical; padding stays zero AFTER the normalisation
+    (maps with clipped tiles, all three tile geometries)"""
+    from ssl4gie_amd.dpt_engine import Conv3x3Fn
+    from ssl4gie_amd.engine import GradSink, LPCache
+    from ssl4gie_amd import resnet_engine
+    from ssl4gie_amd.resnet_engine import BatchNormFn, BnReluConv3x3Fn, bn_relu_conv3x3_ok
+    resnet_engine._BN_CONV_FUSED = True   # opt-in path (SSL4GIE_BN_CONV_FUSED=1): measured null, kept correct
+    g = G(90 + C)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.3 + 0.4).to(BF).to(DEV)
+    x2 = x.view(-1, C).float()
+    xp = torch.cat([x2, x2.new_zeros((-x2.shape[0]) % 128, C)]).view(-1, 128, C)
+    st = torch.stack([xp.sum(1), (xp * xp).sum(1)], 1).contiguous()
+    conv = torch.nn.Conv2d(C, C, 3, 1, 1, bias=False).to(DEV)
+    outs = []
+    for fused in (False, True):
+        bn = torch.nn.BatchNorm2d(C).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_((1 + 0.3 * torch.randn(C, generator=G(91))).to(DEV))
+            bn.bias.copy_((0.3 * torch.randn(C, generator=G(92))).to(DEV))
+        conv.weight.grad = None
+        lp = LPCache()
+        xi = x.clone().requires_grad_(grad)
+        with torch.set_grad_enabled(grad):
+            if fused:
+                assert bn_relu_conv3x3_ok(xi, bn, st, conv, grad) == (C <= 128)   # wider layers keep the separate pass
+                y, ys = BnReluConv3x3Fn.apply(xi, bn.weight, bn.bias, bn, st, conv.weight, GradSink(None), lp, True)
+            else:
+                z = BatchNormFn.apply(xi, bn.weight, bn.bias, None, bn, True, GradSink(None), st)
+                y, ys = Conv3x3Fn.apply(z, conv.weight, None, 1, False, GradSink(None), lp, True)
+        res = [y.detach(), ys, bn.running_mean.clone(), bn.running_var.clone()]
+        if grad:
+            y.backward(torch.randn(y.shape, generator=G(93)).to(BF).to(DEV))
+            res += [xi.grad, conv.weight.grad.clone(), bn.weight.grad, bn.bias.grad]
+        outs.append(res)
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), i
+    # the normalised map's zero padding: a border output differs from what padding the RAW map would give
+    assert float(outs[0][0].float().abs().sum()) > 0
+    resnet_engine._BN_CONV_FUSED = False
+
+
 def test_maxpool_avgpool_subsample():
     from ssl4gie_amd.resnet_engine import AvgPoolFn, MaxPoolFn, Subsample2Fn
     x = torch.relu(torch.randn(2, 16, 12, 10, generator=G(6)))  # ReLU output: many tied zeros
