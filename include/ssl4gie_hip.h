@@ -20,7 +20,7 @@
  *     ssl4gie_bn_combine_stats and ssl4gie_debug_nt256_stamps existed — additions only; 4: before
  *     ssl4gie_gemm_desc gained `scale` / `relu` (appended; SSL4GIE_EPI_AFFINE_AUX_RELU and the
  *     statistics-only product with C == NULL) and ssl4gie_bn_bwd_xmask / ssl4gie_bn_coef_partials / ssl4gie_bn_maxpool3x3s2_fwd /
- *     ssl4gie_conv3x3_direct_{fwd,wgrad}_affine existed);
+ *     ssl4gie_conv3x3_direct_{fwd,wgrad}_affine / ssl4gie_bn_fwd_partials_bits / ssl4gie_bn_bwd_bits existed);
  *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
  *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
  */
@@ -465,6 +465,19 @@ int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, const float* ga
 int ssl4gie_bn_bwd_xmask(const void* dy, const void* x, const float* gamma, const float* beta,
                          const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                          int accumulate, float* workspace, int dtype, long long rows, int C, void* stream);
+/* The ReLU mask of a BatchNorm (+ residual) + ReLU as a bit map instead of the ReLU output (bf16 maps): the forward
+ * writes bit j of relu_bits[i] = (y[8 i + j] > 0) beside y (rows * C / 8 bytes), the backward's reduction pass reads
+ * that byte stream instead of y — 1/16 of the bytes — and writes the masked gradient `dres` (required), which its
+ * apply pass reads.  bn3 of a torchvision Bottleneck (its mask depends on the residual input too, so it cannot be
+ * rebuilt from the BatchNorm input as ssl4gie_bn_bwd_xmask does).  Results equal ssl4gie_bn_bwd exactly. */
+int ssl4gie_bn_fwd_partials_bits(const void* x, const float* partial, int parts, const float* gamma,
+                                 const float* beta, const void* res, void* y, unsigned char* relu_bits,
+                                 float* mean, float* rstd, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* workspace, int dtype, long long rows, int C,
+                                 void* stream);
+int ssl4gie_bn_bwd_bits(const void* dy, const unsigned char* relu_bits, const void* x, const float* gamma,
+                        const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                        int accumulate, float* workspace, int dtype, long long rows, int C, void* stream);
 /* SyncBatchNorm (convert_sync_batchnorm: Depth_estimation/train_depth.py:225,
  * Models/moco_v3/main_moco.py:196) = the same kernels with the exchange step between them:
  *   forward : ssl4gie_bn_stats (LOCAL mean / biased var) -> caller combines over ranks ->

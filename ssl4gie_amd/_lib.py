@@ -129,6 +129,9 @@ PROTOTYPES = {
     "ssl4gie_bn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_stats": (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
+    "ssl4gie_bn_fwd_partials_bits": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, i32, i64,
+                                           i32, vp]),
+    "ssl4gie_bn_bwd_bits": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_xmask": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_reduce": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, vp, i32, i64, i32, vp]),

@@ -332,11 +332,12 @@ __global__ __launch_bounds__(256) void bn_bwd_tail_kernel(
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s : s;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + q : q;
 }
-// y = act(x coef[c] + coef[C + c] (+ res))
+// y = act(x coef[c] + coef[C + c] (+ res));  bits (optional, bf16 only: 8 elements per thread = one byte):
+// bit j of bits[idx / 8] = (y[idx + j] > 0) — the ReLU mask the backward needs, at 1/16 of y's bytes
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef,
                                 const T* __restrict__ res, T* __restrict__ y, int relu, int C,
-                                long long total) {
+                                long long total, unsigned char* __restrict__ bits) {
     constexpr int V = V16<T>::N;
     const long long idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (idx >= total) return;
@@ -355,14 +356,26 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
         if (res) v += r[j];
         f[j] = (relu && v < 0.f) ? 0.f : v;
     }
-    *(typename V16<T>::raw*)(y + idx) = pk<T>(f);
+    const typename V16<T>::raw out = pk<T>(f);
+    *(typename V16<T>::raw*)(y + idx) = out;
+    if constexpr (V == 8) {
+        if (bits) {  // of the ROUNDED outputs: what `y > 0` reads back
+            float r2[V];
+            un<T>(out, r2);
+            unsigned m = 0;
+#pragma unroll
+            for (int j = 0; j < V; ++j) m |= (r2[j] > 0.f ? 1u : 0u) << j;
+            bits[idx >> 3] = (unsigned char)m;
+        }
+    }
 }
 // g = relu ? (y > 0 ? dy : 0) : dy;  partial[blk][0][c] = sum g, [1][c] = sum g * xhat; when the block
 // had a residual input its gradient is g itself (dres, optional).  Lane mapping as bn_stats_kernel,
 // two rows (x 2-3 streams) in flight per lane.
 // XMASK (BatchNorm + ReLU without a residual input): the mask is rebuilt as x a + b > 0 from the forward's own
 // coefficients instead of read from the ReLU output — two streams instead of three.
-template <typename T, bool XMASK>
+// XMASK == 2 (BITS): the mask comes from the forward's bit map (`y` points at it): one byte per 8 elements.
+template <typename T, int XMASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dres,
@@ -381,18 +394,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         [[maybe_unused]] float ma[V], mb[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) { mu[j] = mean[m.c + j]; rs[j] = rstd[m.c + j]; }
-        if constexpr (XMASK) {
+        if constexpr (XMASK == 1) {
 #pragma unroll
             for (int j = 0; j < V; ++j)
                 bn_affine(gamma ? gamma[m.c + j] : 1.f, beta ? beta[m.c + j] : 0.f, mu[j], rs[j], ma[j], mb[j]);
         }
+        [[maybe_unused]] const unsigned char* bits = (const unsigned char*)y;
         auto acc = [&](const raw_t& gv, const raw_t& yv, const raw_t& xv, size_t o) {
             float g[V], xx[V];
             un<T>(gv, g);
             un<T>(xv, xx);
-            if constexpr (XMASK) {
+            if constexpr (XMASK == 1) {
 #pragma unroll
                 for (int j = 0; j < V; ++j) g[j] = xx[j] * ma[j] + mb[j] > 0.f ? g[j] : 0.f;
+            } else if constexpr (XMASK == 2) {
+                const unsigned mk = (unsigned)yv[0];  // the byte, carried in the first word of `yv`
+#pragma unroll
+                for (int j = 0; j < V; ++j) g[j] = ((mk >> j) & 1u) ? g[j] : 0.f;
             } else if (relu) {
                 float yy[V];
                 un<T>(yv, yy);
@@ -409,6 +427,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         const long long step = (long long)gridDim.y * 4 * m.rpw;
         long long r = ((long long)blockIdx.y * 4 + wave) * m.rpw + m.rsub;
         constexpr int NR = XMASK ? 4 : 2;  // rows in flight per lane: ~8 16-B loads outstanding either way
+        auto mask_of = [&](size_t o) -> raw_t {  // XMASK == 2: this row's byte of the bit map, in word 0
+            raw_t r = {};
+            if constexpr (XMASK == 2 && V == 8) r[0] = bits[o >> 3];
+            return r;
+        };
         for (; r + (NR - 1) * step < rows; r += NR * step) {
             size_t o[NR];
             raw_t gv[NR], xv[NR], yv[NR];
@@ -418,6 +441,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                 gv[i] = *(const raw_t*)(dy + o[i]);
                 xv[i] = *(const raw_t*)(x + o[i]);
                 yv[i] = gv[i];
+                if (XMASK == 2) yv[i] = mask_of(o[i]);
                 if (!XMASK && relu) yv[i] = *(const raw_t*)(y + o[i]);
             }
 #pragma unroll
@@ -427,6 +451,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             const size_t o0 = (size_t)r * C + m.c;
             const raw_t g0 = *(const raw_t*)(dy + o0), x0 = *(const raw_t*)(x + o0);
             raw_t y0 = g0;
+            if (XMASK == 2) y0 = mask_of(o0);
             if (!XMASK && relu) y0 = *(const raw_t*)(y + o0);
             acc(g0, y0, x0, o0);
         }
@@ -763,7 +788,7 @@ extern "C" int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* be
                            gamma, beta, coef, C);
         LAUNCH_CHECK();
         RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, coef, (const T*)res, (T*)y,
-                  relu, C, total);
+                  relu, C, total, (unsigned char*)nullptr);
         return 0;
     }
     const int parts = bn_parts(rows, C);
@@ -783,7 +808,7 @@ extern "C" int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* be
                        momentum, C);
     LAUNCH_CHECK();
     RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, coef, (const T*)res, (T*)y, relu,
-              C, total);
+              C, total, (unsigned char*)nullptr);
     return 0;
 }
 // backward: dgamma / dbeta (overwritten or accumulated), dx, and (optional) the residual gradient.
@@ -791,18 +816,21 @@ extern "C" int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* be
 // coefficients (gamma, beta, mean, rstd) instead of read from the ReLU output: 5 instead of 7 tensor passes.
 static int bn_bwd_impl(const void* dy, const void* y, const void* x, const float* gamma, const float* beta,
                        const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
-                       float* dbeta, int accumulate, int relu, bool xmask, float* workspace, int dtype,
-                       long long rows, int C, hipStream_t st) {
+                       float* dbeta, int accumulate, int relu, int xmask /* 0: mask from y, 1: from x, 2: y is the forward's bit map (bf16) */,
+                       float* workspace, int dtype, long long rows, int C, hipStream_t st) {
     const int parts = bn_parts(rows, C);
     dim3 grid(bn_strips(C, dtype), parts), block(256);
     float* coef = workspace;
     float* partial = workspace + 3 * (size_t)C;
-    float* mcoef = xmask ? partial + (size_t)parts * 2 * C : nullptr;  // the forward's `sums` slot: free here
+    float* mcoef = xmask == 1 ? partial + (size_t)parts * 2 * C : nullptr;  // the forward's `sums` slot: free here
 #define BN_REDUCE(T_, XM_)                                                                              \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, XM_>), grid, block, 0, st, (const T_*)dy, (const T_*)y, \
                        (const T_*)x, mean, rstd, (T_*)dres, partial, relu, rows, C, gamma, beta)
-    if (dtype == SSL4GIE_BF16) { if (xmask) BN_REDUCE(bf16_t, true); else BN_REDUCE(bf16_t, false); }
-    else { if (xmask) BN_REDUCE(float, true); else BN_REDUCE(float, false); }
+    if (dtype == SSL4GIE_BF16) {
+        if (xmask == 1) BN_REDUCE(bf16_t, 1); else if (xmask == 2) BN_REDUCE(bf16_t, 2); else BN_REDUCE(bf16_t, 0);
+    } else {
+        if (xmask == 1) BN_REDUCE(float, 1); else BN_REDUCE(float, 0);
+    }
 #undef BN_REDUCE
     LAUNCH_CHECK();
     // dbeta = sum g, dgamma = sum g xhat, and the dx coefficients, in one launch (after a 64-way
@@ -832,7 +860,19 @@ extern "C" int ssl4gie_bn_bwd(const void* dy, const void* y, const void* x, cons
                               float* workspace, int dtype, long long rows, int C, void* stream) {
     REQUIRE(dy && x && mean && rstd && dx && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
     REQUIRE(!relu || y);
-    return bn_bwd_impl(dy, y, x, gamma, nullptr, mean, rstd, dx, dres, dgamma, dbeta, accumulate, relu, false,
+    return bn_bwd_impl(dy, y, x, gamma, nullptr, mean, rstd, dx, dres, dgamma, dbeta, accumulate, relu, 0,
+                       workspace, dtype, rows, C, (hipStream_t)stream);
+}
+// BatchNorm (+ residual) + ReLU backward with the ReLU mask from the bit map ssl4gie_bn_fwd_partials_bits wrote
+// (one byte per 8 elements) instead of the ReLU output: the reduction pass streams dy, x and 1/16 of a tensor
+// (bf16 maps only; `dres` is required: the apply pass reads the masked gradient the reduction wrote)
+extern "C" int ssl4gie_bn_bwd_bits(const void* dy, const unsigned char* relu_bits, const void* x,
+                                   const float* gamma, const float* mean, const float* rstd, void* dx,
+                                   void* dres, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                                   int dtype, long long rows, int C, void* stream) {
+    REQUIRE(dy && relu_bits && x && mean && rstd && dx && dres && workspace && dtype == SSL4GIE_BF16 && rows > 0 &&
+            C > 0 && C % 8 == 0);
+    return bn_bwd_impl(dy, relu_bits, x, gamma, nullptr, mean, rstd, dx, dres, dgamma, dbeta, accumulate, 1, 2,
                        workspace, dtype, rows, C, (hipStream_t)stream);
 }
 extern "C" int ssl4gie_bn_bwd_xmask(const void* dy, const void* x, const float* gamma, const float* beta,
@@ -840,7 +880,7 @@ extern "C" int ssl4gie_bn_bwd_xmask(const void* dy, const void* x, const float* 
                                     float* dbeta, int accumulate, float* workspace, int dtype,
                                     long long rows, int C, void* stream) {
     REQUIRE(dy && x && mean && rstd && dx && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
-    return bn_bwd_impl(dy, nullptr, x, gamma, beta, mean, rstd, dx, nullptr, dgamma, dbeta, accumulate, 1, true,
+    return bn_bwd_impl(dy, nullptr, x, gamma, beta, mean, rstd, dx, nullptr, dgamma, dbeta, accumulate, 1, 1,
                        workspace, dtype, rows, C, (hipStream_t)stream);
 }
 extern "C" int ssl4gie_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* arg, int dtype, int B,
@@ -964,11 +1004,34 @@ extern "C" int ssl4gie_bn_stats(const void* x, float* mean, float* var, float* w
 }
 // training-mode forward with the statistics taken from `partial` [parts][2][C] instead of a pass
 // over x; everything else as ssl4gie_bn_fwd.  workspace: ssl4gie_bn_workspace_bytes(rows, C).
+static int bn_fwd_partials_impl(const void* x, const float* partial, int parts, const float* gamma,
+                                const float* beta, const void* res, void* y, float* mean,
+                                float* rstd, float* running_mean, float* running_var,
+                                float momentum, float eps, int relu, float* workspace, int dtype,
+                                long long rows, int C, void* stream, unsigned char* relu_bits);
 extern "C" int ssl4gie_bn_fwd_partials(const void* x, const float* partial, int parts, const float* gamma,
                                        const float* beta, const void* res, void* y, float* mean,
                                        float* rstd, float* running_mean, float* running_var,
                                        float momentum, float eps, int relu, float* workspace, int dtype,
                                        long long rows, int C, void* stream) {
+    return bn_fwd_partials_impl(x, partial, parts, gamma, beta, res, y, mean, rstd, running_mean, running_var,
+                                momentum, eps, relu, workspace, dtype, rows, C, stream, nullptr);
+}
+// ... and relu_bits [rows * C / 8] bytes: bit j of byte i = (y[8 i + j] > 0), for ssl4gie_bn_bwd_bits (bf16 maps)
+extern "C" int ssl4gie_bn_fwd_partials_bits(const void* x, const float* partial, int parts, const float* gamma,
+                                            const float* beta, const void* res, void* y,
+                                            unsigned char* relu_bits, float* mean, float* rstd,
+                                            float* running_mean, float* running_var, float momentum, float eps,
+                                            float* workspace, int dtype, long long rows, int C, void* stream) {
+    REQUIRE(relu_bits && dtype == SSL4GIE_BF16);
+    return bn_fwd_partials_impl(x, partial, parts, gamma, beta, res, y, mean, rstd, running_mean, running_var,
+                                momentum, eps, 1, workspace, dtype, rows, C, stream, relu_bits);
+}
+static int bn_fwd_partials_impl(const void* x, const float* partial, int parts, const float* gamma,
+                                const float* beta, const void* res, void* y, float* mean,
+                                float* rstd, float* running_mean, float* running_var,
+                                float momentum, float eps, int relu, float* workspace, int dtype,
+                                long long rows, int C, void* stream, unsigned char* relu_bits) {
     REQUIRE(x && partial && parts > 0 && y && mean && rstd && workspace && rdt(dtype) && rows > 0 &&
             C > 0 && C % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
@@ -983,7 +1046,7 @@ extern "C" int ssl4gie_bn_fwd_partials(const void* x, const float* partial, int 
     LAUNCH_CHECK();
     const long long total = rows * C;
     RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, coef, (const T*)res, (T*)y, relu,
-              C, total);
+              C, total, relu_bits);
     return 0;
 }
 // the statistics half of ssl4gie_bn_fwd_partials alone: mean / rstd / running statistics and the normalisation
@@ -1035,11 +1098,11 @@ extern "C" int ssl4gie_bn_bwd_reduce(const void* dy, const void* y, const void* 
     dim3 grid(bn_strips(C, dtype), parts), block(256);
     float* partial = workspace + 3 * (size_t)C;
     if (dtype == SSL4GIE_BF16)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)dy,
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 0>), grid, block, 0, st, (const bf16_t*)dy,
                            (const bf16_t*)y, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, partial,
                            relu, rows, C, (const float*)nullptr, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), grid, block, 0, st, (const float*)dy,
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 0>), grid, block, 0, st, (const float*)dy,
                            (const float*)y, (const float*)x, mean, rstd, (float*)dres, partial, relu,
                            rows, C, (const float*)nullptr, (const float*)nullptr);
     LAUNCH_CHECK();

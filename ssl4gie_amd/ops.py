@@ -989,6 +989,40 @@ def bn_bwd(dy2d, y2d, x2d, gamma, mean, rstd, relu, want_dres, dgamma, dbeta, ac
     return dx, dres
 
 
+def bn_fwd_bits(x2d, gamma, beta, res, running_mean, running_var, momentum, eps, partials):
+    """training-mode BatchNorm (+ residual) + ReLU from GEMM-epilogue partials that also writes the ReLU mask as
+    a bit map [rows * C / 8] (bf16): -> (y, bits, mean, rstd) (ssl4gie_bn_fwd_partials_bits)"""
+    _dev(x2d, gamma, beta, res, running_mean, running_var, partials)
+    rows, C = x2d.shape
+    assert x2d.dtype == torch.bfloat16 and partials.dtype == torch.float32 and partials.shape[1:] == (2, C)
+    L = _lib.load()
+    y = torch.empty_like(x2d)
+    bits = torch.empty(rows * C // 8, dtype=torch.uint8, device=x2d.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_fwd_partials_bits(ptr(x2d), ptr(partials), partials.shape[0], ptr(gamma), ptr(beta),
+                                              ptr(res), ptr(y), ptr(bits), ptr(mean), ptr(rstd), ptr(running_mean),
+                                              ptr(running_var), float(momentum), float(eps), ptr(ws),
+                                              code(x2d.dtype), rows, C, stream()), "bn_fwd_partials_bits")
+    return y, bits, mean, rstd
+
+
+def bn_bwd_bits(dy2d, bits, x2d, gamma, mean, rstd, dgamma, dbeta, accumulate):
+    """backward of bn_fwd_bits: -> (dx, dres = the masked gradient) (ssl4gie_bn_bwd_bits)"""
+    _dev(dy2d, bits, x2d, gamma, mean, rstd, dgamma, dbeta)
+    rows, C = x2d.shape
+    assert bits.dtype == torch.uint8 and bits.numel() == rows * C // 8
+    L = _lib.load()
+    dx = torch.empty_like(x2d)
+    dres = torch.empty_like(x2d)
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_bwd_bits(ptr(dy2d), ptr(bits), ptr(x2d), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                     ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), code(x2d.dtype),
+                                     rows, C, stream()), "bn_bwd_bits")
+    return dx, dres
+
+
 def bn_bwd_xmask(dy2d, x2d, gamma, beta, mean, rstd, dgamma, dbeta, accumulate):
     """BatchNorm + ReLU without a residual input: the mask is rebuilt from x and the forward's coefficients, the
     ReLU output is not read (ssl4gie_bn_bwd_xmask)"""

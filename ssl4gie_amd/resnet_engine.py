@@ -259,6 +259,8 @@ def flush_batch_counts(model):
             _flush_one(m)
 
 
+# SSL4GIE_BN_BITS=0: BatchNorm + residual + ReLU backward reads the ReLU output for its mask again (A/B)
+_BN_BITS = __import__("os").environ.get("SSL4GIE_BN_BITS", "1") != "0"
 # SSL4GIE_BN_XMASK=0: read the ReLU output for the mask of residual-free BatchNorm + ReLU layers again (A/B)
 _XMASK = __import__("os").environ.get("SSL4GIE_BN_XMASK", "1") != "0"
 
@@ -284,7 +286,13 @@ class BatchNormFn(torch.autograd.Function):
         b = beta.detach() if beta is not None else None
         sync, group = _sync_group(bn)
         total = None  # SyncBatchNorm: 0-d device tensor, rows over all ranks
-        if training and not sync:
+        bits = None
+        if training and not sync and _BN_BITS and relu and r2 is not None and stats is not None \
+                and x2.dtype == torch.bfloat16 and any(ctx.needs_input_grad):
+            # bn3 of a bottleneck: the backward gets its ReLU mask as a bit map (1/16 of the output's bytes)
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            y, bits, mean, rstd = ops.bn_fwd_bits(x2, g, b, r2, bn.running_mean, bn.running_var, mom, bn.eps, stats)
+        elif training and not sync:
             mom = bn.momentum if bn.momentum is not None else 0.1
             y, mean, rstd = ops.bn_fwd(x2, g, b, r2, bn.running_mean, bn.running_var, mom, bn.eps, relu,
                                        True, partials=stats)
@@ -298,7 +306,7 @@ class BatchNormFn(torch.autograd.Function):
             y, _, _ = ops.bn_fwd(x2, g, b, r2, None, None, 0.0, bn.eps, relu, False, mean, rstd)
         if training and bn.num_batches_tracked is not None:
             _count_batch(bn)
-        ctx.save_for_backward(x2, y if relu else None, gamma, beta, mean, rstd)
+        ctx.save_for_backward(x2, bits if bits is not None else (y if relu else None), gamma, beta, mean, rstd)
         ctx.cfg = (shp, relu, res is not None, sink, training, sync, group, total)
         return y.view(shp)
 
@@ -313,7 +321,9 @@ class BatchNormFn(torch.autograd.Function):
         (tg, tb), acc, rets = sink.plan([gamma, beta])
         dy2 = dy.contiguous().view(-1, C)
         gd = gamma.detach() if gamma is not None else None
-        if not sync and relu and not has_res and _XMASK:
+        if not sync and relu and has_res and y is not None and y.dtype == torch.uint8:
+            dx, dres = ops.bn_bwd_bits(dy2, y, x2, gd, mean, rstd, tg, tb, acc)   # `y` holds the forward's bit map
+        elif not sync and relu and not has_res and _XMASK:
             # the ReLU mask from x and the forward's coefficients: the ReLU output is not read again
             dx, dres = ops.bn_bwd_xmask(dy2, x2, gd, beta.detach() if beta is not None else None, mean, rstd,
                                         tg, tb, acc), None

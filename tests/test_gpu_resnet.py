@@ -176,6 +176,35 @@ def test_bn_relu_inside_the_direct_convolution_equals_the_separate_pass(B, H, W,
     resnet_engine._BN_CONV_FUSED = False
 
 
+@pytest.mark.parametrize("rows,C", [(1531, 64), (4099, 256), (777, 1024)])
+def test_batchnorm_residual_relu_backward_from_the_bit_map(rows, C):
+    """ssl4gie_bn_fwd_partials_bits / ssl4gie_bn_bwd_bits (the ReLU mask of bn3 as one bit per element) against
+    ssl4gie_bn_fwd_partials / ssl4gie_bn_bwd reading the ReLU output: y, dx, dres, dgamma, dbeta bit-identical"""
+    from ssl4gie_amd import ops
+    g = G(rows + C + 1)
+    x = (torch.randn(rows, C, generator=g) * 2 + 1).to(BF).to(DEV)
+    res = torch.randn(rows, C, generator=g).to(BF).to(DEV)
+    gamma = torch.randn(C, generator=g).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    x2 = x.float()
+    xp = torch.cat([x2, x2.new_zeros((-rows) % 128, C)]).view(-1, 128, C)
+    st = torch.stack([xp.sum(1), (xp * xp).sum(1)], 1).contiguous()
+    rm0, rv0 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    y0, mean0, rstd0 = ops.bn_fwd(x, gamma, beta, res, rm0, rv0, 0.1, 1e-5, True, True, partials=st)
+    y1, bits, mean1, rstd1 = ops.bn_fwd_bits(x, gamma, beta, res, rm1, rv1, 0.1, 1e-5, st)
+    assert torch.equal(y0, y1) and torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1) and torch.equal(rm0, rm1)
+    ref_bits = (y0.float() > 0).view(-1, 8).to(torch.int32)
+    ref_bits = (ref_bits << torch.arange(8, device=DEV, dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, ref_bits)
+    dy = torch.randn(rows, C, generator=g).to(BF).to(DEV)
+    dg0, db0 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dg1, db1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dx0, dr0 = ops.bn_bwd(dy, y0, x, gamma, mean0, rstd0, True, True, dg0, db0, False)
+    dx1, dr1 = ops.bn_bwd_bits(dy, bits, x, gamma, mean0, rstd0, dg1, db1, False)
+    assert torch.equal(dx0, dx1) and torch.equal(dr0, dr1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+
+
 def test_maxpool_avgpool_subsample():
     from ssl4gie_amd.resnet_engine import AvgPoolFn, MaxPoolFn, Subsample2Fn
     x = torch.relu(torch.randn(2, 16, 12, 10, generator=G(6)))  # ReLU output: many tied zeros
