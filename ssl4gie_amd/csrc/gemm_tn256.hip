@@ -346,6 +346,44 @@ int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d) {
     return s;
 }
 
+// Predicted HBM bytes of a paired launch with `splits` K-splits (tools/tn_traffic_model.py, checked against the PMC
+// counters: 405 MB per launch predicted, 397 measured): consecutive logical workgroups share an XCD's L2
+// (xcd_remap), so an XCD chunk holding r m-tiles and c n-tiles of one split of one product reads r + c operand
+// slabs; plus the fp32 slabs (GEMM write, reduce read + write).
+static double tn256_pair_traffic(const ssl4gie_gemm_desc* const* ds, int n, int splits, bool m_inner_ok) {
+    int tm[2], tn[2], nt[2], all = 0;
+    for (int i = 0; i < n; ++i) {
+        tm[i] = (ds[i]->M + P_BM - 1) / P_BM; tn[i] = (ds[i]->N + P_BN - 1) / P_BN;
+        if (tm[i] > 64 || tn[i] > 64) return 1e30;  // (bit sets below; no such product in the models)
+        nt[i] = tm[i] * tn[i]; all += nt[i];
+    }
+    const int G = all * splits, q = G / 8, r = G % 8;
+    long long slabs = 0;
+    int lo = 0;
+    for (int x = 0; x < 8; ++x) {  // the 8 contiguous chunks of logical ids xcd_remap deals to the XCDs
+        const int hi = lo + q + (x < r ? 1 : 0);
+        int cur_s = -1, cur_p = -1;
+        unsigned long long rows = 0, cols = 0;
+        for (int lid = lo; lid < hi; ++lid) {
+            const int sidx = lid / all;
+            int t = lid % all, p = 0;
+            while (p < n - 1 && t >= nt[p]) t -= nt[p++];
+            if (sidx != cur_s || p != cur_p) {
+                slabs += __builtin_popcountll(rows) + __builtin_popcountll(cols);
+                rows = cols = 0; cur_s = sidx; cur_p = p;
+            }
+            const bool m_inner = tm[p] < tn[p] && m_inner_ok;
+            const int mt = m_inner ? t % tm[p] : t / tn[p], ntile = m_inner ? t / tm[p] : t % tn[p];
+            rows |= 1ull << mt; cols |= 1ull << ntile;
+        }
+        slabs += __builtin_popcountll(rows) + __builtin_popcountll(cols);
+        lo = hi;
+    }
+    double out = 0;
+    for (int i = 0; i < n; ++i) out += (double)ds[i]->M * ds[i]->N * 4;
+    return (double)slabs * 256 * ((double)ds[0]->K / splits) * 2 + (splits > 1 ? out * (2 * splits + 1) : out);
+}
+
 int ssl4gie_internal_tn256_pair_splits(const ssl4gie_gemm_desc* a, const ssl4gie_gemm_desc* b) {
     const int tiles = ((a->M + P_BM - 1) / P_BM) * ((a->N + P_BN - 1) / P_BN) +
                       ((b->M + P_BM - 1) / P_BM) * ((b->N + P_BN - 1) / P_BN);
@@ -365,6 +403,22 @@ int ssl4gie_internal_tn256_pair_splits(const ssl4gie_gemm_desc* a, const ssl4gie
     if (s > nkt / 8) s = nkt / 8;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
+    // SSL4GIE_TN_ALIGN=1 (A/B): among the split counts that keep 70 .. 110 % of the target's workgroups, the one
+    // with the least predicted HBM traffic (chunks of whole K-splits per XCD read every operand slab once)
+    static int align = -1;
+    if (align < 0) { const char* e = getenv("SSL4GIE_TN_ALIGN"); align = e ? atoi(e) : 0; }
+    if (align) {
+        const ssl4gie_gemm_desc* ds[2] = {a, b};
+        int best = s;
+        double best_t = tn256_pair_traffic(ds, 2, s, true);
+        for (int c = 1; c <= 64 && c <= nkt / 8; ++c) {
+            const int wgs = c * tiles;
+            if (wgs * 10 < target * 7 || wgs * 10 > target * 11) continue;
+            const double t = tn256_pair_traffic(ds, 2, c, true);
+            if (t < best_t * 0.97) { best_t = t; best = c; }
+        }
+        s = best;
+    }
     return s;
 }
 
