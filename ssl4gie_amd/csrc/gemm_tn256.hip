@@ -47,7 +47,9 @@ DEVI bf16x8 q_frag(const char* img, int krow0, int x0, int lane) {
 // ones fragment — 2 extra MFMAs in P0 and in P2 — and writes 2 x 16 sums.
 // CONV: 0 = Bt is a matrix; 1 = Bt is the implicit 3x3 patch matrix of the map at `Bt` (k-row =
 // output pixel, column = (tap, channel); ssl4gie_conv3x3_geom); 2 = with ReLU on the B fragments.
-template <bool COLSUM, int CONV>
+// PARTIAL: the launch has tiles that M x N does not fill (see `mmask` below); a separate instantiation, so that
+// the full-tile kernels keep their register allocation.
+template <bool COLSUM, int CONV, bool PARTIAL = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     const bf16_t* __restrict__ At, long long ldat, const bf16_t* __restrict__ Bt, long long ldbt,
     float* __restrict__ C, long long ldc, float* __restrict__ slabs, int M, int N, int K,
@@ -189,6 +191,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
+    // Partial tiles (the 1x1-convolution weight gradients of ResNet's first stages: dW [64, 256], [128, 512] ...
+    // over hundreds of thousands of pixels — one or two tiles, HBM-streaming): 16-row / 16-column fragment blocks
+    // that lie wholly outside M x N are skipped (wave-uniform masks), so a 64-row product costs a quarter of the
+    // tile's MFMAs instead of all of them and stays HBM-bound.  Full tiles take the unconditional sequence.
+    [[maybe_unused]] unsigned mmask = 0xffu, nmask = 0xfu;
+    if constexpr (PARTIAL) {
+        mmask = nmask = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mmask |= (m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 < M ? 1u : 0u) << i;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nmask |= (n0 + wc * 64 + (i >> 1) * 32 + (i & 1) * 16 < N ? 1u : 0u) << i;
+        mmask = __builtin_amdgcn_readfirstlane(mmask);
+        nmask = __builtin_amdgcn_readfirstlane(nmask);
+    }
     auto mma = [&](auto QMc, auto QNc, bf16x8 (&bb)[2][2]) {
         constexpr int QM = decltype(QMc)::value, QN = decltype(QNc)::value;
         __builtin_amdgcn_s_setprio(1);
@@ -210,14 +226,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
                 else cs(a[3]);
             }
         }
+        if constexpr (!PARTIAL) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[QM * 4 + mi][QN * 2 + ni] =
-                        P_MFMA(bb[ni][ks], a[mi][ks], acc[QM * 4 + mi][QN * 2 + ni]);
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[QM * 4 + mi][QN * 2 + ni] =
+                            P_MFMA(bb[ni][ks], a[mi][ks], acc[QM * 4 + mi][QN * 2 + ni]);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                if (!((mmask >> (QM * 4 + mi)) & 1u)) continue;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (!((nmask >> (QN * 2 + ni)) & 1u)) continue;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        acc[QM * 4 + mi][QN * 2 + ni] =
+                            P_MFMA(bb[ni][ks], a[mi][ks], acc[QM * 4 + mi][QN * 2 + ni]);
+                }
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -342,7 +373,7 @@ int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d) {
     int s = (ssl4gie_internal_compute_cus() + tiles / 2) / tiles;  // one workgroup per CU
     if (s > nkt / 8) s = nkt / 8;       // at least 8 K-tiles per split
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > 256) s = 256;               // (a single-tile product over a long contraction: one split per CU)
     return s;
 }
 
@@ -488,9 +519,10 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, 
         const int rc = ssl4gie_internal_conv_k(d->conv, &ck);
         if (rc) return rc;
     }
-#define Q_LAUNCH(CS_, CONV_)                                                                       \
+#define Q_LAUNCH(CS_, CONV_) do { if (partial) Q_LAUNCH_P(CS_, CONV_, true); else Q_LAUNCH_P(CS_, CONV_, false); } while (0)
+#define Q_LAUNCH_P(CS_, CONV_, PART_)                                                              \
     do {                                                                                           \
-        auto kfn = gemm_bf16_tn256_kernel<CS_, CONV_>;                                             \
+        auto kfn = gemm_bf16_tn256_kernel<CS_, CONV_, PART_>;                                      \
         static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
         if (!attr_set) {                                                                           \
             HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
@@ -503,6 +535,8 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, 
                            colsum_part, ck, sec);                                                  \
     } while (0)
     const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
+    // a lone plain product whose tiles M x N does not fill (ResNet's narrow 1x1 weight gradients)
+    const bool partial = n == 1 && cv == 0 && (d->M % P_BM != 0 || d->N % P_BN != 0);
     if (any_colsum) {
         if (cv == 0) Q_LAUNCH(true, 0);
         else if (cv == 1) Q_LAUNCH(true, 1);
@@ -513,6 +547,7 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, 
         else Q_LAUNCH(false, 2);
     }
 #undef Q_LAUNCH
+#undef Q_LAUNCH_P
     LAUNCH_CHECK();
     return 0;
 }

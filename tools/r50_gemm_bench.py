@@ -36,8 +36,8 @@ def timeit(fn, n=10):
 
 def main():
     _lib.load()
-    print(f"{'case':32s} {'fwd':>8s} | {'fwd+stats':>10s} {'TB/s':>5s} {'TF/s':>5s} | {'stats only':>10s} | {'affine':>8s} {'TB/s':>5s} | {'dgrad':>8s} {'TB/s':>5s}")
-    tot = [0.0] * 4
+    print(f"{'case':32s} {'fwd':>8s} | {'fwd+stats':>10s} {'TB/s':>5s} {'TF/s':>5s} | {'stats only':>10s} | {'affine':>8s} {'TB/s':>5s} | {'dgrad':>8s} {'TB/s':>5s} | {'wgrad':>8s} {'TB/s':>5s}")
+    tot = [0.0] * 5
     for name, T, K, N in CASES:
         x = torch.randn(T, K, device="cuda").bfloat16()
         w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
@@ -51,10 +51,11 @@ def main():
         t1 = timeit(lambda: ops.linear_colstats_only(x, w))
         t2 = timeit(lambda: ops.linear_affine_fwd(x, w, sc, sh, aux, True))
         t3 = timeit(lambda: ops.linear_bwd_data(dy, w, wt))
-        for i, t in enumerate((t0, t1, t2, t3)):
+        t4 = timeit(lambda: ops.linear_bwd_weight(dy, x))
+        for i, t in enumerate((t0, t1, t2, t3, t4)):
             tot[i] += t
         print(f"{name:32s} {tp:8.1f} | {t0:10.1f} {byt / t0 / 1e6:5.2f} {2.0 * T * K * N / t0 / 1e6:5.0f} | {t1:10.1f} | "
-              f"{t2:8.1f} {(byt + 2.0 * T * N) / t2 / 1e6:5.2f} | {t3:8.1f} {byt / t3 / 1e6:5.2f}")
+              f"{t2:8.1f} {(byt + 2.0 * T * N) / t2 / 1e6:5.2f} | {t3:8.1f} {byt / t3 / 1e6:5.2f} | {t4:8.1f} {byt / t4 / 1e6:5.2f}")
     print("sum: " + " ".join(f"{t:.0f}" for t in tot) + " us")
 
 
