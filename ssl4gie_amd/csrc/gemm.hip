@@ -710,6 +710,50 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
     st4(c, s);
 }
 
+// The same reduction for MANY slabs of a small output (the long-contraction weight gradients of ResNet's 1x1
+// convolutions: up to 256 splits of a 64 KiB tile): 64 float4 columns x 4 slab groups per block — group g sums
+// slabs g, g + 4, g + 8, ... in that order, then the four group sums are added in group order (fixed order:
+// deterministic), so four times as many loads are in flight as with one thread per column.
+__global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* __restrict__ slabs,
+                                                               float* __restrict__ C, long long ldc, int M, int N,
+                                                               int splits, float alpha, int accumulate) {
+    __shared__ f32x4 part[3][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i4 = (size_t)blockIdx.x * 64 + c;
+    const size_t total4 = (size_t)M * N / 4;
+    const bool ok = i4 < total4;
+    const size_t idx = i4 * 4, slab = (size_t)M * N;
+    f32x4 s = {0, 0, 0, 0};
+    if (ok)
+        for (int k = g; k < splits; k += 4) s += ld4(slabs + (size_t)k * slab + idx);
+    if (g > 0) part[g - 1][c] = s;
+    __syncthreads();
+    if (g != 0 || !ok) return;
+    s += part[0][c]; s += part[1][c]; s += part[2][c];
+    s *= alpha;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    float* o = C + (size_t)m * ldc + n;
+    if (accumulate) s += ld4(o);
+    st4(o, s);
+}
+// slab reduction of one product: the wide form from 32 slabs on when no column-sum partials ride along
+static int launch_slab_reduce(const float* slabs, float* C, long long ldc, int M, int N, int splits, float alpha,
+                              int accumulate, const float* cs_part, float* cs_out, bool fused_cs, hipStream_t st) {
+    const size_t total4 = (size_t)M * N / 4;
+    if (splits >= 32 && !fused_cs) {
+        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, slabs, C,
+                           ldc, M, N, splits, alpha, accumulate);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    const unsigned c_blocks = (unsigned)((total4 + 255) / 256);
+    const unsigned b_blocks = fused_cs ? (unsigned)((M + 255) / 256) : 0;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(c_blocks + b_blocks), dim3(256), 0, st, slabs, C, ldc, M, N, splits,
+                       alpha, accumulate, cs_part, cs_out, c_blocks);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // =====================================================================================
 // dispatch
 // =====================================================================================
@@ -915,13 +959,9 @@ extern "C" int ssl4gie_gemm(const ssl4gie_gemm_desc* d, void* workspace, size_t 
         }
         const bool fused_cs = p.big && d->colsum_a;
         if (splits > 1) {
-            const size_t total4 = (size_t)d->M * d->N / 4;
-            const unsigned c_blocks = (unsigned)((total4 + 255) / 256);
-            const unsigned b_blocks = fused_cs ? (unsigned)((d->M + 255) / 256) : 0;
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(c_blocks + b_blocks), dim3(256), 0, st,
-                               (const float*)slabs, (float*)d->C, d->ldc, d->M, d->N, splits,
-                               d->alpha, d->accumulate, (const float*)cs_ws, d->colsum_a, c_blocks);
-            LAUNCH_CHECK();
+            const int rc = launch_slab_reduce((const float*)slabs, (float*)d->C, d->ldc, d->M, d->N, splits, d->alpha,
+                                              d->accumulate, (const float*)cs_ws, d->colsum_a, fused_cs, st);
+            if (rc) return rc;
         }
         if (d->colsum_a && !fused_cs)
             return ssl4gie_colsum(d->A, d->dtype_ab, d->colsum_a, d->accumulate, cs_ws, d->K, d->M,
