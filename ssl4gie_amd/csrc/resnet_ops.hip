@@ -266,7 +266,20 @@ DEVI bool bn_sum_partials(const float* __restrict__ partial, int parts, int C, f
     const int c = blockIdx.x * 64 + lane;
     s = 0.f; q = 0.f;
     if (c < C) {
-        for (int p = wave; p < parts; p += 4) {
+        // eight rows' loads in flight, then the adds in row order (the sums are those of the plain loop; a
+        // dependent load per row cost up to 64 L2 round trips in this kernel's one wave per 64 channels)
+        int p = wave;
+        for (; p + 28 < parts; p += 32) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = partial[(size_t)(p + 4 * u) * 2 * C + c];
+                b[u] = partial[(size_t)(p + 4 * u) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += a[u]; q += b[u]; }
+        }
+        for (; p < parts; p += 4) {
             s += partial[(size_t)p * 2 * C + c];
             q += partial[(size_t)p * 2 * C + C + c];
         }
@@ -742,7 +755,18 @@ __global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __re
     const int c = blockIdx.x * 64 + lane, k = blockIdx.y;
     float s = 0.f, q = 0.f;
     if (c < C) {
-        for (int p = k + BN_FOLD * wave; p < parts; p += BN_FOLD * 4) {
+        int p = k + BN_FOLD * wave;  // eight rows' loads in flight, adds in row order (as bn_sum_partials)
+        for (; p + 7 * BN_FOLD * 4 < parts; p += 8 * BN_FOLD * 4) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = pin[(size_t)(p + u * BN_FOLD * 4) * 2 * C + c];
+                b[u] = pin[(size_t)(p + u * BN_FOLD * 4) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += a[u]; q += b[u]; }
+        }
+        for (; p < parts; p += BN_FOLD * 4) {
             s += pin[(size_t)p * 2 * C + c];
             q += pin[(size_t)p * 2 * C + C + c];
         }
