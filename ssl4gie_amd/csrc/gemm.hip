@@ -703,7 +703,13 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
     const size_t idx = i4 * 4;
     const int m = (int)(idx / N), n = (int)(idx % N);
     f32x4 s = ld4(slabs + idx);
-    for (int k = 1; k < splits; ++k) s += ld4(slabs + (size_t)k * M * N + idx);
+    int k = 1;
+    for (; k + 3 < splits; k += 4) {  // four slabs' loads in flight, added in slab order
+        const f32x4 a = ld4(slabs + (size_t)k * M * N + idx), b = ld4(slabs + (size_t)(k + 1) * M * N + idx);
+        const f32x4 c2 = ld4(slabs + (size_t)(k + 2) * M * N + idx), d2 = ld4(slabs + (size_t)(k + 3) * M * N + idx);
+        s += a; s += b; s += c2; s += d2;
+    }
+    for (; k < splits; ++k) s += ld4(slabs + (size_t)k * M * N + idx);
     s *= alpha;
     float* c = C + (size_t)m * ldc + n;
     if (accumulate) s += ld4(c);

@@ -176,6 +176,15 @@ __global__ __launch_bounds__(64 * RP_WAVES) void reduce_partials_kernel(
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < n_out) {
         int p = wave;
+        // sixteen rows' loads in flight (24 blocks cover the 1536 LayerNorm columns: the pass is latency-, not
+        // bandwidth-bound), added to the four accumulators in the order of the four-row loop below
+        for (; p + 15 * RP_WAVES < nparts; p += 16 * RP_WAVES) {
+            float a[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u] = partial[(size_t)(p + u * RP_WAVES) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { s0 += a[u]; s1 += a[u + 1]; s2 += a[u + 2]; s3 += a[u + 3]; }
+        }
         for (; p + 3 * RP_WAVES < nparts; p += 4 * RP_WAVES) {
             s0 += partial[(size_t)p * stride + c];
             s1 += partial[(size_t)(p + RP_WAVES) * stride + c];
