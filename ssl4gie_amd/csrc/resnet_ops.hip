@@ -262,24 +262,26 @@ __global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* 
 // dx coefficients and dgamma / dbeta.  One launch instead of three (four) ~5 us ones per layer.
 DEVI bool bn_sum_partials(const float* __restrict__ partial, int parts, int C, float& s, float& q,
                           float (*red)[2][64]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // 4 waves per block, or 16 (BN_TAIL_WIDE: a few hundred to two thousand partial rows summed in ONE launch,
+    // without the 64-way fold in front — two ~5 us launches become one)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     s = 0.f; q = 0.f;
     if (c < C) {
         // eight rows' loads in flight, then the adds in row order (the sums are those of the plain loop; a
         // dependent load per row cost up to 64 L2 round trips in this kernel's one wave per 64 channels)
         int p = wave;
-        for (; p + 28 < parts; p += 32) {
+        for (; p + 7 * nw < parts; p += 8 * nw) {
             float a[8], b[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                a[u] = partial[(size_t)(p + 4 * u) * 2 * C + c];
-                b[u] = partial[(size_t)(p + 4 * u) * 2 * C + C + c];
+                a[u] = partial[(size_t)(p + nw * u) * 2 * C + c];
+                b[u] = partial[(size_t)(p + nw * u) * 2 * C + C + c];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { s += a[u]; q += b[u]; }
         }
-        for (; p < parts; p += 4) {
+        for (; p < parts; p += nw) {
             s += partial[(size_t)p * 2 * C + c];
             q += partial[(size_t)p * 2 * C + C + c];
         }
@@ -287,8 +289,7 @@ DEVI bool bn_sum_partials(const float* __restrict__ partial, int parts, int C, f
     if (wave > 0) { red[wave - 1][0][lane] = s; red[wave - 1][1][lane] = q; }
     __syncthreads();
     if (wave != 0 || c >= C) return false;
-#pragma unroll
-    for (int w = 0; w < 3; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
+    for (int w = 0; w < nw - 1; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
     return true;
 }
 // the forward's normalisation coefficients y = x a + b; ONE definition, because the backward kernels that rebuild
@@ -297,12 +298,12 @@ DEVI void bn_affine(float gamma, float beta, float mean, float rstd, float& a, f
     a = rstd * gamma;
     b = beta - mean * a;
 }
-__global__ __launch_bounds__(256) void bn_fwd_tail_kernel(
+__global__ __launch_bounds__(1024) void bn_fwd_tail_kernel(
     const float* __restrict__ partial, int parts, const float* __restrict__ pivot,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
     float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
     float* __restrict__ coef, float count, float eps, float momentum, int C) {
-    __shared__ float red[3][2][64];
+    __shared__ float red[15][2][64];
     float s, q;
     if (!bn_sum_partials(partial, parts, C, s, q, red)) return;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -322,12 +323,12 @@ __global__ __launch_bounds__(256) void bn_fwd_tail_kernel(
     coef[c] = a;
     coef[C + c] = b;
 }
-__global__ __launch_bounds__(256) void bn_bwd_tail_kernel(
+__global__ __launch_bounds__(1024) void bn_bwd_tail_kernel(
     const float* __restrict__ partial, int parts, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, float inv_n,
     float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
     int accumulate, int C, const float* __restrict__ beta, float* __restrict__ mcoef) {
-    __shared__ float red[3][2][64];
+    __shared__ float red[15][2][64];
     float s, q;
     if (!bn_sum_partials(partial, parts, C, s, q, red)) return;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -781,9 +782,12 @@ __global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __re
     }
 }
 // -> (partials to hand to the tail kernels, their count); `scratch` holds BN_FOLD x 2C floats
+#define BN_TAIL_WIDE 2048
+// threads of the tail kernel for `np` partial rows (see bn_sum_partials)
+static dim3 bn_tail_block(int np) { return dim3(np > 4 * BN_FOLD ? 1024 : 256); }
 static int bn_fold(const float* partial, int parts, float* scratch, int C, hipStream_t st,
                    const float** out, int* nout) {
-    if (parts <= 4 * BN_FOLD) { *out = partial; *nout = parts; return 0; }
+    if (parts <= BN_TAIL_WIDE) { *out = partial; *nout = parts; return 0; }
     hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + 63) / 64, BN_FOLD), dim3(256), 0, st, partial,
                        parts, scratch, C);
     LAUNCH_CHECK();
@@ -827,7 +831,7 @@ extern "C" int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* be
         hipLaunchKernelGGL(bn_stats_kernel<float>, grid, block, 0, st, (const float*)x, partial,
                            pivot, rows, C);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_fwd_tail_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, parts, pivot,
+    hipLaunchKernelGGL(bn_fwd_tail_kernel, dim3((C + 63) / 64), bn_tail_block(parts), 0, st, partial, parts, pivot,
                        gamma, beta, mean, rstd, running_mean, running_var, coef, (float)rows, eps,
                        momentum, C);
     LAUNCH_CHECK();
@@ -863,7 +867,7 @@ static int bn_bwd_impl(const void* dy, const void* y, const void* x, const float
     float* fold_scratch = partial + ((size_t)parts * 2 + 3) * C;
     int rc = bn_fold(partial, parts, fold_scratch, C, st, &pp, &np);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_tail_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pp, np, mean,
+    hipLaunchKernelGGL(bn_bwd_tail_kernel, dim3((C + 63) / 64), bn_tail_block(np), 0, st, pp, np, mean,
                        rstd, gamma, 1.0f / (float)rows, coef, dgamma, dbeta, accumulate, C, beta, mcoef);
     LAUNCH_CHECK();
     const long long total = rows * C;
@@ -1064,7 +1068,7 @@ static int bn_fwd_partials_impl(const void* x, const float* partial, int parts, 
     const float* pp; int np;
     int rc = bn_fold(partial, parts, scratch, C, st, &pp, &np);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_fwd_tail_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pp, np,
+    hipLaunchKernelGGL(bn_fwd_tail_kernel, dim3((C + 63) / 64), bn_tail_block(np), 0, st, pp, np,
                        (const float*)nullptr, gamma, beta, mean, rstd, running_mean, running_var, coef,
                        (float)rows, eps, momentum, C);
     LAUNCH_CHECK();
@@ -1086,7 +1090,7 @@ extern "C" int ssl4gie_bn_coef_partials(const float* partial, int parts, const f
     const float* pp; int np;
     int rc = bn_fold(partial, parts, scratch, C, st, &pp, &np);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_fwd_tail_kernel, dim3((C + 63) / 64), dim3(256), 0, st, pp, np,
+    hipLaunchKernelGGL(bn_fwd_tail_kernel, dim3((C + 63) / 64), bn_tail_block(np), 0, st, pp, np,
                        (const float*)nullptr, gamma, beta, mean, rstd, running_mean, running_var, coef,
                        (float)rows, eps, momentum, C);
     LAUNCH_CHECK();
