@@ -646,7 +646,17 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     const int nj = nt256_pick_nj(d, cus);
     const int tm = (d->M + P_BM - 1) / P_BM, tn = (d->N + 64 * nj - 1) / (64 * nj);
     const int ntiles = tm * tn;
-    dim3 grid(ntiles < cus ? ntiles : cus), block(512);
+    // the launch takes ceil(ntiles / cus) rounds of tiles whatever happens: with that many rounds, the FEWEST
+    // persistent workgroups that still finish in them (600 tiles: 3 rounds on 200 CUs instead of 240) leave the
+    // other CUs to whatever runs beside the launch — the weight-gradient stream in the backward pass
+    static int balance = -1;
+    if (balance < 0) { const char* e = getenv("SSL4GIE_NT_BALANCE"); balance = e ? atoi(e) : 1; }
+    int wgs = ntiles < cus ? ntiles : cus;
+    if (balance && ntiles > cus) {
+        const int rounds = (ntiles + cus - 1) / cus;
+        wgs = (ntiles + rounds - 1) / rounds;
+    }
+    dim3 grid(wgs), block(512);
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate,
               d->colstats};
     if (d->epilogue == SSL4GIE_EPI_AFFINE_AUX_RELU) {  // two borrowed slots (gemm256.h p_epilogue)
