@@ -102,7 +102,16 @@ SideStream* side_stream() {
     SideStream* ss = &per_dev[dev];
     if (!ss->s) {
         hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        // SSL4GIE_WGRAD_PRIO=high|low: scheduling priority of the weight-gradient stream against the caller's
+        // (default: the same).  Measured on the MAE step (profiles/r04bs): see DESIGN.md section 5.
+        const char* pe = getenv("SSL4GIE_WGRAD_PRIO");
+        int least = 0, greatest = 0;
+        if (pe && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+            const int prio = (pe[0] == 'h' || pe[0] == 'H') ? greatest : least;
+            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
+        } else if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            return nullptr;
+        }
         for (int i = 0; i < 10; ++i) {
             if (hipEventCreateWithFlags(&ss->ev[i], hipEventDisableTiming) != hipSuccess) {
                 (void)hipStreamDestroy(st);
