@@ -20,7 +20,8 @@
  *     ssl4gie_bn_combine_stats and ssl4gie_debug_nt256_stamps existed — additions only; 4: before
  *     ssl4gie_gemm_desc gained `scale` / `relu` (appended; SSL4GIE_EPI_AFFINE_AUX_RELU and the
  *     statistics-only product with C == NULL) and ssl4gie_bn_bwd_xmask / ssl4gie_bn_coef_partials / ssl4gie_bn_maxpool3x3s2_fwd /
- *     ssl4gie_conv3x3_direct_{fwd,wgrad}_affine / ssl4gie_bn_fwd_partials_bits / ssl4gie_bn_bwd_bits existed);
+ *     ssl4gie_conv3x3_direct_{fwd,wgrad}_affine / ssl4gie_bn_fwd_partials_bits / ssl4gie_bn_bwd_bits /
+ *     ssl4gie_bn_bwd_{reduce,apply}_xmask existed);
  *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
  *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
  */
@@ -500,6 +501,15 @@ int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x, const flo
                          const float* mean, const float* rstd, const float* sums, float inv_count,
                          void* dx, int relu, float* workspace, int dtype, long long rows, int C,
                          void* stream);
+/* The two SyncBatchNorm backward halves for BatchNorm + ReLU without a residual input, with the ReLU mask rebuilt
+ * from x and the forward's coefficients (gamma, beta and the GLOBAL mean / rstd) as ssl4gie_bn_bwd_xmask does:
+ * the ReLU output is read by neither pass. */
+int ssl4gie_bn_bwd_reduce_xmask(const void* dy, const void* x, const float* gamma, const float* beta,
+                                const float* mean, const float* rstd, float* sums, float* workspace, int dtype,
+                                long long rows, int C, void* stream);
+int ssl4gie_bn_bwd_apply_xmask(const void* dy, const void* x, const float* gamma, const float* beta,
+                               const float* mean, const float* rstd, const float* sums, float inv_count, void* dx,
+                               float* workspace, int dtype, long long rows, int C, void* stream);
 /* MoCo._update_momentum_encoder (moco/builder.py:57-61): dst = dst m + src (1 - m), fp32, over a
  * whole parameter-arena slice */
 int ssl4gie_ema_update(float* dst, const float* src, float m, long long n, void* stream);

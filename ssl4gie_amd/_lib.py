@@ -133,6 +133,8 @@ PROTOTYPES = {
                                            i32, vp]),
     "ssl4gie_bn_bwd_bits": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_xmask": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
+    "ssl4gie_bn_bwd_reduce_xmask": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
+    "ssl4gie_bn_bwd_apply_xmask": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_reduce": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_ema_update": (i32, [vp, vp, f32, i64, vp]),

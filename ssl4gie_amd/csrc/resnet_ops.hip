@@ -235,14 +235,21 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
     }
 }
 // per-channel affine of the normalisation: y = x * coef[c] + coef[C + c]
+// the forward's normalisation coefficients y = x a + b; ONE definition, because the backward kernels that rebuild
+// the ReLU mask from x (xmask) must reproduce the forward's sign decisions
+DEVI void bn_affine(float gamma, float beta, float mean, float rstd, float& a, float& b) {
+    a = rstd * gamma;
+    b = beta - mean * a;
+}
 __global__ void bn_fwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ coef, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float a = rstd[c] * (gamma ? gamma[c] : 1.f);
+    float a, b;
+    bn_affine(gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f, mean[c], rstd[c], a, b);
     coef[c] = a;
-    coef[C + c] = (beta ? beta[c] : 0.f) - mean[c] * a;
+    coef[C + c] = b;
 }
 // dx = coef[c] g + coef[C+c] x + coef[2C+c]   (expansion of gamma rstd (g - s1/n - xhat s2/n))
 __global__ void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -291,12 +298,6 @@ DEVI bool bn_sum_partials(const float* __restrict__ partial, int parts, int C, f
     if (wave != 0 || c >= C) return false;
     for (int w = 0; w < nw - 1; ++w) { s += red[w][0][lane]; q += red[w][1][lane]; }
     return true;
-}
-// the forward's normalisation coefficients y = x a + b; ONE definition, because the backward kernels that rebuild
-// the ReLU mask from x (xmask) must reproduce the forward's sign decisions
-DEVI void bn_affine(float gamma, float beta, float mean, float rstd, float& a, float& b) {
-    a = rstd * gamma;
-    b = beta - mean * a;
 }
 __global__ __launch_bounds__(1024) void bn_fwd_tail_kernel(
     const float* __restrict__ partial, int parts, const float* __restrict__ pivot,
@@ -1135,6 +1136,46 @@ extern "C" int ssl4gie_bn_bwd_reduce(const void* dy, const void* y, const void* 
                            rows, C, (const float*)nullptr, (const float*)nullptr);
     LAUNCH_CHECK();
     return ssl4gie_internal_reduce_partials(partial, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+}
+// ... and for BatchNorm + ReLU without a residual input, with the mask rebuilt from x and the forward's
+// coefficients (as ssl4gie_bn_bwd_xmask; mean / rstd are the GLOBAL statistics the forward normalised with)
+extern "C" int ssl4gie_bn_bwd_reduce_xmask(const void* dy, const void* x, const float* gamma, const float* beta,
+                                           const float* mean, const float* rstd, float* sums,
+                                           float* workspace, int dtype, long long rows, int C, void* stream) {
+    REQUIRE(dy && x && mean && rstd && sums && workspace && rdt(dtype) && rows > 0 && C > 0 && C % 8 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = bn_parts(rows, C);
+    dim3 grid(bn_strips(C, dtype), parts), block(256);
+    float* partial = workspace + 3 * (size_t)C;
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)dy,
+                           (const bf16_t*)nullptr, (const bf16_t*)x, mean, rstd, (bf16_t*)nullptr, partial, 1,
+                           rows, C, gamma, beta);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), grid, block, 0, st, (const float*)dy,
+                           (const float*)nullptr, (const float*)x, mean, rstd, (float*)nullptr, partial, 1, rows,
+                           C, gamma, beta);
+    LAUNCH_CHECK();
+    return ssl4gie_internal_reduce_partials(partial, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+}
+extern "C" int ssl4gie_bn_bwd_apply_xmask(const void* dy, const void* x, const float* gamma, const float* beta,
+                                          const float* mean, const float* rstd, const float* sums,
+                                          float inv_count, void* dx, float* workspace, int dtype,
+                                          long long rows, int C, void* stream) {
+    REQUIRE(dy && x && mean && rstd && sums && dx && workspace && rdt(dtype) && rows > 0 && C > 0 &&
+            C % 8 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    float* mcoef = workspace + 3 * (size_t)C;  // [2][C] behind the dx coefficients
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd, gamma,
+                       sums, inv_count, workspace, C);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_fwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd, gamma, beta,
+                       mcoef, C);
+    LAUNCH_CHECK();
+    const long long total = rows * C;
+    RN_LAUNCH(dtype, bn_bwd_apply_kernel, total / rvn(dtype), (const T*)dy, (const T*)nullptr, (const T*)x,
+              workspace, (T*)dx, 1, C, total, (const float*)mcoef);
+    return 0;
 }
 extern "C" int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* gamma,
                                     const float* mean, const float* rstd, const float* sums,

@@ -1114,6 +1114,32 @@ def bn_bwd_reduce(dy2d, y2d, x2d, mean, rstd, relu, want_dres):
     return sums, dres
 
 
+def bn_bwd_reduce_xmask(dy2d, x2d, gamma, beta, mean, rstd):
+    """SyncBatchNorm + ReLU (no residual) backward, first half with the mask rebuilt from x: LOCAL sums [2, C]"""
+    _dev(dy2d, x2d, gamma, beta, mean, rstd)
+    rows, C = x2d.shape
+    L = _lib.load()
+    sums = torch.empty(2, C, dtype=torch.float32, device=x2d.device)
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_bwd_reduce_xmask(ptr(dy2d), ptr(x2d), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                             ptr(sums), ptr(ws), code(x2d.dtype), rows, C, stream()),
+               "bn_bwd_reduce_xmask")
+    return sums
+
+
+def bn_bwd_apply_xmask(dy2d, x2d, gamma, beta, mean, rstd, sums, inv_count):
+    """... second half: dx from the GLOBAL sums and 1 / (global row count)"""
+    _dev(dy2d, x2d, gamma, beta, mean, rstd, sums)
+    rows, C = x2d.shape
+    dx = torch.empty_like(x2d)
+    L = _lib.load()
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_bwd_apply_xmask(ptr(dy2d), ptr(x2d), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                            ptr(sums), float(inv_count), ptr(dx), ptr(ws), code(x2d.dtype), rows, C,
+                                            stream()), "bn_bwd_apply_xmask")
+    return dx
+
+
 def bn_bwd_apply(dy2d, y2d, x2d, gamma, mean, rstd, sums, inv_count, relu):
     _dev(dy2d, y2d, x2d, gamma, mean, rstd, sums)
     rows, C = x2d.shape

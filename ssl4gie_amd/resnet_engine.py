@@ -331,7 +331,12 @@ class BatchNormFn(torch.autograd.Function):
             dx, dres = ops.bn_bwd(dy2, y, x2, gd, mean, rstd, relu, has_res, tg, tb, acc)
         else:
             import torch.distributed as dist
-            sums, dres = ops.bn_bwd_reduce(dy2, y, x2, mean, rstd, relu, has_res)
+            xm = relu and not has_res and _XMASK   # mask rebuilt from x and the (global) forward coefficients
+            bd = beta.detach() if beta is not None else None
+            if xm:
+                sums, dres = ops.bn_bwd_reduce_xmask(dy2, x2, gd, bd, mean, rstd), None
+            else:
+                sums, dres = ops.bn_bwd_reduce(dy2, y, x2, mean, rstd, relu, has_res)
             for tgt, row in ((tb, 0), (tg, 1)):  # parameter gradients are the LOCAL sums
                 if tgt is not None:
                     if acc:
@@ -340,7 +345,9 @@ class BatchNormFn(torch.autograd.Function):
                         tgt.copy_(sums[row])
             gsums = sync_sum(sums, group)
             gsums /= total  # the 1 / count of the dx formula, folded into the sums on the device
-            if relu and has_res:   # dres is the masked gradient: one tensor instead of dy and the ReLU output
+            if xm:
+                dx = ops.bn_bwd_apply_xmask(dy2, x2, gd, bd, mean, rstd, gsums, 1.0)
+            elif relu and has_res:   # dres is the masked gradient: one tensor instead of dy and the ReLU output
                 dx = ops.bn_bwd_apply(dres, None, x2, gd, mean, rstd, gsums, 1.0, False)
             else:
                 dx = ops.bn_bwd_apply(dy2, y, x2, gd, mean, rstd, gsums, 1.0, relu)

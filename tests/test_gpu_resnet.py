@@ -95,6 +95,13 @@ def test_batchnorm_relu_backward_mask_from_x_equals_mask_from_output(rows, C, dt
     # accumulate
     dx2 = ops.bn_bwd_xmask(dy, x, gamma, beta, mean, rstd, dg1, db1, True)
     assert torch.equal(dx2, dx1) and torch.equal(dg1, 2 * dg0) and torch.equal(db1, 2 * db0)
+    # the SyncBatchNorm halves (local sums -> [exchange] -> apply): mask from x == mask from the output
+    s0, _ = ops.bn_bwd_reduce(dy, y, x, mean, rstd, True, False)
+    s1 = ops.bn_bwd_reduce_xmask(dy, x, gamma, beta, mean, rstd)
+    assert torch.equal(s0, s1)
+    a0 = ops.bn_bwd_apply(dy, y, x, gamma, mean, rstd, s0, 1.0 / rows, True)
+    a1 = ops.bn_bwd_apply_xmask(dy, x, gamma, beta, mean, rstd, s1, 1.0 / rows)
+    assert torch.equal(a0, a1)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF])
