@@ -483,8 +483,17 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial,
     const int ci = idx % Cin, tap = (idx / Cin) % 9, co = idx / (9 * Cin);
     const int combo = (co >> 5) * nslice + (ci >> 6), cl = ci & 63;
     float s = 0.f;
-    for (int g = 0; g < wgs_per_combo; ++g)
-        s += partial[(size_t)(g * ncombo + combo) * (32 * 9 * 64) + ((co & 31) * 9 + tap) * 64 + cl];
+    const float* src = partial + (size_t)combo * (32 * 9 * 64) + ((co & 31) * 9 + tap) * 64 + cl;
+    const size_t gs = (size_t)ncombo * (32 * 9 * 64);
+    int g = 0;
+    for (; g + 7 < wgs_per_combo; g += 8) {  // eight workgroups' partials in flight, added in workgroup order
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(g + u) * gs];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u];
+    }
+    for (; g < wgs_per_combo; ++g) s += src[(size_t)g * gs];
     float* o = dw2 + (size_t)co * 9 * Cin + tap * Cin + ci;
     *o = accumulate ? *o + s : s;
 }
