@@ -474,8 +474,16 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial,
         const int co = idx - nw;
         if (co < Cout && dbias) {
             float s = 0.f;
-            for (int g = 0; g < wgs_per_combo; ++g)
-                s += partial_b[(size_t)(g * ncombo + (co >> 5) * nslice) * 32 + (co & 31)];
+            const float* src = partial_b + (size_t)((co >> 5) * nslice) * 32 + (co & 31);
+            int g = 0;
+            for (; g + 7 < wgs_per_combo; g += 8) {  // loads in flight, adds in workgroup order (as below)
+                float a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(g + u) * ncombo * 32];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += a[u];
+            }
+            for (; g < wgs_per_combo; ++g) s += src[(size_t)g * ncombo * 32];
             dbias[co] = accumulate ? dbias[co] + s : s;
         }
         return;

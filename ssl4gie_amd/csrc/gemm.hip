@@ -731,7 +731,17 @@ __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* __re
     const size_t idx = i4 * 4, slab = (size_t)M * N;
     f32x4 s = {0, 0, 0, 0};
     if (ok)
-        for (int k = g; k < splits; k += 4) s += ld4(slabs + (size_t)k * slab + idx);
+    {
+        int k = g;
+        for (; k + 28 < splits; k += 32) {  // eight of this group's slabs in flight, added in slab order
+            f32x4 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = ld4(slabs + (size_t)(k + 4 * u) * slab + idx);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += a[u];
+        }
+        for (; k < splits; k += 4) s += ld4(slabs + (size_t)k * slab + idx);
+    }
     if (g > 0) part[g - 1][c] = s;
     __syncthreads();
     if (g != 0 || !ok) return;
