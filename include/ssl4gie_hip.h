@@ -21,7 +21,7 @@
  *     ssl4gie_gemm_desc gained `scale` / `relu` (appended; SSL4GIE_EPI_AFFINE_AUX_RELU and the
  *     statistics-only product with C == NULL) and ssl4gie_bn_bwd_xmask / ssl4gie_bn_coef_partials / ssl4gie_bn_maxpool3x3s2_fwd /
  *     ssl4gie_conv3x3_direct_{fwd,wgrad}_affine / ssl4gie_bn_fwd_partials_bits / ssl4gie_bn_bwd_bits /
- *     ssl4gie_bn_bwd_{reduce,apply}_xmask existed);
+ *     ssl4gie_bn_bwd_{reduce,apply}_xmask / ssl4gie_conv3x3_weight_pack_batch existed);
  *   - "lp" tensors are the MFMA operand type: SSL4GIE_BF16 for the production path,
  *     SSL4GIE_F32 for the exact-fp32 parity path (f32 MFMA, bit-level fp32 FMA chains).
  */
@@ -338,6 +338,10 @@ int ssl4gie_set_compute_cus(int n);
  * torchvision Bottleneck.conv2), once per optimizer step. */
 int ssl4gie_conv3x3_weight_pack(const float* w, void* out, int dtype, int Cout, int Cin, int mode, int ld,
                                 void* stream);
+/* The same for n weights in ONE launch (arrays of n pointers / geometries; all outputs of type `dtype`): every 3x3
+ * convolution of a model re-packs its operand images after each optimizer step. */
+int ssl4gie_conv3x3_weight_pack_batch(const void* const* w, void* const* out, const int* Cout, const int* Cin,
+                                      const int* mode, const int* ld, int n, int dtype, void* stream);
 /* ... and back for the weight gradient: dw2 [Cout][ld] fp32 with columns (tap, ci) -> (+)= dW [Cout][Cin][3][3] */
 int ssl4gie_conv3x3_wgrad_unpack(const float* dw2, float* dw, int Cout, int Cin, int ld, int accumulate,
                                  void* stream);

@@ -78,7 +78,7 @@ class MoCo(EngineModule):
         ops.ema_update(a.data[m0:m1], a.data[b0:b1], m)
         # the kernel writes through raw pointers: torch's version counters do not move, so the
         # operand caches (bf16 weight copies) are invalidated through the engine's epoch instead
-        bump_weights_epoch()
+        bump_weights_epoch(touched=pm)
 
     def contrastive_loss(self, q, k):
         import torch.distributed as dist

@@ -182,6 +182,7 @@ PROTOTYPES = {
     "ssl4gie_allreduce_direct_error": (C.c_uint, [vp]),
     "ssl4gie_allreduce_direct_set_timeout": (i32, [vp, C.c_double]),
     "ssl4gie_allreduce_direct_destroy": (i32, [vp]),
+    "ssl4gie_conv3x3_weight_pack_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "ssl4gie_conv3x3_weight_pack": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ssl4gie_conv3x3_wgrad_unpack": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ssl4gie_debug_nt256_stamps": (i32, [vp, sz]),

@@ -543,6 +543,76 @@ extern "C" int ssl4gie_conv3x3_weight_pack(const float* w, void* out, int dtype,
     return 0;
 }
 
+// ... and for MANY weights in one launch (every 3x3 convolution of a ResNet-50 re-packs two or three operand
+// images per optimizer step: 61 launches of ~6 us in front of their convolutions): the items ride in the kernel
+// arguments, a block finds its item by bisection of the block-count prefix sums
+#define PACK_MAX 64
+struct PackBatch {
+    const float* w[PACK_MAX];
+    void* out[PACK_MAX];
+    int Cout[PACK_MAX], Cin[PACK_MAX], mode[PACK_MAX], ld[PACK_MAX];
+    unsigned first[PACK_MAX + 1];  // first block of item i; first[n] = total blocks
+    int n;
+};
+template <typename TO>
+__global__ void conv3x3_weight_pack_batch_kernel(const PackBatch b) {
+    int lo = 0, hi = b.n;  // first[lo] <= blockIdx.x < first[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blockIdx.x >= b.first[mid]) lo = mid; else hi = mid;
+    }
+    const int Cout = b.Cout[lo], Cin = b.Cin[lo], mode = b.mode[lo], ld = b.ld[lo];
+    const float* __restrict__ w = b.w[lo];
+    TO* __restrict__ out = (TO*)b.out[lo];
+    const long long total = mode == 0 ? (long long)Cout * ld : (mode == 1 ? (long long)Cin * ld : (long long)ld * Cout);
+    const long long i = (long long)(blockIdx.x - b.first[lo]) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float v = 0.f;
+    if (mode == 0) {
+        const int co = (int)(i / ld), k = (int)(i % ld);
+        if (k < 9 * Cin) { const int tap = k / Cin, ci = k - tap * Cin; v = w[((size_t)co * Cin + ci) * 9 + tap]; }
+    } else if (mode == 1) {
+        const int ci = (int)(i / ld), k = (int)(i % ld);
+        if (k < 9 * Cout) { const int ft = k / Cout, co = k - ft * Cout; v = w[((size_t)co * Cin + ci) * 9 + (8 - ft)]; }
+    } else {
+        const int k = (int)(i / Cout), co = (int)(i % Cout);
+        if (k < 9 * Cin) { const int tap = k / Cin, ci = k - tap * Cin; v = w[((size_t)co * Cin + ci) * 9 + tap]; }
+    }
+    if constexpr (sizeof(TO) == 2) out[i] = f2bf(v);
+    else out[i] = v;
+}
+extern "C" int ssl4gie_conv3x3_weight_pack_batch(const void* const* w, void* const* out, const int* Cout,
+                                                 const int* Cin, const int* mode, const int* ld, int n, int dtype,
+                                                 void* stream) {
+    REQUIRE(w && out && Cout && Cin && mode && ld && n >= 0 && (dtype == SSL4GIE_BF16 || dtype == SSL4GIE_F32));
+    for (int base = 0; base < n; base += PACK_MAX) {
+        PackBatch b;
+        b.n = n - base < PACK_MAX ? n - base : PACK_MAX;
+        unsigned blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const int j = base + i;
+            REQUIRE(w[j] && out[j] && Cout[j] > 0 && Cin[j] > 0 && mode[j] >= 0 && mode[j] <= 2 &&
+                    ld[j] >= 9 * (mode[j] == 1 ? Cout[j] : Cin[j]));
+            b.w[i] = (const float*)w[j]; b.out[i] = out[j];
+            b.Cout[i] = Cout[j]; b.Cin[i] = Cin[j]; b.mode[i] = mode[j]; b.ld[i] = ld[j];
+            const long long total = mode[j] == 0 ? (long long)Cout[j] * ld[j]
+                                  : (mode[j] == 1 ? (long long)Cin[j] * ld[j] : (long long)ld[j] * Cout[j]);
+            b.first[i] = blocks;
+            blocks += (unsigned)((total + 255) / 256);
+        }
+        b.first[b.n] = blocks;
+        if (!blocks) continue;
+        if (dtype == SSL4GIE_BF16)
+            hipLaunchKernelGGL(conv3x3_weight_pack_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0,
+                               (hipStream_t)stream, b);
+        else
+            hipLaunchKernelGGL(conv3x3_weight_pack_batch_kernel<float>, dim3(blocks), dim3(256), 0,
+                               (hipStream_t)stream, b);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 // the inverse for the weight GRADIENT: dw2 [Cout][ld] fp32 (columns (tap, ci), as the TN product / the direct
 // kernels deliver it) -> (+)= dW [Cout][Cin][3][3], the parameter's layout, in one launch
 __global__ void conv3x3_wgrad_unpack_kernel(const float* __restrict__ dw2, float* __restrict__ dw, int Cout, int Cin,

@@ -16,11 +16,12 @@ HIP.  Reference: Models/DPT_decoder.py (lines cited per node).
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
 from . import ops
-from .engine import GradSink, LPCache, weights_epoch
+from .engine import GradSink, LPCache, touched_since, weights_epoch
 
 
 # SSL4GIE_IMPLICIT_CONV=0 forces the materialised patch matrix (A/B measurements, parity tests)
@@ -40,13 +41,19 @@ def _fills_chip(x, stride, n_out):
 def _w_direct(lp, weight, dtype):
     """[Cout, 9 Cin] operand of the direct kernels (taps row-major, channels innermost, unpadded)"""
     Cout = weight.shape[0]
-    return _derived(lp, weight, "c3x", dtype, lambda w: ops.conv3x3_weight_pack(w, dtype, 0))
+    return _derived(lp, weight, "c3x", dtype, lambda w: ops.conv3x3_weight_pack(w, dtype, 0), recipe=(0, None))
 
 
-def _derived(lp: LPCache, p: torch.Tensor, tag: str, dtype, fn):
-    """operand-type tensor derived from parameter `p` by `fn`, cached until p changes"""
+def _derived(lp: LPCache, p: torch.Tensor, tag: str, dtype, fn, recipe=None):
+    """operand-type tensor derived from parameter `p` by `fn`, cached until p changes.
+    recipe = (mode, ld) of ops.conv3x3_weight_pack when `fn` is exactly that: the image is then also refreshed,
+    together with every other stale one, by ONE launch at the top of the next forward (refresh_conv_operands)."""
     key = (id(p), tag)
     ver = (p._version, p.data_ptr(), dtype, weights_epoch())
+    if recipe is not None:
+        rec = lp.__dict__.setdefault("_conv_recipes", {})
+        if key not in rec:
+            rec[key] = (weakref.ref(p), recipe[0], recipe[1], dtype)
     ent = lp._c.get(key)
     if ent is None or ent[0] != ver:
         with torch.no_grad():
@@ -58,6 +65,51 @@ def _derived(lp: LPCache, p: torch.Tensor, tag: str, dtype, fn):
         ent = (ver, t)
         lp._c[key] = ent
     return ent[1]
+
+
+def refresh_conv_operands(lp: LPCache):
+    """Re-pack every stale 3x3-convolution operand image registered with _derived(recipe=...) in ONE launch
+    (ssl4gie_conv3x3_weight_pack_batch) — a ResNet-50 otherwise issues ~60 small pack kernels per optimizer step,
+    each in front of its convolution.  Runs when the fused optimizers have moved the weights (the engine's
+    weights epoch); images made stale any other way are re-packed lazily, one by one, as before."""
+    rec = lp.__dict__.get("_conv_recipes")
+    if not rec or not _BATCH_PACK:
+        return
+    epoch = weights_epoch()
+    seen = lp.__dict__.get("_conv_epoch")
+    if seen == epoch:
+        return
+    lp.__dict__["_conv_epoch"] = epoch
+    moved = touched_since(seen) if seen is not None else None   # None: any parameter may have moved
+    items, dead = [], []
+    for key, (ref, mode, ld, dtype) in rec.items():
+        p = ref()
+        if p is None:
+            dead.append(key)
+            continue
+        ver = (p._version, p.data_ptr(), dtype, epoch)
+        ent = lp._c.get(key)
+        if ent is not None and ent[0] == ver:
+            continue
+        if ent is not None and moved is not None and key[0] not in moved and ent[0][:3] == ver[:3]:
+            lp._c[key] = (ver, ent[1])   # only the epoch moved, and not for this parameter: the image stands
+            continue
+        if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.dim() != 4:
+            continue
+        items.append((key, ver, p, mode, ld, dtype))
+    for key in dead:
+        rec.pop(key, None)
+        lp._c.pop(key, None)
+    for dtype in {it[5] for it in items}:
+        group = [it for it in items if it[5] == dtype]
+        outs = ops.conv3x3_weight_pack_batch([it[2].detach() for it in group], dtype, [it[3] for it in group],
+                                             [it[4] for it in group])
+        for it, t in zip(group, outs):
+            lp._c[it[0]] = (it[1], t)
+
+
+# SSL4GIE_CONV_PACK_BATCH=0: every 3x3 operand image by its own launch again (A/B)
+_BATCH_PACK = os.environ.get("SSL4GIE_CONV_PACK_BATCH", "1") != "0"
 
 
 def _pad_cols(m: torch.Tensor, ld: int) -> torch.Tensor:
@@ -102,7 +154,7 @@ class Conv3x3Fn(torch.autograd.Function):
         Cout = weight.shape[0]
         dt = x.dtype
         ld = ops.k_pad(9 * Cin, dt)
-        w2 = _derived(lp, weight, f"c3:{ld}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 0, ld))
+        w2 = _derived(lp, weight, f"c3:{ld}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 0, ld), recipe=(0, ld))
         x = x.contiguous()
         b = bias.detach() if bias is not None else None
         ctx.save_for_backward(x, weight, bias)
@@ -174,11 +226,13 @@ class Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if stride == 1:
                 ld2 = ops.k_pad(9 * Cout, dt)
-                wd = _derived(lp, weight, f"c3d:{ld2}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1, ld2))
+                wd = _derived(lp, weight, f"c3d:{ld2}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1, ld2),
+                              recipe=(1, ld2))
                 dy4 = dy.view(B, H, W, Cout)
                 if _DIRECT and ops.conv3x3_direct_ok(dy4, Cin):
                     # the data gradient is the same direct kernel on dy with the flipped weight
-                    wdd = _derived(lp, weight, "c3dd", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1))
+                    wdd = _derived(lp, weight, "c3dd", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1),
+                                   recipe=(1, None))
                     dxr = ops.conv3x3_direct_fwd(dy4, wdd, None, relu_mask=x if relu_in else None)
                     return dxr, rets[0], rets[1], None, None, None, None, None
                 if _IMPLICIT and ld2 == 9 * Cout and _fills_chip(dy4, 1, Cin) and \
@@ -190,8 +244,9 @@ class Conv3x3Fn(torch.autograd.Function):
                     dcols = ops.im2col3x3(dy4, 1, False, ld2)
                     dxr = ops.linear_fwd(dcols, wd, None, out_dtype=dt).view(B, H, W, Cin)
             else:
-                w2 = _derived(lp, weight, f"c3:{ld}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 0, ld))
-                w2t = _derived(lp, weight, f"c3t:{ld}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 2, ld))
+                w2 = _derived(lp, weight, f"c3:{ld}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 0, ld), recipe=(0, ld))
+                w2t = _derived(lp, weight, f"c3t:{ld}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 2, ld),
+                               recipe=(2, ld))
                 dcols = ops.linear_bwd_data(dy2, w2, w2t)  # [M_out, ld]
                 dxr = ops.col2im3x3(dcols, B, H, W, Cin, stride)
             dx = ops.relu_bwd(x, dxr) if relu_in else dxr

@@ -150,8 +150,29 @@ def weights_epoch() -> int:
     return _WEIGHTS_EPOCH[0]
 
 
-def bump_weights_epoch():
+# epoch -> ids of the parameters that moved when it was entered, or None for "any of them" (an optimizer step);
+# lets a cache that holds derived images of MANY parameters re-stamp the untouched ones instead of rebuilding
+# them (dpt_engine.refresh_conv_operands: MoCo's EMA update moves the momentum encoder only).  Short history.
+_EPOCH_TOUCHED = {}
+
+
+def bump_weights_epoch(touched=None):
+    """`touched`: the parameters whose storage was just rewritten (None = unknown / all)"""
     _WEIGHTS_EPOCH[0] += 1
+    _EPOCH_TOUCHED[_WEIGHTS_EPOCH[0]] = None if touched is None else frozenset(id(p) for p in touched)
+    for e in [e for e in _EPOCH_TOUCHED if e < _WEIGHTS_EPOCH[0] - 16]:
+        del _EPOCH_TOUCHED[e]
+
+
+def touched_since(epoch: int):
+    """ids of the parameters rewritten after `epoch`, or None when that is not known"""
+    out = set()
+    for e in range(epoch + 1, _WEIGHTS_EPOCH[0] + 1):
+        t = _EPOCH_TOUCHED.get(e, None)
+        if t is None:
+            return None
+        out |= t
+    return out
 
 
 # torch's FUSED optimizers (torch.optim.AdamW(..., fused=True)) update parameters without bumping
@@ -804,6 +825,9 @@ class EngineModule(nn.Module):
         _lib.load()
         self.arena()
         self.sink().new_pass()
+        if self.lp_cache.__dict__.get("_conv_recipes"):   # 3x3 operand images: one launch for all stale ones
+            from .dpt_engine import refresh_conv_operands
+            refresh_conv_operands(self.lp_cache)
 
     def sink(self) -> GradSink:
         if self._root is not None:

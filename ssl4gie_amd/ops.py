@@ -771,6 +771,32 @@ def conv3x3_weight_pack(weight, dtype, mode, ld=None):
     return out
 
 
+def conv3x3_weight_pack_batch(weights, dtype, modes, lds):
+    """conv3x3_weight_pack for a list of weights in one launch (ssl4gie_conv3x3_weight_pack_batch); lds[i] None =
+    the unpadded row length"""
+    import ctypes as C
+    n = len(weights)
+    if n == 0:
+        return []
+    outs, geo = [], []
+    for w, mode, ld in zip(weights, modes, lds):
+        _dev(w)
+        assert w.dtype == torch.float32 and w.dim() == 4 and w.shape[2:] == (3, 3) and w.is_contiguous()
+        Cout, Cin = w.shape[:2]
+        need = 9 * (Cout if mode == 1 else Cin)
+        ld = need if ld is None else ld
+        shape = (Cout, ld) if mode == 0 else ((Cin, ld) if mode == 1 else (ld, Cout))
+        outs.append(torch.empty(shape, dtype=dtype, device=w.device))
+        geo.append((Cout, Cin, mode, ld))
+    vp_arr = C.c_void_p * n
+    i_arr = C.c_int * n
+    _lib.check(_lib.load().ssl4gie_conv3x3_weight_pack_batch(
+        vp_arr(*[ptr(w) for w in weights]), vp_arr(*[ptr(o) for o in outs]), i_arr(*[g[0] for g in geo]),
+        i_arr(*[g[1] for g in geo]), i_arr(*[g[2] for g in geo]), i_arr(*[g[3] for g in geo]), n, code(dtype),
+        stream()), "conv3x3_weight_pack_batch")
+    return outs
+
+
 def conv3x3_wgrad_unpack(dw2, target, accumulate=False):
     """dw2 [Cout, ld >= 9 Cin] fp32, columns (tap, ci) -> (+)= target [Cout, Cin, 3, 3] (contiguous) in one launch"""
     _dev(dw2, target)

@@ -434,7 +434,8 @@ class BnReluConv3x3Fn(torch.autograd.Function):
                                                 bn.running_var, mom, bn.eps)
         if bn.num_batches_tracked is not None:
             _count_batch(bn)
-        w2 = _derived(lp, weight, f"c3:{9 * Cin}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 0, 9 * Cin))
+        w2 = _derived(lp, weight, f"c3:{9 * Cin}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 0, 9 * Cin),
+                      recipe=(0, 9 * Cin))
         x = x.contiguous()
         r = ops.conv3x3_direct_fwd(x, w2, None, True, colstats=want_stats, in_coef=coef)
         y, stats = r if want_stats else (r, None)
@@ -465,7 +466,7 @@ class BnReluConv3x3Fn(torch.autograd.Function):
                 _write_grad(tw, dw2.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), acc)
         dx = None
         if ctx.needs_input_grad[0]:
-            wdd = _derived(lp, weight, "c3dd", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1))
+            wdd = _derived(lp, weight, "c3dd", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1), recipe=(1, None))
             dz = ops.conv3x3_direct_fwd(dy.view(B, H, W, Cout), wdd, None)   # gradient at the ReLU's output
             dx = ops.bn_bwd_xmask(dz.view(-1, Cin), x.view(-1, Cin), gamma.detach() if gamma is not None else None,
                                   beta.detach() if beta is not None else None, mean, rstd, tg, tb, acc).view(B, H, W, Cin)

@@ -212,6 +212,41 @@ def test_batchnorm_residual_relu_backward_from_the_bit_map(rows, C):
     assert torch.equal(dx0, dx1) and torch.equal(dr0, dr1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
 
 
+def test_conv_operand_images_in_one_launch_equal_the_single_packs():
+    """ssl4gie_conv3x3_weight_pack_batch against ssl4gie_conv3x3_weight_pack: all three modes, padded and unpadded
+    rows, 70 weights (two kernel-argument batches); and a ResNet-50 step after a fused optimizer step gives the
+    same output with the batched refresh as with the lazy single packs"""
+    from ssl4gie_amd import dpt_engine, ops
+    g = G(55)
+    ws, modes, lds = [], [], []
+    for i in range(70):
+        co, ci = [(64, 64), (128, 32), (96, 256), (32, 128), (512, 64)][i % 5]
+        ws.append(torch.randn(co, ci, 3, 3, generator=g).to(DEV))
+        modes.append(i % 3)
+        need = 9 * (co if i % 3 == 1 else ci)
+        lds.append(None if i % 2 else need + 64)
+    outs = ops.conv3x3_weight_pack_batch(ws, BF, modes, lds)
+    for w, m, ld, o in zip(ws, modes, lds, outs):
+        assert torch.equal(o, ops.conv3x3_weight_pack(w, BF, m, ld))
+    from ssl4gie_amd.optim import ArenaAdamW
+    res = []
+    for batched in (True, False):
+        dpt_engine._BATCH_PACK = batched
+        m, _ = _resnet_pair(5)
+        m.to(DEV).set_precision("bf16")
+        m.train()
+        opt = ArenaAdamW(m, list(m.parameters()), lr=1e-3)
+        imgs = torch.randn(4, 3, 64, 64, generator=G(56)).to(DEV)
+        for _ in range(2):
+            opt.zero_grad()
+            m(imgs).square().mean().backward()
+            opt.step()
+        with torch.no_grad():
+            res.append(m(imgs).clone())
+    dpt_engine._BATCH_PACK = True
+    assert torch.equal(res[0], res[1])
+
+
 def test_maxpool_avgpool_subsample():
     from ssl4gie_amd.resnet_engine import AvgPoolFn, MaxPoolFn, Subsample2Fn
     x = torch.relu(torch.randn(2, 16, 12, 10, generator=G(6)))  # ReLU output: many tied zeros
