@@ -286,6 +286,13 @@ int ssl4gie_block_fwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* 
  * dY operands and must stay untouched until the caller has launched them (next two entries). */
 #define SSL4GIE_BWD_ACCUMULATE 1
 #define SSL4GIE_BWD_DEFER_WGRAD 2
+/* SSL4GIE_BWD_NO_JOIN | SSL4GIE_BWD_SLOT(s), s in 0..3: `stream` does NOT wait for the block's weight-gradient
+ * products at the end of the call (the default join makes the next block's first data-gradient GEMM wait for
+ * this block's last weight gradient: 20 stalls per MAE step).  Instead their completion is recorded under slot s
+ * (as ssl4gie_wgrad_group does): `workspace`, dx_out_lp and the gradient targets must stay untouched until
+ * ssl4gie_wgrad_wait(s, stream) has been called — the caller alternates two workspaces and slots. */
+#define SSL4GIE_BWD_NO_JOIN 4
+#define SSL4GIE_BWD_SLOT(s) (((s) & 3) << 4)
 int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_block_weights* w,
                       const ssl4gie_block_act* a, const ssl4gie_block_grads* g,
                       const float* x_in, const float* dx_out, const void* dx_out_lp,

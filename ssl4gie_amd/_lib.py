@@ -23,7 +23,7 @@ if os.environ.get("SSL4GIE_DEBUG_LIB") == "1":
 ABI_VERSION = 5
 
 F32, BF16 = 0, 1
-BWD_ACCUMULATE, BWD_DEFER_WGRAD = 1, 2
+BWD_ACCUMULATE, BWD_DEFER_WGRAD, BWD_NO_JOIN = 1, 2, 4
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_DGELU, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX, \
     EPI_RELU_MASK_AUX, EPI_ADD_AUX, EPI_AFFINE_AUX_RELU = range(10)
 

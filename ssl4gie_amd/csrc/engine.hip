@@ -264,6 +264,8 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     // `accumulate` carries flags: bit 0 accumulate, bit 1 SSL4GIE_BWD_DEFER_WGRAD (the caller launches
     // the four dW products later: ssl4gie_block_wgrad_descs + ssl4gie_wgrad_group)
     const bool defer = (accumulate & SSL4GIE_BWD_DEFER_WGRAD) != 0;
+    const bool no_join = (accumulate & SSL4GIE_BWD_NO_JOIN) != 0;
+    const int slot = (accumulate >> 4) & 3;
     accumulate &= SSL4GIE_BWD_ACCUMULATE;
     const BwdLayout L = bwd_layout(d);
     char* ws = (char*)workspace;
@@ -331,7 +333,10 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     RC(ssl4gie_layernorm_bwd(dh, dt, x_in, w->ln1_g, a->mean1, a->rstd1, dxmid, dx_in,
                              dt == SSL4GIE_F32 ? nullptr : dx_in_lp, dt, g->ln1_g, g->ln1_b,
                              accumulate, ln_ws, T, D, stream));
-    if (ss) {  // join: the caller's stream continues after the last weight gradient
+    if (ss && no_join) {  // completion under the caller's slot: ssl4gie_wgrad_wait(slot, stream) before reuse
+        HIP_RET(hipEventRecord(ss->ev[6 + slot], ss->s));
+        ss->slot_used[slot] = true;
+    } else if (ss) {  // join: the caller's stream continues after the last weight gradient
         HIP_RET(hipEventRecord(ss->ev[4], ss->s));
         HIP_RET(hipStreamWaitEvent(main_st, ss->ev[4], 0));
     }

@@ -430,6 +430,10 @@ class BlockStackFn(torch.autograd.Function):
                 if cfg.on_block_grads is not None:
                     for j in done:
                         cfg.on_block_grads(j)
+        nojoin = (not grp) and lp is not None and _BWD_NO_JOIN and depth > 1
+        if nojoin:
+            ring2 = [ctx.ws, torch.empty_like(ctx.ws)]
+            keep2 = [[], []]
         for i in range(depth - 1, -1, -1):
             if i != depth - 1 and i in tap_g:
                 dx, dx_lp = ops.add_cast(dx, tap_g[i].contiguous(), want_f32=True, lp_dtype=lp)
@@ -464,6 +468,20 @@ class BlockStackFn(torch.autograd.Function):
                 keep[(k // grp) % 2] += [dx_lp, scratch]  # dY of dW_fc2 (+ frozen-parameter scratch)
                 if len(pending) == grp or i == 0:
                     launch_group()
+            elif nojoin:
+                # two workspaces in alternation: the caller's stream does not wait for this block's weight
+                # gradients (side stream) — only, two blocks later, before their operands are overwritten
+                k = (depth - 1 - i) % 2
+                _lib.check(L.ssl4gie_wgrad_wait(k, st), "wgrad_wait")
+                keep2[k].clear()
+                _lib.check(L.ssl4gie_block_bwd(C.byref(dims), C.byref(ctx.wstructs[i]), C.byref(a),
+                                               C.byref(g), ctx.xs[i].data_ptr(), dx.data_ptr(),
+                                               ops.ptr(dx_lp), dxn.data_ptr(), ops.ptr(dxn_lp),
+                                               int(accumulate) | _lib.BWD_NO_JOIN | (k << 4), ring2[k].data_ptr(), st),
+                           f"block_bwd[{i}]")
+                keep2[k] += [dx, dx_lp, scratch]   # dY of dW_fc2 / frozen-parameter scratch: read on the side stream
+                if cfg.on_block_grads is not None:
+                    cfg.on_block_grads(i)
             else:
                 _lib.check(L.ssl4gie_block_bwd(C.byref(dims), C.byref(ctx.wstructs[i]), C.byref(a),
                                                C.byref(g), ctx.xs[i].data_ptr(), dx.data_ptr(),
@@ -477,8 +495,17 @@ class BlockStackFn(torch.autograd.Function):
             for slot in range(min(n_groups, 2)):
                 _lib.check(L.ssl4gie_wgrad_wait(slot, st), "wgrad_wait")
             keep[0].clear(); keep[1].clear()
+        if nojoin:
+            for slot in (0, 1):
+                _lib.check(L.ssl4gie_wgrad_wait(slot, st), "wgrad_wait")
+            keep2[0].clear(); keep2[1].clear()
         ctx.acts = ctx.xs = ctx.ws = ctx.keepalive = None
         return (dx, None) + tuple(returns)
+
+
+# SSL4GIE_BWD_NO_JOIN=0: every block's backward ends with the caller's stream waiting for its weight gradients
+# again (one workspace) — A/B
+_BWD_NO_JOIN = os.environ.get("SSL4GIE_BWD_NO_JOIN", "1") != "0"
 
 
 def _wgrad_group_size(dims, depth: int) -> int:
