@@ -15,13 +15,14 @@ HIP.  Reference: Models/DPT_decoder.py (lines cited per node).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import weakref
 
 import torch
 
 from . import ops
-from .engine import GradSink, LPCache, touched_since, weights_epoch
+from .engine import GradSink, LPCache, touched_since, weights_epoch, wgrad_fork
 
 
 # SSL4GIE_IMPLICIT_CONV=0 forces the materialised patch matrix (A/B measurements, parity tests)
@@ -204,6 +205,16 @@ class Conv3x3Fn(torch.autograd.Function):
         dy = dy.contiguous()
         dy2 = dy.view(-1, Cout)
         (tw, tb), acc, rets = sink.plan([weight, bias])
+        side = wgrad_fork(dy, x, weight, bias) if tw is not None else None
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            Conv3x3Fn._wgrad(tw, tb, acc, dy2, x, stride, relu_in, ld, Cin, Cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            return Conv3x3Fn._dgrad(ctx, dy, dy2, x, weight, stride, relu_in, lp, ld, B, H, W, Cin, Cout, dt, rets)
+        return dx, rets[0], rets[1], None, None, None, None, None
+
+    @staticmethod
+    def _wgrad(tw, tb, acc, dy2, x, stride, relu_in, ld, Cin, Cout):
         if tw is not None:
             fuse_b = tb is not None and not acc  # the bias gradient rides on the same product
             if _DIRECT and stride == 1 and ops.conv3x3_direct_wgrad_ok(x, Cout):
@@ -222,8 +233,10 @@ class Conv3x3Fn(torch.autograd.Function):
                 _write_grad(tw, dw2[:, :9 * Cin].view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), acc)
         elif tb is not None:
             ops.colsum(dy2, out=tb, accumulate=acc)
-        dx = None
-        if ctx.needs_input_grad[0]:
+
+    @staticmethod
+    def _dgrad(ctx, dy, dy2, x, weight, stride, relu_in, lp, ld, B, H, W, Cin, Cout, dt, rets):
+        if True:
             if stride == 1:
                 ld2 = ops.k_pad(9 * Cout, dt)
                 wd = _derived(lp, weight, f"c3d:{ld2}", dt, lambda w: ops.conv3x3_weight_pack(w, dt, 1, ld2),

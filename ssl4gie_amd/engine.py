@@ -11,6 +11,7 @@ Precision modes (module attribute `engine_dtype`):
 from __future__ import annotations
 
 import ctypes as C
+import contextlib
 import os
 import weakref
 from dataclasses import dataclass
@@ -597,6 +598,39 @@ class GradJoin:
         return g
 
 
+# ---- weight gradients of single layers beside their data gradients -----------------------------------------------
+# (SSL4GIE_CONV_WGRAD_STREAM=0 turns it off.)  LinearFn / Conv3x3Fn.backward enqueue their weight-gradient product (and what follows
+# it: slab reduction, scatter into the parameter's layout) on a second stream forked from the caller's, so that it
+# runs beside the data-gradient chain — what the transformer blocks' executor does with the library's side stream.
+# The caller's stream joins at the end of the backward pass (autograd-engine call-backs); operands are kept alive
+# until then.  Off while a DataParallel wrapper is live (its bucket hooks would not see the second stream).
+_WGRAD_SIDE = os.environ.get("SSL4GIE_CONV_WGRAD_STREAM", "1") != "0"
+_WG = {"stream": None, "keep": []}
+
+
+def _wgrad_join():
+    if _WG["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_WG["stream"])
+    _WG["keep"].clear()
+
+
+def wgrad_fork(*keep):
+    """-> the weight-gradient stream (forked from the current one) or None; `keep` stays alive until the join"""
+    if not _WGRAD_SIDE or not keep or keep[0] is None or not keep[0].is_cuda:
+        return None
+    from . import parallel
+    if len(parallel._LIVE):
+        return None
+    if _WG["stream"] is None:
+        _WG["stream"] = torch.cuda.Stream()
+    side = _WG["stream"]
+    side.wait_stream(torch.cuda.current_stream())
+    _WG["keep"] += [k for k in keep if k is not None]
+    from torch.autograd import Variable
+    Variable._execution_engine.queue_callback(_wgrad_join)   # idempotent: one per use, all run at the end of the pass
+    return side
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b on operand-type activations; y in `out_dtype`."""
 
@@ -647,7 +681,9 @@ class LinearFn(torch.autograd.Function):
                 ctx.join.deposit(dx)
                 dx = None
         if tw is not None:
-            ops.linear_bwd_weight(dy2, x2, out=tw, accumulate=acc, bias_out=tb)
+            side = wgrad_fork(dy2, x2, weight, bias)   # beside the data-gradient chain when the option is on
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                ops.linear_bwd_weight(dy2, x2, out=tw, accumulate=acc, bias_out=tb)
         elif tb is not None:
             ops.colsum(dy2, out=tb, accumulate=acc)
         return dx, rets[0], rets[1], None, None, None, None, None, None
