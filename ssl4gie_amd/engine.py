@@ -603,7 +603,7 @@ class GradJoin:
 # it: slab reduction, scatter into the parameter's layout) on a second stream forked from the caller's, so that it
 # runs beside the data-gradient chain — what the transformer blocks' executor does with the library's side stream.
 # The caller's stream joins at the end of the backward pass (autograd-engine call-backs); operands are kept alive
-# until then.  Off while a DataParallel wrapper is live (its bucket hooks would not see the second stream).
+# until then.  DataParallel's communication stream waits for this stream before every bucket (parallel._wait_wgrad_stream).
 _WGRAD_SIDE = os.environ.get("SSL4GIE_CONV_WGRAD_STREAM", "1") != "0"
 _WG = {"stream": None, "keep": []}
 
@@ -617,9 +617,6 @@ def _wgrad_join():
 def wgrad_fork(*keep):
     """-> the weight-gradient stream (forked from the current one) or None; `keep` stays alive until the join"""
     if not _WGRAD_SIDE or not keep or keep[0] is None or not keep[0].is_cuda:
-        return None
-    from . import parallel
-    if len(parallel._LIVE):
         return None
     if _WG["stream"] is None:
         _WG["stream"] = torch.cuda.Stream()

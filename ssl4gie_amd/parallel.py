@@ -307,6 +307,11 @@ class DataParallel(nn.Module):
         cs = self._comm_stream.cuda_stream
         for slot in (0, 1):
             L.ssl4gie_wgrad_wait(slot, cs)
+        # ... and the single layers' weight gradients (engine.wgrad_fork: LinearFn / Conv3x3Fn) on theirs: whatever
+        # has been enqueued there so far belongs to gradients whose hooks have fired
+        from .engine import _WG
+        if _WG["stream"] is not None:
+            self._comm_stream.wait_stream(_WG["stream"])
 
     def _adopt(self, p):
         """a gradient autograd produced with torch ops (outside the engine's sinks) is moved into the
