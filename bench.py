@@ -698,6 +698,8 @@ def main():
         # per-kernel durations are taken with each launch alone on the chip: the weight-gradient
         # side stream (ssl4gie_set_wgrad_stream) is folded back for these steps only
         L.ssl4gie_set_wgrad_stream(0)
+        from ssl4gie_amd import engine as _engine
+        prev_side = _engine.set_wgrad_side(False)   # ... and the single layers' one (engine.wgrad_fork)
         _lib.check(L.ssl4gie_prof_begin(2000 * a.prof_steps), "prof_begin")
         for _ in range(a.prof_steps):
             step()
@@ -707,6 +709,7 @@ def main():
         _lib.check(L.ssl4gie_prof_collect(ms, fl, nl), "prof_collect")
         L.ssl4gie_prof_end()
         L.ssl4gie_set_wgrad_stream(0 if os.environ.get("SSL4GIE_WGRAD_STREAM") == "0" else 1)
+        _engine.set_wgrad_side(prev_side)
         per = {k: {"launches_per_step": nl[i] // a.prof_steps,
                    "ms_per_step": round(ms[i] / a.prof_steps, 3),
                    "avg_launch_us": round(1e3 * ms[i] / max(nl[i], 1), 2),

@@ -608,6 +608,14 @@ _WGRAD_SIDE = os.environ.get("SSL4GIE_CONV_WGRAD_STREAM", "1") != "0"
 _WG = {"stream": None, "keep": []}
 
 
+def set_wgrad_side(on: bool) -> bool:
+    """turn the single layers' weight-gradient stream on / off at run time (bench.py folds every stream back while it
+    takes per-kernel durations); returns the previous setting"""
+    global _WGRAD_SIDE
+    prev, _WGRAD_SIDE = _WGRAD_SIDE, bool(on)
+    return prev
+
+
 def _wgrad_join():
     if _WG["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_WG["stream"])
