@@ -370,7 +370,12 @@ bool ssl4gie_internal_tn256_ok(const ssl4gie_gemm_desc* d) {
 int ssl4gie_internal_tn256_splits(const ssl4gie_gemm_desc* d) {
     const int tiles = ((d->M + P_BM - 1) / P_BM) * ((d->N + P_BN - 1) / P_BN);
     const int nkt = d->K / P_BK;
-    int s = (ssl4gie_internal_compute_cus() + tiles / 2) / tiles;  // one workgroup per CU
+    // SSL4GIE_TN_FILL1 (percent, default 75): share of the CUs a lone product aims to fill.  These launches run
+    // beside the data-gradient chain on a weight-gradient stream, like the pairs (whose fill is 75 % too): MoCo-R50
+    // step 55.5 / 55.7 -> 54.9 / 55.0 ms in a same-box A/B (profiles/r04cy_tn_fill1.log), depth and MAE unchanged
+    static int fill1 = -1;
+    if (fill1 < 0) { const char* e = getenv("SSL4GIE_TN_FILL1"); fill1 = e ? atoi(e) : 75; if (fill1 < 10) fill1 = 10; }
+    int s = (ssl4gie_internal_compute_cus() * fill1 / 100 + tiles / 2) / tiles;  // one workgroup per CU
     if (s > nkt / 8) s = nkt / 8;       // at least 8 K-tiles per split
     if (s < 1) s = 1;
     if (s > 256) s = 256;               // (a single-tile product over a long contraction: one split per CU)
