@@ -13,6 +13,10 @@ if os.environ.get("ATTN_SMALL"):  # the same heads at a batch whose tensors stay
              ("vitb/8", 32, 197, 12, 64), ("vitb.full", 256, 197, 12, 64)]
 
 
+if os.environ.get("ATTN_CASES"):  # "name:B:N:H:hd,..."
+    CASES = [(c.split(":")[0],) + tuple(int(v) for v in c.split(":")[1:]) for c in os.environ["ATTN_CASES"].split(",")]
+
+
 def timeit(fn, iters=20):
     for _ in range(3):
         fn()
