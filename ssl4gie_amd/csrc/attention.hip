@@ -160,7 +160,14 @@ DEVI void stage_kv(char* img0, char* img1, const bf16_t* src0, const bf16_t* src
 // kernel into a dQ and a dK/dV launch with two images each was measured and changes nothing (304
 // vs 305 us): the backward is issue-bound, not latency-bound.
 template <int HD, int NKT> struct AttnFwdQG { static constexpr bool value = HD == 64 && NKT >= 10; };
-template <int HD, int NKT, int WAVES>
+// HT ("half tail"): N <= 16 (NKT - 1), i.e. the last 16-key tile of the last pair is all padding (N = 197: tiles
+// 0..12 hold keys, tile 13 none): its scores, maxima and exponentials are skipped and its probabilities are
+// zeros (N = 197 costs what N = 224 costs otherwise: profiles/r04db).  The LDS images keep their NKT tiles of
+// zero-padded rows, so the pair-wise transposed reads stay in range.  Used where it was measured to pay
+// (profiles/r04dd, same box): the hd-32 forward (N = 197: 60 -> 57 us, N = 208: 58.5 -> 53) and the hd-64
+// backward (N = 197: 286 -> 271 us); the hd-64 forward variant spills and the hd-32 backward does not move
+// (159 us either way: it follows the bytes, not the tile count), so those keep the plain kernels.
+template <int HD, int NKT, int WAVES, bool HT>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 14 ? 3 : 2))) void attn_fwd_bf16_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H,
     float scale) {
@@ -206,17 +213,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag<HD>(Qimg, qt * 16, ks, lane);
         }
+        constexpr int NKC = NKT - (HT ? 1 : 0);  // tiles that hold keys
         f32x4 s[NKT];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+        for (int kt = 0; kt < NKC; ++kt) {
             s[kt] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 s[kt] = MFMA16(row_frag<HD>(Kimg, kt * 16, ks, lane), qf[ks], s[kt]);
         }
+        if (HT) s[NKT - 1] = f32x4{0, 0, 0, 0};  // probabilities of the all-padding tile
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+        for (int kt = 0; kt < NKC; ++kt) {
             if (kt >= NKT - 2) {  // 16 (NKT - 2) < N: only the last two tiles hold padded keys
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
         const f32x2 nmc2 = {-mx * c, -mx * c};
         f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {  // packed fp32: one v_pk_fma / v_pk_add per two scores
+        for (int kt = 0; kt < NKC; ++kt) {  // packed fp32: one v_pk_fma / v_pk_add per two scores
             f32x2 a = {s[kt][0], s[kt][1]}, bq = {s[kt][2], s[kt][3]};
             a = a * c2 + nmc2;
             bq = bq * c2 + nmc2;
@@ -274,7 +283,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
 template <int NKT> struct AttnBwdWaves {
     static constexpr int value = NKT <= 4 ? 4 : (NKT <= 8 ? NKT : NKT / 2);
 };
-template <int HD, int NKT>
+// HT as in the forward kernel: the last pair of key tiles (phase A) / query tiles (phase B) is a single tile
+template <int HD, int NKT, bool HT>
 __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf16_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
@@ -352,24 +362,29 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
         f32x4 dq[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
-        auto pairA = [&](const int kp, auto tail) {
+        // MODE 0: a pair of full tiles; 1: the last pair, padded keys masked; 2: the last pair when its second
+        // tile is all padding (HT): one tile's worth of scores, the other half of dS^T is zero
+        auto pairA = [&](const int kp, auto modec) {
+            constexpr int MODE = decltype(modec)::value;
             f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s0 = MFMA16(row_frag<HD>(Kimg, kp * 32, ks, lane), qf[ks], s0);
-                s1 = MFMA16(row_frag<HD>(Kimg, kp * 32 + 16, ks, lane), qf[ks], s1);
                 p0 = MFMA16(row_frag<HD>(Vimg, kp * 32, ks, lane), dof[ks], p0);
-                p1 = MFMA16(row_frag<HD>(Vimg, kp * 32 + 16, ks, lane), dof[ks], p1);
+                if constexpr (MODE != 2) {
+                    s1 = MFMA16(row_frag<HD>(Kimg, kp * 32 + 16, ks, lane), qf[ks], s1);
+                    p1 = MFMA16(row_frag<HD>(Vimg, kp * 32 + 16, ks, lane), dof[ks], p1);
+                }
             }
-            f32x4 pa, pb, dsa, dsb;
+            f32x4 pa, pb, dsa, dsb = {0, 0, 0, 0};
             softmax_bwd4(s0, p0, l4, dl4, c, pa, dsa);
-            softmax_bwd4(s1, p1, l4, dl4, c, pb, dsb);
-            if constexpr (decltype(tail)::value) {
+            if constexpr (MODE != 2) softmax_bwd4(s1, p1, l4, dl4, c, pb, dsb);
+            if constexpr (MODE != 0) {
                 const int ka = kp * 32 + 4 * g;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dsa[r] = (ka + r < N) ? dsa[r] : 0.f;
-                    dsb[r] = (ka + 16 + r < N) ? dsb[r] : 0.f;
+                    if constexpr (MODE == 1) dsb[r] = (ka + 16 + r < N) ? dsb[r] : 0.f;
                 }
             }
             const bf16x8 dsf = pack8(dsa, dsb);
@@ -379,8 +394,8 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
         };
         // 16 (NKT - 2) < N: padded keys only in the last pair, which is peeled
 #pragma unroll 1
-        for (int kp = 0; kp < NKT / 2 - 1; ++kp) pairA(kp, std::false_type{});
-        pairA(NKT / 2 - 1, std::true_type{});
+        for (int kp = 0; kp < NKT / 2 - 1; ++kp) pairA(kp, std::integral_constant<int, 0>{});
+        pairA(NKT / 2 - 1, std::integral_constant<int, HT ? 2 : 1>{});
         if (q < N) {
             bf16_t* r = dqb + (size_t)q * rs + 4 * g;
 #pragma unroll
@@ -404,24 +419,31 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
             dk[dt] = f32x4{0, 0, 0, 0};
             dv[dt] = f32x4{0, 0, 0, 0};
         }
+        // HT: the last pair's second query tile is all padding — its scores are skipped (a wave-uniform branch, not
+        // a peeled copy of the body: the copy costs registers and spills at hd 64) and its P / dS are zeros
 #pragma unroll 1
         for (int qp = 0; qp < NKT / 2; ++qp) {
+            const bool full = !HT || qp < NKT / 2 - 1;
             f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s0 = MFMA16(row_frag<HD>(Qimg, qp * 32, ks, lane), kf[ks], s0);
-                s1 = MFMA16(row_frag<HD>(Qimg, qp * 32 + 16, ks, lane), kf[ks], s1);
                 p0 = MFMA16(row_frag<HD>(Oimg, qp * 32, ks, lane), vf[ks], p0);
-                p1 = MFMA16(row_frag<HD>(Oimg, qp * 32 + 16, ks, lane), vf[ks], p1);
+            }
+            if (full) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s1 = MFMA16(row_frag<HD>(Qimg, qp * 32 + 16, ks, lane), kf[ks], s1);
+                    p1 = MFMA16(row_frag<HD>(Oimg, qp * 32 + 16, ks, lane), vf[ks], p1);
+                }
             }
             // lane holds S[q = qp*32 (+16) + 4g + r][key]; p0/p1 hold dP.  Padded queries carry
             // lse = +inf (P = 0) and zero dO / delta rows, so they need no mask here.
             const int qa = qp * 32 + 4 * g;
-            const f32x4 la = *(const f32x4*)(lse_s + qa), lb = *(const f32x4*)(lse_s + qa + 16);
-            const f32x4 da = *(const f32x4*)(del_s + qa), db = *(const f32x4*)(del_s + qa + 16);
-            f32x4 pa, pb, dsa, dsb;
-            softmax_bwd4(s0, p0, la, da, c, pa, dsa);
-            softmax_bwd4(s1, p1, lb, db, c, pb, dsb);
+            f32x4 pa, pb = {0, 0, 0, 0}, dsa, dsb = {0, 0, 0, 0};
+            softmax_bwd4(s0, p0, *(const f32x4*)(lse_s + qa), *(const f32x4*)(del_s + qa), c, pa, dsa);
+            if (full)
+                softmax_bwd4(s1, p1, *(const f32x4*)(lse_s + qa + 16), *(const f32x4*)(del_s + qa + 16), c, pb, dsb);
             const bf16x8 pf = pack8(pa, pb), dsf = pack8(dsa, dsb);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -872,13 +894,19 @@ extern "C" size_t ssl4gie_attn_workspace_bytes(int dtype, int B, int N, int H, i
     return (size_t)2 * B * H * N * N * sizeof(float);  // scores + dscores
 }
 
-template <int HD, int NKT>
+// SSL4GIE_ATTN_HALF_TAIL=0: the kernels without the half-tail variants (A/B)
+static bool attn_half_tail() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SSL4GIE_ATTN_HALF_TAIL"); v = e ? atoi(e) != 0 : 1; }
+    return v != 0;
+}
+template <int HD, int NKT, bool HT>
 static int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale,
                       hipStream_t st) {
     constexpr bool QG = AttnFwdQG<HD, NKT>::value;
     const size_t lds = (size_t)(QG ? 2 : 3) * NKT * 16 * HD * 2;
     constexpr int WAVES = (!QG && 3 * NKT * 16 * HD * 2 > 80 * 1024) ? 8 : 4;
-    auto k = attn_fwd_bf16_kernel<HD, NKT, WAVES>;
+    auto k = attn_fwd_bf16_kernel<HD, NKT, WAVES, HT>;
     if (lds > 65536)
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * HD, st);
@@ -887,11 +915,11 @@ static int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int 
     LAUNCH_CHECK();
     return 0;
 }
-template <int HD, int NKT>
+template <int HD, int NKT, bool HT>
 static int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                       void* dqkv, int B, int N, int H, float scale, hipStream_t st) {
     const size_t lds = (size_t)4 * NKT * 16 * HD * 2 + 2 * NKT * 16 * sizeof(float);
-    auto k = attn_bwd_bf16_kernel<HD, NKT>;
+    auto k = attn_bwd_bf16_kernel<HD, NKT, HT>;
     if (lds > 65536)
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * HD, st);
@@ -935,16 +963,20 @@ extern "C" int ssl4gie_attn_fwd(const void* qkv, void* out, float* lse, int dtyp
         REQUIRE(N <= 256);
 // the kernels are instantiated for every even number of 16-key tiles: 16 (NKT - 2) < N <= 16 NKT,
 // so that only the last tile pair can hold padded keys (the kernels rely on it)
+#define FWD_HT(HD_, NKT_)                                                                 \
+    return (HD_ == 32 && N <= 16 * (NKT_ - 1) && attn_half_tail()) /* hd 64: the variant spills */ \
+               ? launch_fwd<HD_, NKT_, HD_ == 32>(qkv, out, lse, B, N, H, scale, st)           \
+               : launch_fwd<HD_, NKT_, false>(qkv, out, lse, B, N, H, scale, st)
 #define FWD(HD_)                                                                          \
     switch ((N + 31) >> 5) {                                                              \
-    case 1: return launch_fwd<HD_, 2>(qkv, out, lse, B, N, H, scale, st);                 \
-    case 2: return launch_fwd<HD_, 4>(qkv, out, lse, B, N, H, scale, st);                 \
-    case 3: return launch_fwd<HD_, 6>(qkv, out, lse, B, N, H, scale, st);                 \
-    case 4: return launch_fwd<HD_, 8>(qkv, out, lse, B, N, H, scale, st);                 \
-    case 5: return launch_fwd<HD_, 10>(qkv, out, lse, B, N, H, scale, st);                \
-    case 6: return launch_fwd<HD_, 12>(qkv, out, lse, B, N, H, scale, st);                \
-    case 7: return launch_fwd<HD_, 14>(qkv, out, lse, B, N, H, scale, st);                \
-    default: return launch_fwd<HD_, 16>(qkv, out, lse, B, N, H, scale, st);               \
+    case 1: FWD_HT(HD_, 2); \
+    case 2: FWD_HT(HD_, 4); \
+    case 3: FWD_HT(HD_, 6); \
+    case 4: FWD_HT(HD_, 8); \
+    case 5: FWD_HT(HD_, 10); \
+    case 6: FWD_HT(HD_, 12); \
+    case 7: FWD_HT(HD_, 14); \
+    default: FWD_HT(HD_, 16); \
     }
         if (hd == 64) { FWD(64) } else { FWD(32) }
 #undef FWD
@@ -1022,16 +1054,20 @@ extern "C" int ssl4gie_attn_bwd(const void* qkv, const void* out, const void* do
             return 0;
         }
         REQUIRE(N <= 256);
+#define BWD_HT(HD_, NKT_)                                                                          \
+    return (HD_ == 64 && N <= 16 * (NKT_ - 1) && attn_half_tail()) /* hd 32: measured no gain */   \
+               ? launch_bwd<HD_, NKT_, HD_ == 64>(qkv, out, dout, lse, dqkv, B, N, H, scale, st)   \
+               : launch_bwd<HD_, NKT_, false>(qkv, out, dout, lse, dqkv, B, N, H, scale, st)
 #define BWD(HD_)                                                                                   \
     switch ((N + 31) >> 5) {                                                                       \
-    case 1: return launch_bwd<HD_, 2>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);              \
-    case 2: return launch_bwd<HD_, 4>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);              \
-    case 3: return launch_bwd<HD_, 6>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);              \
-    case 4: return launch_bwd<HD_, 8>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);              \
-    case 5: return launch_bwd<HD_, 10>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);             \
-    case 6: return launch_bwd<HD_, 12>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);             \
-    case 7: return launch_bwd<HD_, 14>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);             \
-    default: return launch_bwd<HD_, 16>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);            \
+    case 1: BWD_HT(HD_, 2); \
+    case 2: BWD_HT(HD_, 4); \
+    case 3: BWD_HT(HD_, 6); \
+    case 4: BWD_HT(HD_, 8); \
+    case 5: BWD_HT(HD_, 10); \
+    case 6: BWD_HT(HD_, 12); \
+    case 7: BWD_HT(HD_, 14); \
+    default: BWD_HT(HD_, 16); \
     }
         if (hd == 64) { BWD(64) } else { BWD(32) }
 #undef BWD

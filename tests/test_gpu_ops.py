@@ -235,7 +235,9 @@ def test_attention_f32_path(N, H, hd):
     assert rel_err(dqkv, t.grad) < 2e-5
 
 
-@pytest.mark.parametrize("N", [50, 197, 17, 64, 65, 128, 129, 224, 256, 300, 1])
+# 1, 16, 40, 65, 129, 193, 197, 208: the last 16-key tile of the last pair is all padding (the kernels' HT variants);
+# 209: one key in it
+@pytest.mark.parametrize("N", [50, 197, 17, 64, 65, 128, 129, 224, 256, 300, 1, 16, 40, 193, 208, 209])
 @pytest.mark.parametrize("hd", [64, 32])
 def test_attention_bf16_fused(N, hd):
     from ssl4gie_amd import ops
