@@ -98,6 +98,16 @@ DEVI void softmax_bwd4(const f32x4 s, const f32x4 dp, const f32x4 l, const f32x4
     ds = f32x4{da[0], da[1], db[0], db[1]};
 }
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// Output rows leave as 16-byte pieces: a lane holds 4 consecutive columns (4 g ..) of its row in each 16-column
+// accumulator block; v_permlane16_swap between the lane groups g and g ^ 1 of two neighbouring blocks gives it 8
+// consecutive columns of one of them (gemm256.h's xpose_swap), so a row's 64 B (hd 32) are 4 stores of 16 B instead
+// of 8 of 8 B.  Call with all lanes of the wave active; the partner lanes hold the same row.
+DEVI u32x4 pair8(const f32x4 a, const f32x4 b) {
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pack_bf2(a[0], a[1]), pack_bf2(b[0], b[1]), false, false);
+    const u32x2 s2 = __builtin_amdgcn_permlane16_swap(pack_bf2(a[2], a[3]), pack_bf2(b[2], b[3]), false, false);
+    return u32x4{s1[0], s2[0], s1[1], s2[1]};
+}
+DEVI int pair8_col(int g) { return 16 * (g & 1) + 8 * (g >> 1); }  // the piece's first column inside the 32-column pair
 
 // three [n, HD] slices (Q, K, V of one head: same row stride, bases D apart) staged in one go: all
 // global loads of a thread are issued before the first LDS write, so the prologue costs one HBM
@@ -261,10 +271,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
                 o[dt] = MFMA16(tr_frag<HD>(Vimg, kp * 32, dt * 16, lane), pf, o[dt]);
         }
         const float inv = 1.0f / sum;
-        if (q < N) {
-            bf16_t* orow = out + ((size_t)b * N + q) * D + h * HD + 4 * g;
+        u32x4 ow[DT / 2];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) st4(orow + dt * 16, o[dt] * inv);
+        for (int dp = 0; dp < DT / 2; ++dp) ow[dp] = pair8(o[2 * dp] * inv, o[2 * dp + 1] * inv);
+        if (q < N) {
+            bf16_t* orow = out + ((size_t)b * N + q) * D + h * HD + pair8_col(g);
+#pragma unroll
+            for (int dp = 0; dp < DT / 2; ++dp) *(u32x4*)(orow + dp * 32) = ow[dp];
             if (g == 0) lse[((size_t)b * H + h) * N + q] = mx * scale + __logf(sum);
         }
         if (NKT <= WAVES) break;  // at most one tile per wave: not a loop
@@ -313,22 +326,33 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
     const float c = scale * LOG2E;
 
     constexpr int ATTN_BWD_WAVES = AttnBwdWaves<NKT>::value, NTH = 64 * ATTN_BWD_WAVES;
-    // ---------------- prologue: stage K, V, Q, dO; delta and lse rows
-    stage_qkv<HD, NPAD, NTH>(Kimg, Vimg, Qimg, qb + D, qb + 2 * D, qb, rs, N, tid);
-    {  // dO image + delta rows; loads first, then arithmetic and LDS writes (one HBM round trip)
+    // ---------------- prologue: stage K, V, Q, dO; delta and lse rows.  EVERY global load of the prologue is issued
+    // before the first LDS write — one HBM round trip per workgroup instead of three (Q/K/V, then dO/O, then lse:
+    // with two workgroups per CU nothing hides them, and this kernel's time follows its bytes: profiles/r04dd)
+    {
         constexpr int TOTAL = NPAD * CPR, IT = (TOTAL + NTH - 1) / NTH;  // TOTAL % 64 == 0: wave-uniform guards
-        u32x4 vv[IT], oo[IT];
+        static_assert(NTH >= NPAD, "one lse row per thread");
+        u32x4 kk[IT], vk[IT], qq[IT], vv[IT], oo[IT];
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
             const bool ok = idx < TOTAL && row < N;
-            vv[i] = ok ? *(const u32x4*)(dob + (size_t)row * D + ch * 8) : u32x4{0, 0, 0, 0};
-            oo[i] = ok ? *(const u32x4*)(ob + (size_t)row * D + ch * 8) : u32x4{0, 0, 0, 0};
+            const size_t off = (size_t)row * rs + ch * 8, offo = (size_t)row * D + ch * 8;
+            const u32x4 z = {0, 0, 0, 0};
+            kk[i] = ok ? *(const u32x4*)(qb + D + off) : z;
+            vk[i] = ok ? *(const u32x4*)(qb + 2 * D + off) : z;
+            qq[i] = ok ? *(const u32x4*)(qb + off) : z;
+            vv[i] = ok ? *(const u32x4*)(dob + offo) : z;
+            oo[i] = ok ? *(const u32x4*)(ob + offo) : z;
         }
+        const float lv = tid < N ? lrow[tid] : 0.f;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
             if (idx < TOTAL) {
+                *(u32x4*)(Kimg + img_off<HD>(row, ch)) = kk[i];
+                *(u32x4*)(Vimg + img_off<HD>(row, ch)) = vk[i];
+                *(u32x4*)(Qimg + img_off<HD>(row, ch)) = qq[i];
                 float dot = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -341,8 +365,8 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
                 if (ch == 0) del_s[row] = -dot;  // kept negated: see softmax_bwd4
             }
         }
+        if (tid < NPAD) lse_s[tid] = tid < N ? lv * LOG2E : INFINITY;  // padded queries: P = 0
     }
-    for (int i = tid; i < NPAD; i += NTH) lse_s[i] = i < N ? lrow[i] * LOG2E : INFINITY;  // padded queries: P = 0
     __syncthreads();
     const int nqt = (N + 15) >> 4;
 
@@ -396,10 +420,13 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
 #pragma unroll 1
         for (int kp = 0; kp < NKT / 2 - 1; ++kp) pairA(kp, std::integral_constant<int, 0>{});
         pairA(NKT / 2 - 1, std::integral_constant<int, HT ? 2 : 1>{});
-        if (q < N) {
-            bf16_t* r = dqb + (size_t)q * rs + 4 * g;
+        u32x4 qw[DT / 2];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) st4(r + dt * 16, dq[dt] * scale);
+        for (int dp = 0; dp < DT / 2; ++dp) qw[dp] = pair8(dq[2 * dp] * scale, dq[2 * dp + 1] * scale);
+        if (q < N) {
+            bf16_t* r = dqb + (size_t)q * rs + pair8_col(g);
+#pragma unroll
+            for (int dp = 0; dp < DT / 2; ++dp) *(u32x4*)(r + dp * 32) = qw[dp];
         }
         if (NKT <= ATTN_BWD_WAVES) break;  // at most one tile per wave: not a loop
     }
@@ -451,12 +478,18 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
                 dk[dt] = MFMA16(tr_frag<HD>(Qimg, qp * 32, dt * 16, lane), dsf, dk[dt]);
             }
         }
-        if (key < N) {
-            bf16_t* r = dqb + (size_t)key * rs + 4 * g;
+        u32x4 kw[DT / 2], vw[DT / 2];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                st4(r + D + dt * 16, dk[dt] * scale);
-                st4(r + 2 * D + dt * 16, dv[dt]);
+        for (int dp = 0; dp < DT / 2; ++dp) {
+            kw[dp] = pair8(dk[2 * dp] * scale, dk[2 * dp + 1] * scale);
+            vw[dp] = pair8(dv[2 * dp], dv[2 * dp + 1]);
+        }
+        if (key < N) {
+            bf16_t* r = dqb + (size_t)key * rs + pair8_col(g);
+#pragma unroll
+            for (int dp = 0; dp < DT / 2; ++dp) {
+                *(u32x4*)(r + D + dp * 32) = kw[dp];
+                *(u32x4*)(r + 2 * D + dp * 32) = vw[dp];
             }
         }
         if (NKT <= ATTN_BWD_WAVES) break;
