@@ -256,6 +256,14 @@ class ViTDet_FPN(EngineModule):
                                   nn.LayerNorm((out, 4 * g, 4 * g)), nn.Conv2d(out, out, 3, padding=1),
                                   nn.LayerNorm((out, 4 * g, 4 * g)))
         self.grid = g
+        # The (C, H, W) affine tables of the map LayerNorms live channels-LAST in memory — logical shape and
+        # state_dict entry unchanged, strides (1, W C, C) — which is the order the channels-last kernels read and
+        # write them in: no permuted copy of a 67 MB table per use, none of its gradient (engine.ParamArena keeps
+        # the layout when it re-homes the parameter; without it MapLayerNormFn falls back to the copies).
+        for mod in self.modules():
+            if isinstance(mod, nn.LayerNorm) and len(mod.normalized_shape) == 3:
+                for q in (mod.weight, mod.bias):
+                    q.data = q.data.permute(1, 2, 0).contiguous().permute(2, 0, 1)
 
     # ------------------------------------------------------------------ building blocks
     def _c1(self, x, conv):

@@ -48,14 +48,22 @@ class GeluMapFn(torch.autograd.Function):
         return ops.gelu_map(x, dy.contiguous())
 
 
+def _hwc(lp, p):
+    """[H, W, C] fp32 view of a (C, H, W) table: the parameter's own memory when it is stored channels-last
+    (ViTDet_FPN), else a permuted copy cached until the parameter changes"""
+    v = p.detach().permute(1, 2, 0)
+    if v.is_contiguous() and v.dtype == torch.float32:
+        return v
+    return _derived(lp, p, "mapln", torch.float32, lambda q: q.permute(1, 2, 0))
+
+
 class MapLayerNormFn(torch.autograd.Function):
     """nn.LayerNorm((C, H, W)) on a channels-last map: weight / bias are [C, H, W] parameters."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps, sink: GradSink, lp: LPCache):
         x = x.contiguous()
-        w = _derived(lp, weight, "mapln", torch.float32, lambda p: p.permute(1, 2, 0))
-        b = _derived(lp, bias, "mapln", torch.float32, lambda p: p.permute(1, 2, 0))
+        w, b = _hwc(lp, weight), _hwc(lp, bias)
         y, mean, rstd = ops.map_layernorm_fwd(x, w, b, eps)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.cfg = (sink, lp)
@@ -65,14 +73,24 @@ class MapLayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, bias, mean, rstd = ctx.saved_tensors
         sink, lp = ctx.cfg
-        w = _derived(lp, weight, "mapln", torch.float32, lambda p: p.permute(1, 2, 0))
+        w = _hwc(lp, weight)
         (tw, tb), acc, rets = sink.plan([weight, bias])
         C, H, W = weight.shape
-        dw = torch.empty(H, W, C, dtype=torch.float32, device=x.device) if tw is not None else None
-        db = torch.empty(H, W, C, dtype=torch.float32, device=x.device) if tb is not None else None
-        dx = ops.map_layernorm_bwd(x, dy.contiguous(), w, mean, rstd, dw, db)
-        if tw is not None:
-            _write_grad(tw, dw.permute(2, 0, 1), acc)
-        if tb is not None:
-            _write_grad(tb, db.permute(2, 0, 1), acc)
+
+        # the kernel writes (or accumulates into) the gradient where it belongs when that memory is channels-last
+        # already (ViTDet_FPN's tables in the arena): no [H, W, C] temporary, no permuted copy back
+        views = [t.permute(1, 2, 0) for t in (tw, tb) if t is not None]
+        direct = bool(views) and all(v.is_contiguous() for v in views)
+        if direct:
+            dw = tw.permute(1, 2, 0) if tw is not None else None
+            db = tb.permute(1, 2, 0) if tb is not None else None
+        else:
+            dw = torch.empty(H, W, C, dtype=torch.float32, device=x.device) if tw is not None else None
+            db = torch.empty(H, W, C, dtype=torch.float32, device=x.device) if tb is not None else None
+        dx = ops.map_layernorm_bwd(x, dy.contiguous(), w, mean, rstd, dw, db, accumulate=direct and acc)
+        if not direct:
+            if tw is not None:
+                _write_grad(tw, dw.permute(2, 0, 1), acc)
+            if tb is not None:
+                _write_grad(tb, db.permute(2, 0, 1), acc)
         return dx, rets[0], rets[1], None, None, None

@@ -58,11 +58,21 @@ class ParamArena:
         self._index = {}
         with torch.no_grad():
             for p, o in zip(params, self.offsets):
-                v = self.data[o:o + p.numel()].view(p.shape)
+                v = self._shaped(self.data[o:o + p.numel()], p)
                 v.copy_(p.data)
                 p.data = v
                 self._index[id(p)] = o
         self.device = dev
+
+    @staticmethod
+    def _shaped(flat, p):
+        """the slice as a tensor of p's shape; a (C, H, W) parameter stored channels-last (the map LayerNorm
+        tables of ViTDet_FPN) keeps that memory order: strides (1, W C, C).  Recognised by its strides, which
+        survive .to() / deepcopy / load_state_dict."""
+        if p.ndim == 3 and not p.is_contiguous() and p.permute(1, 2, 0).is_contiguous():
+            C, H, W = p.shape
+            return flat.view(H, W, C).permute(2, 0, 1)
+        return flat.view(p.shape)
 
     def owns(self, p) -> bool:
         o = self._index.get(id(p))
@@ -73,7 +83,7 @@ class ParamArena:
 
     def grad_view(self, p) -> torch.Tensor:
         o = self._index[id(p)]
-        return self.grad[o:o + p.numel()].view(p.shape)
+        return self._shaped(self.grad[o:o + p.numel()], p)
 
     # -- operand-type (bf16) shadow of the whole arena, refreshed in two launches ---------------
     def lp_views(self, p, dtype):

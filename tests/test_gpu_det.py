@@ -101,15 +101,23 @@ def _fpn_state(m, seed):
                 p.copy_(0.1 * torch.randn(p.shape, generator=g))
 
 
-@pytest.mark.parametrize("prec,tol,gtol", [("fp32", 1e-3, 5e-3), ("bf16", 4e-2, 1.5e-1)])
-def test_vitdet_fpn_vs_oracle(prec, tol, gtol):
+@pytest.mark.parametrize("prec,tol,gtol,arena", [("fp32", 1e-3, 5e-3, False), ("bf16", 4e-2, 1.5e-1, False),
+                                                 ("fp32", 1e-3, 5e-3, True)])
+def test_vitdet_fpn_vs_oracle(prec, tol, gtol, arena):
+    """arena: parameters and gradients re-homed into ParamArena slices (ArenaAdamW) — the (C, H, W) LayerNorm
+    tables keep their channels-last memory there and the kernels read / write them in place"""
     from oracle import det_ref
     from ssl4gie_amd.Models.models import ViTDet_FPN
     torch.manual_seed(0)
     m = ViTDet_FPN(grid=16, dim=768)
     _fpn_state(m, 7)
-    sd = {"fpn." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    sd = {"fpn." + k: v.detach().clone().contiguous().requires_grad_(True) for k, v in m.state_dict().items()}
     m.to(DEV).set_precision(prec)
+    if arena:
+        from ssl4gie_amd.optim import ArenaAdamW
+        opt = ArenaAdamW(m, list(m.parameters()), lr=1e-4)
+        w = m.fpn1[2].weight
+        assert m.arena().owns(w) and not w.is_contiguous() and w.permute(1, 2, 0).is_contiguous()
     x = torch.randn(2, 256, 768, generator=G(8))
     xd = x.to(DEV).requires_grad_(True)
     out = m(xd)
@@ -130,6 +138,9 @@ def test_vitdet_fpn_vs_oracle(prec, tol, gtol):
     for name in ("fpn1.1.weight", "fpn1.2.weight", "fpn2.3.bias", "fpn3.0.weight", "fpn4.1.weight",
                  "fpn4.3.bias", "fpn4.5.weight", "fpn4.6.weight", "fpn4.7.bias"):
         assert rel_err(pg[name].grad.cpu(), sd["fpn." + name].grad) < gtol, name
+    if arena:
+        g = m.fpn4[5].weight.grad
+        assert g.data_ptr() == m.arena().grad_view(m.fpn4[5].weight).data_ptr() and g.permute(1, 2, 0).is_contiguous()
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-3), ("bf16", 6e-2)])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which Python lines issue device copies / fills / torch arithmetic kernels in one training step?
-(torch.profiler with stacks).  usage: find_memcpy.py [mae|depth|moco]"""
+(torch.profiler with stacks).  usage: find_memcpy.py [mae|depth|moco|det]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from functools import partial
@@ -18,6 +18,16 @@ if which == "moco":
     def step():
         opt.zero_grad(set_to_none=True)
         loss = m(x1, x2, 0.99); loss.backward(); opt.step()
+elif which == "det":
+    from ssl4gie_amd.Models import models
+    from ssl4gie_amd.optim import ArenaAdamW
+    m = models.VisionTransformer_from_Any(False, 0, False, None, True, 1024, 768, 12, 12, "cls").cuda().set_precision("bf16")
+    opt = ArenaAdamW(m, [p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    x = torch.randn(2, 3, 1024, 1024, device="cuda")
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = m(x)
+        loss = sum((v * v).mean() for v in out.values()); loss.backward(); opt.step()
 elif which == "depth":
     from ssl4gie_amd.Models import models
     from ssl4gie_amd.losses import ScaleAndShiftInvariantLoss
