@@ -530,8 +530,13 @@ def bench_bt(a):
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model.to(dev).set_precision(a.precision)
     ddp = parallel.DataParallel(model) if world > 1 else None
-    opt = LARS([p for p in model.parameters() if p.requires_grad], lr=0.02 * B * world / 256,
-               weight_decay=1.5e-6, momentum=0.9)
+    if a.optim == "arena":  # the same update as one kernel over the parameter arena (as bench_moco)
+        from ssl4gie_amd.optim import ArenaLARS
+        opt = ArenaLARS(model, [p for p in model.parameters() if p.requires_grad], lr=0.02 * B * world / 256,
+                        weight_decay=1.5e-6, momentum=0.9)
+    else:
+        opt = LARS([p for p in model.parameters() if p.requires_grad], lr=0.02 * B * world / 256,
+                   weight_decay=1.5e-6, momentum=0.9)
     g = torch.Generator("cpu").manual_seed(rank)
     y1 = torch.randn(B, 3, 224, 224, generator=g).to(dev)
     y2 = (y1.cpu() + 0.5 * torch.randn(B, 3, 224, 224, generator=g)).to(dev)  # correlated views
