@@ -82,18 +82,17 @@ DEVI float group_sum(float v) {
     v += __shfl_xor(v, 16, 64);
     return v + __shfl_xor(v, 32, 64);
 }
-// P = exp2(S c - l) and dS = P (dP - delta) for four scores of a lane, in packed fp32 (v_pk_fma_f32 /
-// v_pk_add_f32 / v_pk_mul_f32 handle two values per instruction); ndl = -delta (a packed add is
-// selected, a packed subtract is not)
-DEVI void softmax_bwd4(const f32x4 s, const f32x4 dp, const f32x4 l, const f32x4 ndl, const float c,
-                       f32x4& p, f32x4& ds) {
+// P = exp2(S c - l) and dS = P dPd for four scores of a lane, in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 handle
+// two values per instruction).  dPd = dP - delta comes out of the MFMA: the dP accumulators START at -delta (del_s
+// holds the negated row sums), which costs nothing and saves a packed add per two scores in a VALU-bound kernel.
+DEVI void softmax_bwd4(const f32x4 s, const f32x4 dpd, const f32x4 l, const float c, f32x4& p, f32x4& ds) {
     const f32x2 c2 = {c, c};
     f32x2 a = f32x2{s[0], s[1]} * c2 - f32x2{l[0], l[1]};
     f32x2 b = f32x2{s[2], s[3]} * c2 - f32x2{l[2], l[3]};
     a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
     b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
-    const f32x2 da = a * (f32x2{dp[0], dp[1]} + f32x2{ndl[0], ndl[1]});
-    const f32x2 db = b * (f32x2{dp[2], dp[3]} + f32x2{ndl[2], ndl[3]});
+    const f32x2 da = a * f32x2{dpd[0], dpd[1]};
+    const f32x2 db = b * f32x2{dpd[2], dpd[3]};
     p = f32x4{a[0], a[1], b[0], b[1]};
     ds = f32x4{da[0], da[1], db[0], db[1]};
 }
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
         // tile is all padding (HT): one tile's worth of scores, the other half of dS^T is zero
         auto pairA = [&](const int kp, auto modec) {
             constexpr int MODE = decltype(modec)::value;
-            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = dl4, p1 = dl4;  // dP - delta (softmax_bwd4)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s0 = MFMA16(row_frag<HD>(Kimg, kp * 32, ks, lane), qf[ks], s0);
@@ -401,8 +400,8 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
                 }
             }
             f32x4 pa, pb, dsa, dsb = {0, 0, 0, 0};
-            softmax_bwd4(s0, p0, l4, dl4, c, pa, dsa);
-            if constexpr (MODE != 2) softmax_bwd4(s1, p1, l4, dl4, c, pb, dsb);
+            softmax_bwd4(s0, p0, l4, c, pa, dsa);
+            if constexpr (MODE != 2) softmax_bwd4(s1, p1, l4, c, pb, dsb);
             if constexpr (MODE != 0) {
                 const int ka = kp * 32 + 4 * g;
 #pragma unroll
@@ -451,7 +450,9 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
 #pragma unroll 1
         for (int qp = 0; qp < NKT / 2; ++qp) {
             const bool full = !HT || qp < NKT / 2 - 1;
-            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+            const int qa = qp * 32 + 4 * g;
+            // the dP accumulators start at -delta of their query rows (softmax_bwd4)
+            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = *(const f32x4*)(del_s + qa), p1 = *(const f32x4*)(del_s + qa + 16);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s0 = MFMA16(row_frag<HD>(Qimg, qp * 32, ks, lane), kf[ks], s0);
@@ -466,11 +467,9 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
             }
             // lane holds S[q = qp*32 (+16) + 4g + r][key]; p0/p1 hold dP.  Padded queries carry
             // lse = +inf (P = 0) and zero dO / delta rows, so they need no mask here.
-            const int qa = qp * 32 + 4 * g;
             f32x4 pa, pb = {0, 0, 0, 0}, dsa, dsb = {0, 0, 0, 0};
-            softmax_bwd4(s0, p0, *(const f32x4*)(lse_s + qa), *(const f32x4*)(del_s + qa), c, pa, dsa);
-            if (full)
-                softmax_bwd4(s1, p1, *(const f32x4*)(lse_s + qa + 16), *(const f32x4*)(del_s + qa + 16), c, pb, dsb);
+            softmax_bwd4(s0, p0, *(const f32x4*)(lse_s + qa), c, pa, dsa);
+            if (full) softmax_bwd4(s1, p1, *(const f32x4*)(lse_s + qa + 16), c, pb, dsb);
             const bf16x8 pf = pack8(pa, pb), dsf = pack8(dsa, dsb);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
