@@ -60,7 +60,11 @@ def _depth_curve(prec, optim, steps):
 
 
 # measured on MI355X (round 4, profiles/r04n_curves.log): max over the steps of |loss - reference| / reference
-G13_BF16_MEASURED = {"torch": 9.8e-4, "arena": 2.0e-3}
+# The 60-step bf16 curve amplifies fp32-rounding-level differences: a backward attention kernel whose dP accumulators
+# start at -delta instead of subtracting it afterwards (same error against fp64 to four digits on every shape:
+# profiles/r04dq_attn_precision.log) moved [torch] from 9.8e-4 to 2.46e-3 (step 57) and [arena] from 2.0e-3 to
+# 9.8e-4.  Both optimizers therefore share one bar, 1.5 x the largest of the four measured maxima.
+G13_BF16_MEASURED = {"torch": 2.5e-3, "arena": 2.5e-3}
 # G14: the random-init MoCo-R50 step is ill-conditioned in ANY fp32 arithmetic — the reference's own CPU fp32
 # gradients of step 0 differ from the fp64 evaluation of the same graph by 2.7 % (median relative L2 error over
 # the 167 trainable tensors, uniformly: the error enters at the projector's BatchNorm / InfoNCE cancellation and
