@@ -245,21 +245,31 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
         }
         mx = group_max(mx);
         const f32x2 nmc2 = {-mx * c, -mx * c};
+        // hd 32: the row sums come out of the matrix pipe — one more product per key pair against an all-ones operand
+        // gives sum_k P[k][q] in every row of a 16 x 16 tile (a lane reads its query's sum from element 0): no packed
+        // adds per score, no cross-lane reduction, in a kernel bound by its VALU stream (N = 197: 27 + 7 products
+        // against ~160 VALU instructions per query tile; forward 59.8 -> 56.5 us, N = 224 72.5 -> 65.6 same-box,
+        // profiles/r04ds).  That sum is the one of the bf16-rounded probabilities, i.e. of exactly the values
+        // O^T = V^T P^T is accumulated from.  hd 64 has twice the products per score and no slack for it (N = 256:
+        // 29.5 -> 31.0 us): it keeps the packed fp32 adds.
+        constexpr bool MSUM = HD == 32;
         f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < NKC; ++kt) {  // packed fp32: one v_pk_fma / v_pk_add per two scores
+        for (int kt = 0; kt < NKC; ++kt) {  // packed fp32: one v_pk_fma (/ v_pk_add) per two scores
             f32x2 a = {s[kt][0], s[kt][1]}, bq = {s[kt][2], s[kt][3]};
             a = a * c2 + nmc2;
             bq = bq * c2 + nmc2;
             a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
             bq[0] = __builtin_amdgcn_exp2f(bq[0]); bq[1] = __builtin_amdgcn_exp2f(bq[1]);
-            sum2 += a;
-            sum2 += bq;
+            if constexpr (!MSUM) {
+                sum2 += a;
+                sum2 += bq;
+            }
             s[kt] = f32x4{a[0], a[1], bq[0], bq[1]};
         }
-        float sum = sum2[0] + sum2[1];
-        sum = group_sum(sum);
-        f32x4 o[DT];
+        const __bf16 one = (__bf16)1.0f;
+        const bf16x8 ones = {one, one, one, one, one, one, one, one};
+        f32x4 o[DT], osum = {0, 0, 0, 0};
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -268,7 +278,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
                 o[dt] = MFMA16(tr_frag<HD>(Vimg, kp * 32, dt * 16, lane), pf, o[dt]);
+            if constexpr (MSUM) osum = MFMA16(ones, pf, osum);
         }
+        float sum = osum[0];
+        if constexpr (!MSUM) sum = group_sum(sum2[0] + sum2[1]);
         const float inv = 1.0f / sum;
         u32x4 ow[DT / 2];
 #pragma unroll
