@@ -131,20 +131,23 @@ DEVI void bl_src(int d, int n_in, int n_out, int& i0, int& i1, float& w1) {
     i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
     w1 = s - (float)i0;
 }
+// Grid (x chunks, output / input row, image): the row and the image come from the block index, so a thread's
+// index arithmetic is one 32-bit division (the flat form spent four 64-bit divisions per 16-byte store and ran at
+// half of the HBM rate: profiles/r04dw) and the vertical taps / weights are uniform over the block.
 template <typename T>
-__global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
-                                      int W, int C, long long total) {
+__global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H,
+                                                             int W, int C) {
     constexpr int V = Vec<T>::N;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int cpr = C / V, Ho = 2 * H, Wo = 2 * W;
-    const long long p = idx / cpr;
-    const int c = (int)(idx % cpr) * V;
-    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((long long)Wo * Ho));
+    const unsigned cpr = (unsigned)(C / V), Ho = 2 * H, Wo = 2 * W;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned ox = t / cpr;
+    if (ox >= Wo) return;
+    const int c = (int)(t - ox * cpr) * V;
+    const int oy = blockIdx.y, b = blockIdx.z;
     int y0, y1, x0, x1;
     float wy, wx;
     bl_src(oy, H, Ho, y0, y1, wy);
-    bl_src(ox, W, Wo, x0, x1, wx);
+    bl_src((int)ox, W, Wo, x0, x1, wx);
     const T* base = x + (size_t)b * H * W * C + c;
     float f00[V], f01[V], f10[V], f11[V], o[V];
     unpack<T>(*(const typename Vec<T>::raw*)(base + ((size_t)y0 * W + x0) * C), f00);
@@ -158,25 +161,40 @@ __global__ void bilinear2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y
         const float bot = f10[j] * (1.f - wx) + f11[j] * wx;
         o[j] = top * (1.f - wy) + bot * wy;
     }
-    *(typename Vec<T>::raw*)(y + (size_t)p * C + c) = pack<T>(o);
+    *(typename Vec<T>::raw*)(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c) = pack<T>(o);
 }
-// backward in gather form: an input pixel collects from every output pixel whose two taps include it
+// backward in gather form: an input pixel collects from every output pixel whose two taps include it, in the
+// order (output row, output column) of the candidates.  The column coefficients are computed once per thread (not
+// once per candidate row), the row coefficients are uniform over the block.
 template <typename T>
-__global__ void bilinear2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H,
-                                      int W, int C, long long total) {
+__global__ __launch_bounds__(256) void bilinear2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H,
+                                                             int W, int C) {
     constexpr int V = Vec<T>::N;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int cpr = C / V, Ho = 2 * H, Wo = 2 * W;
-    const long long p = idx / cpr;
-    const int c = (int)(idx % cpr) * V;
-    const int ix = (int)(p % W), iy = (int)((p / W) % H), b = (int)(p / ((long long)W * H));
+    const unsigned cpr = (unsigned)(C / V);
+    const int Ho = 2 * H, Wo = 2 * W;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned uix = t / cpr;
+    if (uix >= (unsigned)W) return;
+    const int ix = (int)uix, c = (int)(t - uix * cpr) * V;
+    const int iy = blockIdx.y, b = blockIdx.z;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
     // candidate output rows / columns: src within (i - 1, i + 1)  ->  o in about [2i - 2, 2i + 3]
     const int oy_lo = 2 * iy - 3 > 0 ? 2 * iy - 3 : 0, oy_hi = 2 * iy + 3 < Ho - 1 ? 2 * iy + 3 : Ho - 1;
     const int ox_lo = 2 * ix - 3 > 0 ? 2 * ix - 3 : 0, ox_hi = 2 * ix + 3 < Wo - 1 ? 2 * ix + 3 : Wo - 1;
+    float cxs[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int ox = ox_lo + k;
+        int x0, x1;
+        float wx;
+        bl_src(ox <= ox_hi ? ox : ox_hi, W, Wo, x0, x1, wx);
+        float cx = 0.f;
+        if (x0 == ix) cx += 1.f - wx;
+        if (x1 == ix) cx += wx;
+        cxs[k] = ox <= ox_hi ? cx : 0.f;
+    }
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
         int y0, y1;
         float wy;
@@ -185,22 +203,19 @@ __global__ void bilinear2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ 
         if (y0 == iy) cy += 1.f - wy;
         if (y1 == iy) cy += wy;
         if (cy == 0.f) continue;
-        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-            int x0, x1;
-            float wx;
-            bl_src(ox, W, Wo, x0, x1, wx);
-            float cx = 0.f;
-            if (x0 == ix) cx += 1.f - wx;
-            if (x1 == ix) cx += wx;
+        const T* row = dy + (((size_t)b * Ho + oy) * Wo + ox_lo) * C + c;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float cx = cxs[k];
             if (cx == 0.f) continue;
             float f[V];
-            unpack<T>(*(const typename Vec<T>::raw*)(dy + (((size_t)b * Ho + oy) * Wo + ox) * C + c), f);
+            unpack<T>(*(const typename Vec<T>::raw*)(row + (size_t)k * C), f);
             const float w = cy * cx;
 #pragma unroll
             for (int j = 0; j < V; ++j) acc[j] += w * f[j];
         }
     }
-    *(typename Vec<T>::raw*)(dx + (size_t)p * C + c) = pack<T>(acc);
+    *(typename Vec<T>::raw*)(dx + (((size_t)b * H + iy) * W + ix) * C + c) = pack<T>(acc);
 }
 
 // ------------------------------------------------------------------ ConvTranspose2d(k = s) scatter
@@ -409,16 +424,28 @@ extern "C" int ssl4gie_bilinear2x_fwd(const void* x, void* y, int dtype, int B, 
                                       void* stream) {
     REQUIRE(x && y && dt_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && C % vecn(dtype) == 0);
     hipStream_t st = (hipStream_t)stream;
-    const long long total = (long long)B * 4 * H * W * (C / vecn(dtype));
-    DPT_LAUNCH(dtype, bilinear2x_fwd_kernel, total, (const T*)x, (T*)y, B, H, W, C, total);
+    REQUIRE(2 * H <= 65535 && B <= 65535);
+    const unsigned per_row = (unsigned)(2 * W) * (unsigned)(C / vecn(dtype));
+    const dim3 grid((per_row + 255) / 256, 2 * H, B), block(256);
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(bilinear2x_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, H, W, C);
+    else
+        hipLaunchKernelGGL(bilinear2x_fwd_kernel<float>, grid, block, 0, st, (const float*)x, (float*)y, H, W, C);
+    LAUNCH_CHECK();
     return 0;
 }
 extern "C" int ssl4gie_bilinear2x_bwd(const void* dy, void* dx, int dtype, int B, int H, int W,
                                       int C, void* stream) {
     REQUIRE(dy && dx && dt_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && C % vecn(dtype) == 0);
     hipStream_t st = (hipStream_t)stream;
-    const long long total = (long long)B * H * W * (C / vecn(dtype));
-    DPT_LAUNCH(dtype, bilinear2x_bwd_kernel, total, (const T*)dy, (T*)dx, B, H, W, C, total);
+    REQUIRE(H <= 65535 && B <= 65535);
+    const unsigned per_row = (unsigned)W * (unsigned)(C / vecn(dtype));
+    const dim3 grid((per_row + 255) / 256, H, B), block(256);
+    if (dtype == SSL4GIE_BF16)
+        hipLaunchKernelGGL(bilinear2x_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy, (bf16_t*)dx, H, W, C);
+    else
+        hipLaunchKernelGGL(bilinear2x_bwd_kernel<float>, grid, block, 0, st, (const float*)dy, (float*)dx, H, W, C);
+    LAUNCH_CHECK();
     return 0;
 }
 extern "C" int ssl4gie_pixel_shuffle(const void* g, const float* bias, void* y, int dtype, int B,
