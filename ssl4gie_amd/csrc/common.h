@@ -50,6 +50,31 @@ DEVI f32x4 ld4(const bf16_t* p) {
     o[3] = __uint_as_float(r[1] & 0xffff0000u);
     return o;
 }
+// flat work-item index -> (channel vector, x, y, image) of an NHWC map with cpr vectors per pixel.  The 64-bit
+// divisions of the general form cost more than the rest of a 16-byte-per-thread kernel (the bilinear kernels ran at
+// half of the HBM rate because of them: profiles/r04dw); whenever the item count fits 32 bits — every map of the
+// bench configurations — three unsigned 32-bit divisions do.  `total` is uniform, so is the branch.
+struct MapIdx { int cv, x, y; long long b, p; };
+DEVI MapIdx map_index(long long idx, long long total, int cpr, int W, int H) {
+    MapIdx m;
+    if (total <= 0xffffffffLL) {
+        const unsigned i = (unsigned)idx, p = i / (unsigned)cpr, q = p / (unsigned)W;
+        m.cv = (int)(i - p * (unsigned)cpr);
+        m.x = (int)(p - q * (unsigned)W);
+        const unsigned b = q / (unsigned)H;
+        m.y = (int)(q - b * (unsigned)H);
+        m.b = b;
+        m.p = p;
+    } else {
+        const long long p = idx / cpr, q = p / W;
+        m.cv = (int)(idx - p * cpr);
+        m.x = (int)(p - q * W);
+        m.b = q / H;
+        m.y = (int)(q - m.b * H);
+        m.p = p;
+    }
+    return m;
+}
 DEVI void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
 DEVI void st4(bf16_t* p, f32x4 v) {
     u32x2 r;

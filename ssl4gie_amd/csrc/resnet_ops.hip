@@ -592,11 +592,9 @@ __global__ void maxpool_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ 
     typedef typename V16<T>::raw raw_t;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int cpr = C / V;
-    const int c = (int)(idx % cpr) * V;
-    const long long p = idx / cpr;
-    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
-    const long long b = p / ((long long)Wo * Ho);
+    const MapIdx mi = map_index(idx, total, C / V, Wo, Ho);
+    const int c = mi.cv * V, ox = mi.x, oy = mi.y;
+    const long long p = mi.p, b = mi.b;
     float best[V];
     unsigned char bi[V];
 #pragma unroll
@@ -652,11 +650,9 @@ __global__ void maxpool_bwd_vec_kernel(const T* __restrict__ dy, const unsigned 
     typedef typename V16<T>::raw raw_t;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int cpr = C / V;
-    const int c = (int)(idx % cpr) * V;
-    const long long p = idx / cpr;
-    const int x = (int)(p % W), y = (int)((p / W) % H);
-    const long long b = p / ((long long)W * H);
+    const MapIdx mi = map_index(idx, total, C / V, W, H);
+    const int c = mi.cv * V, x = mi.x, y = mi.y;
+    const long long p = mi.p, b = mi.b;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
