@@ -125,6 +125,39 @@ def test_param_arena_and_grad_sink_cpu():
     assert tg3[1] is None and rets3[1] is None and tg3[0] is not None
 
 
+def test_channels_last_layernorm_tables_keep_their_layout_cpu():
+    """ViTDet_FPN stores its (C, H, W) LayerNorm tables channels-last (Models/models.py); state_dict entries keep
+    the reference's shapes and values, and ParamArena re-homes parameter AND gradient with the same strides, so the
+    kernels' [H, W, C] views alias the arena memory (no permuted copies: profiles/r04dm)"""
+    import copy
+    from ssl4gie_amd.Models.models import ViTDet_FPN
+    torch.manual_seed(0)
+    f = ViTDet_FPN(grid=8, dim=64, out=32)
+    tables = [p for m in f.modules() if isinstance(m, nn.LayerNorm) for p in (m.weight, m.bias)]
+    assert len(tables) == 18 and all(p.ndim == 3 for p in tables)
+    assert all(not p.is_contiguous() and p.permute(1, 2, 0).is_contiguous() for p in tables)
+    sd = {k: torch.randn(v.shape) for k, v in f.state_dict().items()}  # contiguous, as a reference checkpoint holds them
+    f.load_state_dict(sd)
+    assert all(torch.equal(v, sd[k]) and v.shape == sd[k].shape for k, v in f.state_dict().items())
+    g = copy.deepcopy(f)  # the layout is recognised by strides: it survives deepcopy / .to()
+    for mod in (f, g):
+        ps = list(mod.parameters())
+        a = engine.ParamArena(ps)
+        assert a.intact() and all(torch.equal(v, sd[k]) for k, v in mod.state_dict().items())
+        for p in ps:
+            gv = a.grad_view(p)
+            assert gv.shape == p.shape and gv.stride() == p.stride()
+            if p.ndim == 3:
+                hwc = p.detach().permute(1, 2, 0)
+                assert hwc.is_contiguous() and hwc.data_ptr() == p.data_ptr()
+                assert gv.permute(1, 2, 0).is_contiguous()
+        # a write through the [H, W, C] view of the gradient slice is the gradient in the parameter's own shape
+        w = [p for p in ps if p.ndim == 3][0]
+        gv = a.grad_view(w)
+        gv.permute(1, 2, 0).copy_(torch.arange(w.numel(), dtype=torch.float32).view(w.shape[1], w.shape[2], w.shape[0]))
+        assert float(gv[3, 1, 2]) == float((1 * w.shape[2] + 2) * w.shape[0] + 3)
+
+
 def test_lds_swizzles_are_conflict_free():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import lds_bank_sim as sim
