@@ -308,9 +308,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : (HD == 32 && NKT <= 1
 template <int NKT> struct AttnBwdWaves {
     static constexpr int value = NKT <= 4 ? 4 : (NKT <= 8 ? NKT : NKT / 2);
 };
+// tiles a wave works on at once (see "U tiles per wave" in the kernel): 2 where the LDS images leave room for one
+// workgroup per CU anyway, i.e. hd 64 from 10 tiles on (4 images x 160 rows x 128 B = 80 KB)
+template <int HD, int NKT> struct AttnBwdU { static constexpr int value = (HD == 64 && NKT >= 10) ? 2 : 1; };
 // HT as in the forward kernel: the last pair of key tiles (phase A) / query tiles (phase B) is a single tile
 template <int HD, int NKT, bool HT>
-__global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf16_kernel(
+__global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, (AttnBwdU<HD, NKT>::value == 2 ? 2 : 4)) void attn_bwd_bf16_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
     int N, int H, float scale) {
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
     const float c = scale * LOG2E;
 
     constexpr int ATTN_BWD_WAVES = AttnBwdWaves<NKT>::value, NTH = 64 * ATTN_BWD_WAVES;
+    constexpr int BWD_U = AttnBwdU<HD, NKT>::value;
     // ---------------- prologue: stage K, V, Q, dO; delta and lse rows.  EVERY global load of the prologue is issued
     // before the first LDS write — one HBM round trip per workgroup instead of three (Q/K/V, then dO/O, then lse:
     // with two workgroups per CU nothing hides them, and this kernel's time follows its bytes: profiles/r04dd)
@@ -382,81 +386,132 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
     __syncthreads();
     const int nqt = (N + 15) >> 4;
 
+    // U tiles per wave AT ONCE (register blocking).  hd 64 above 144 tokens needs > 80 KB of LDS: one workgroup per
+    // CU, two waves per SIMD at most — 256 VGPRs are there for the taking, and the kernel is bound by its LDS reads
+    // (12 KB of fragments per key pair and query tile in phase A, 20 KB in phase B: an LDS floor of ~117 us at
+    // N = 197 against 51 us of MFMA).  With its two tiles in flight together a wave reads every K / V (Q / dO)
+    // fragment, transposed fragment and statistics row once for both: half the LDS traffic, and two independent
+    // dependency chains per wave where two waves per SIMD hide little.
+    constexpr int U = BWD_U;
     // ---------------- phase A: dQ (waves own query tiles)
-    for (int qt = wave; qt < nqt; qt += ATTN_BWD_WAVES) {
-        const int q = qt * 16 + (lane & 15);
-        bf16x8 qf[KS], dof[KS];
+    for (int qt0 = wave; qt0 < nqt; qt0 += ATTN_BWD_WAVES * U) {
+        int qt[U];
+        bool live[U];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = row_frag<HD>(Qimg, qt * 16, ks, lane);
-            dof[ks] = row_frag<HD>(Oimg, qt * 16, ks, lane);
+        for (int u = 0; u < U; ++u) {
+            live[u] = qt0 + u * ATTN_BWD_WAVES < nqt;
+            qt[u] = live[u] ? qt0 + u * ATTN_BWD_WAVES : qt0;  // a dead slot repeats tile 0's work and stores nothing
         }
-        const float dl = del_s[q];
-        const float l2 = lse_s[q];
-        // dS^T needs only the saved row statistics, so key tiles are consumed pair by pair
-        const f32x4 l4 = {l2, l2, l2, l2}, dl4 = {dl, dl, dl, dl};
-        f32x4 dq[DT];
+        bf16x8 qf[U][KS], dof[U][KS];
+        f32x4 l4[U], dl4[U], dq[U][DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qf[u][ks] = row_frag<HD>(Qimg, qt[u] * 16, ks, lane);
+                dof[u][ks] = row_frag<HD>(Oimg, qt[u] * 16, ks, lane);
+            }
+            const float dl = del_s[qt[u] * 16 + (lane & 15)];
+            const float l2 = lse_s[qt[u] * 16 + (lane & 15)];
+            // dS^T needs only the saved row statistics, so key tiles are consumed pair by pair
+            l4[u] = f32x4{l2, l2, l2, l2};
+            dl4[u] = f32x4{dl, dl, dl, dl};
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dq[u][dt] = f32x4{0, 0, 0, 0};
+        }
         // MODE 0: a pair of full tiles; 1: the last pair, padded keys masked; 2: the last pair when its second
         // tile is all padding (HT): one tile's worth of scores, the other half of dS^T is zero
         auto pairA = [&](const int kp, auto modec) {
             constexpr int MODE = decltype(modec)::value;
-            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = dl4, p1 = dl4;  // dP - delta (softmax_bwd4)
+            f32x4 s0[U], s1[U], p0[U], p1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                s0[u] = s1[u] = f32x4{0, 0, 0, 0};
+                p0[u] = p1[u] = dl4[u];  // dP - delta (softmax_bwd4)
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s0 = MFMA16(row_frag<HD>(Kimg, kp * 32, ks, lane), qf[ks], s0);
-                p0 = MFMA16(row_frag<HD>(Vimg, kp * 32, ks, lane), dof[ks], p0);
+                const bf16x8 k0 = row_frag<HD>(Kimg, kp * 32, ks, lane), v0 = row_frag<HD>(Vimg, kp * 32, ks, lane);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    s0[u] = MFMA16(k0, qf[u][ks], s0[u]);
+                    p0[u] = MFMA16(v0, dof[u][ks], p0[u]);
+                }
                 if constexpr (MODE != 2) {
-                    s1 = MFMA16(row_frag<HD>(Kimg, kp * 32 + 16, ks, lane), qf[ks], s1);
-                    p1 = MFMA16(row_frag<HD>(Vimg, kp * 32 + 16, ks, lane), dof[ks], p1);
+                    const bf16x8 k1 = row_frag<HD>(Kimg, kp * 32 + 16, ks, lane),
+                                 v1 = row_frag<HD>(Vimg, kp * 32 + 16, ks, lane);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        s1[u] = MFMA16(k1, qf[u][ks], s1[u]);
+                        p1[u] = MFMA16(v1, dof[u][ks], p1[u]);
+                    }
                 }
             }
-            f32x4 pa, pb, dsa, dsb = {0, 0, 0, 0};
-            softmax_bwd4(s0, p0, l4, c, pa, dsa);
-            if constexpr (MODE != 2) softmax_bwd4(s1, p1, l4, c, pb, dsb);
-            if constexpr (MODE != 0) {
-                const int ka = kp * 32 + 4 * g;
+            bf16x8 dsf[U];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dsa[r] = (ka + r < N) ? dsa[r] : 0.f;
-                    if constexpr (MODE == 1) dsb[r] = (ka + 16 + r < N) ? dsb[r] : 0.f;
+            for (int u = 0; u < U; ++u) {
+                f32x4 pa, pb, dsa, dsb = {0, 0, 0, 0};
+                softmax_bwd4(s0[u], p0[u], l4[u], c, pa, dsa);
+                if constexpr (MODE != 2) softmax_bwd4(s1[u], p1[u], l4[u], c, pb, dsb);
+                if constexpr (MODE != 0) {
+                    const int ka = kp * 32 + 4 * g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dsa[r] = (ka + r < N) ? dsa[r] : 0.f;
+                        if constexpr (MODE == 1) dsb[r] = (ka + 16 + r < N) ? dsb[r] : 0.f;
+                    }
                 }
+                dsf[u] = pack8(dsa, dsb);
             }
-            const bf16x8 dsf = pack8(dsa, dsb);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                dq[dt] = MFMA16(tr_frag<HD>(Kimg, kp * 32, dt * 16, lane), dsf, dq[dt]);
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 kt_ = tr_frag<HD>(Kimg, kp * 32, dt * 16, lane);
+#pragma unroll
+                for (int u = 0; u < U; ++u) dq[u][dt] = MFMA16(kt_, dsf[u], dq[u][dt]);
+            }
         };
         // 16 (NKT - 2) < N: padded keys only in the last pair, which is peeled
 #pragma unroll 1
         for (int kp = 0; kp < NKT / 2 - 1; ++kp) pairA(kp, std::integral_constant<int, 0>{});
         pairA(NKT / 2 - 1, std::integral_constant<int, HT ? 2 : 1>{});
-        u32x4 qw[DT / 2];
 #pragma unroll
-        for (int dp = 0; dp < DT / 2; ++dp) qw[dp] = pair8(dq[2 * dp] * scale, dq[2 * dp + 1] * scale);
-        if (q < N) {
-            bf16_t* r = dqb + (size_t)q * rs + pair8_col(g);
+        for (int u = 0; u < U; ++u) {
+            const int q = qt[u] * 16 + (lane & 15);
+            u32x4 qw[DT / 2];
 #pragma unroll
-            for (int dp = 0; dp < DT / 2; ++dp) *(u32x4*)(r + dp * 32) = qw[dp];
+            for (int dp = 0; dp < DT / 2; ++dp) qw[dp] = pair8(dq[u][2 * dp] * scale, dq[u][2 * dp + 1] * scale);
+            if (live[u] && q < N) {
+                bf16_t* r = dqb + (size_t)q * rs + pair8_col(g);
+#pragma unroll
+                for (int dp = 0; dp < DT / 2; ++dp) *(u32x4*)(r + dp * 32) = qw[dp];
+            }
         }
-        if (NKT <= ATTN_BWD_WAVES) break;  // at most one tile per wave: not a loop
+        if (NKT <= ATTN_BWD_WAVES * U) break;  // at most U tiles per wave: not a loop
     }
 
     // ---------------- phase B: dK, dV (waves own key tiles); same LDS images, no restaging
-    for (int kt = wave; kt < nqt; kt += ATTN_BWD_WAVES) {
-        const int key = kt * 16 + (lane & 15);
-        bf16x8 kf[KS], vf[KS];
+    for (int kt0 = wave; kt0 < nqt; kt0 += ATTN_BWD_WAVES * U) {
+        int kt[U];
+        bool live[U];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = row_frag<HD>(Kimg, kt * 16, ks, lane);
-            vf[ks] = row_frag<HD>(Vimg, kt * 16, ks, lane);
+        for (int u = 0; u < U; ++u) {
+            live[u] = kt0 + u * ATTN_BWD_WAVES < nqt;
+            kt[u] = live[u] ? kt0 + u * ATTN_BWD_WAVES : kt0;
         }
-        f32x4 dk[DT], dv[DT];
+        bf16x8 kf[U][KS], vf[U][KS];
+        f32x4 dk[U][DT], dv[U][DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            dk[dt] = f32x4{0, 0, 0, 0};
-            dv[dt] = f32x4{0, 0, 0, 0};
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kf[u][ks] = row_frag<HD>(Kimg, kt[u] * 16, ks, lane);
+                vf[u][ks] = row_frag<HD>(Vimg, kt[u] * 16, ks, lane);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dk[u][dt] = f32x4{0, 0, 0, 0};
+                dv[u][dt] = f32x4{0, 0, 0, 0};
+            }
         }
         // HT: the last pair's second query tile is all padding — its scores are skipped (a wave-uniform branch, not
         // a peeled copy of the body: the copy costs registers and spills at hd 64) and its P / dS are zeros
@@ -465,46 +520,76 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 4) void attn_bwd_bf1
             const bool full = !HT || qp < NKT / 2 - 1;
             const int qa = qp * 32 + 4 * g;
             // the dP accumulators start at -delta of their query rows (softmax_bwd4)
-            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, p0 = *(const f32x4*)(del_s + qa), p1 = *(const f32x4*)(del_s + qa + 16);
+            const f32x4 da = *(const f32x4*)(del_s + qa), db = *(const f32x4*)(del_s + qa + 16);
+            const f32x4 la = *(const f32x4*)(lse_s + qa), lb = *(const f32x4*)(lse_s + qa + 16);
+            f32x4 s0[U], s1[U], p0[U], p1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                s0[u] = s1[u] = f32x4{0, 0, 0, 0};
+                p0[u] = da;
+                p1[u] = db;
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s0 = MFMA16(row_frag<HD>(Qimg, qp * 32, ks, lane), kf[ks], s0);
-                p0 = MFMA16(row_frag<HD>(Oimg, qp * 32, ks, lane), vf[ks], p0);
+                const bf16x8 q0 = row_frag<HD>(Qimg, qp * 32, ks, lane), o0 = row_frag<HD>(Oimg, qp * 32, ks, lane);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    s0[u] = MFMA16(q0, kf[u][ks], s0[u]);
+                    p0[u] = MFMA16(o0, vf[u][ks], p0[u]);
+                }
             }
             if (full) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    s1 = MFMA16(row_frag<HD>(Qimg, qp * 32 + 16, ks, lane), kf[ks], s1);
-                    p1 = MFMA16(row_frag<HD>(Oimg, qp * 32 + 16, ks, lane), vf[ks], p1);
+                    const bf16x8 q1 = row_frag<HD>(Qimg, qp * 32 + 16, ks, lane),
+                                 o1 = row_frag<HD>(Oimg, qp * 32 + 16, ks, lane);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        s1[u] = MFMA16(q1, kf[u][ks], s1[u]);
+                        p1[u] = MFMA16(o1, vf[u][ks], p1[u]);
+                    }
                 }
             }
             // lane holds S[q = qp*32 (+16) + 4g + r][key]; p0/p1 hold dP.  Padded queries carry
             // lse = +inf (P = 0) and zero dO / delta rows, so they need no mask here.
-            f32x4 pa, pb = {0, 0, 0, 0}, dsa, dsb = {0, 0, 0, 0};
-            softmax_bwd4(s0, p0, *(const f32x4*)(lse_s + qa), c, pa, dsa);
-            if (full) softmax_bwd4(s1, p1, *(const f32x4*)(lse_s + qa + 16), c, pb, dsb);
-            const bf16x8 pf = pack8(pa, pb), dsf = pack8(dsa, dsb);
+            bf16x8 pf[U], dsf[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                f32x4 pa, pb = {0, 0, 0, 0}, dsa, dsb = {0, 0, 0, 0};
+                softmax_bwd4(s0[u], p0[u], la, c, pa, dsa);
+                if (full) softmax_bwd4(s1[u], p1[u], lb, c, pb, dsb);
+                pf[u] = pack8(pa, pb);
+                dsf[u] = pack8(dsa, dsb);
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                dv[dt] = MFMA16(tr_frag<HD>(Oimg, qp * 32, dt * 16, lane), pf, dv[dt]);
-                dk[dt] = MFMA16(tr_frag<HD>(Qimg, qp * 32, dt * 16, lane), dsf, dk[dt]);
+                const bf16x8 ot = tr_frag<HD>(Oimg, qp * 32, dt * 16, lane), qt_ = tr_frag<HD>(Qimg, qp * 32, dt * 16, lane);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    dv[u][dt] = MFMA16(ot, pf[u], dv[u][dt]);
+                    dk[u][dt] = MFMA16(qt_, dsf[u], dk[u][dt]);
+                }
             }
         }
-        u32x4 kw[DT / 2], vw[DT / 2];
 #pragma unroll
-        for (int dp = 0; dp < DT / 2; ++dp) {
-            kw[dp] = pair8(dk[2 * dp] * scale, dk[2 * dp + 1] * scale);
-            vw[dp] = pair8(dv[2 * dp], dv[2 * dp + 1]);
-        }
-        if (key < N) {
-            bf16_t* r = dqb + (size_t)key * rs + pair8_col(g);
+        for (int u = 0; u < U; ++u) {
+            const int key = kt[u] * 16 + (lane & 15);
+            u32x4 kw[DT / 2], vw[DT / 2];
 #pragma unroll
             for (int dp = 0; dp < DT / 2; ++dp) {
-                *(u32x4*)(r + D + dp * 32) = kw[dp];
-                *(u32x4*)(r + 2 * D + dp * 32) = vw[dp];
+                kw[dp] = pair8(dk[u][2 * dp] * scale, dk[u][2 * dp + 1] * scale);
+                vw[dp] = pair8(dv[u][2 * dp], dv[u][2 * dp + 1]);
+            }
+            if (live[u] && key < N) {
+                bf16_t* r = dqb + (size_t)key * rs + pair8_col(g);
+#pragma unroll
+                for (int dp = 0; dp < DT / 2; ++dp) {
+                    *(u32x4*)(r + D + dp * 32) = kw[dp];
+                    *(u32x4*)(r + 2 * D + dp * 32) = vw[dp];
+                }
             }
         }
-        if (NKT <= ATTN_BWD_WAVES) break;
+        if (NKT <= ATTN_BWD_WAVES * U) break;
     }
 }
 
