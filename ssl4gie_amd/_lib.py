@@ -13,8 +13,9 @@ LIB_PATH = os.path.join(_HERE, "libssl4gie_hip.so")
 # kernel-development builds only: `make -C ssl4gie_amd/csrc DEBUG_KNOBS=1` produces a second library with the
 # ablation / time-stamp modes of the NT GEMM compiled in; it is loaded only on this explicit request (and says
 # so on stderr) — the release library has no environment knob that changes results.
-if os.environ.get("SSL4GIE_DEBUG_LIB") == "1":
-    LIB_PATH = os.path.join(_HERE, "libssl4gie_hip_dbg.so")
+_dbg = os.environ.get("SSL4GIE_DEBUG_LIB", "")
+if _dbg == "1" or _dbg.startswith("x"):  # "x<tag>": a tools/build_variant.sh experiment library
+    LIB_PATH = os.path.join(_HERE, "libssl4gie_hip_dbg.so" if _dbg == "1" else f"libssl4gie_hip_{_dbg}.so")
     import sys as _sys
     print(f"ssl4gie_amd: SSL4GIE_DEBUG_LIB=1 -> loading the DEBUG library {LIB_PATH}", file=_sys.stderr)
 

@@ -23,6 +23,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef TN256_ABL
+#define TN256_ABL 0
+#endif
+
 DEVI int q_swz(int k) { return ((k & 3) | ((k >> 1) & 4)) << 1; }
 
 // MFMA operand (16 x-values x 32 k) out of a k-major half-tile image: lane l gets, for
@@ -56,6 +60,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     int tiles_n, int ntiles, int splits, float alpha, int accumulate, float* __restrict__ colsum,
     float* __restrict__ colsum_part, ConvK cg, TnExtras ex) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // -DTN256_ABL=<bits> (tools/build_variant.sh experiment libraries; timing only, garbage outputs): bit 0 no output
+    // stores, bit 1 no fragment reads, bit 2 no LDS-DMA, bit 3 no MFMA — which of the K-loop's streams sets its time
+    constexpr int dbg = TN256_ABL;
     const bool tn_m_inner_ok = ex.m_inner != 0;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     int s_kt = 0;  // stream cursor (K-tile relative to kt0)
     auto issue = [&](auto Jc) {
         constexpr int J = decltype(Jc)::value;
-        if (s_kt < total_kt) {
+        if (s_kt < total_kt && !(dbg & 4)) {
             const unsigned dst = lds0 + (s_kt & 1) * P_BUF + J * P_HALF;
             const size_t krow = (size_t)(kt0 + s_kt) * P_BK;
             const bf16_t* base = (J & 1) ? At + krow * ldat : Bt + krow * ldbt;
@@ -172,10 +179,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     using I3 = std::integral_constant<int, 3>;
 
     const int kl = 8 * (lane >> 4);
+    bf16x8 dbg_z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dbg_z[j] = (__bf16)(0.001f * (float)(lane + j));
+    auto dbg_frag = [&]() -> bf16x8 { return dbg_z; };
     auto ldA = [&](int buf, int h, int mi, int ks) -> bf16x8 {
+        if (dbg & 2) return dbg_frag();
         return q_frag(smem + buf * P_BUF + (h ? 3 : 1) * P_HALF, ks * 32 + kl, wr * 64 + mi * 16, lane);
     };
     auto ldB = [&](int buf, int h, int ni, int ks) -> bf16x8 {
+        if (dbg & 2) return dbg_frag();
         return q_frag(smem + buf * P_BUF + (h ? 2 : 0) * P_HALF, ks * 32 + kl, wc * 32 + ni * 16, lane);
     };
 
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     }
     auto mma = [&](auto QMc, auto QNc, bf16x8 (&bb)[2][2]) {
         constexpr int QM = decltype(QMc)::value, QN = decltype(QNc)::value;
+        if (dbg & 8) return;
         __builtin_amdgcn_s_setprio(1);
         if constexpr (CONV == 2 && QM == 0) {  // P0 has just loaded b0, P1 b1
 #pragma unroll
@@ -333,6 +347,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
     const long long ldo = (splits == 1) ? ldc : N;
     const float al = (splits == 1) ? alpha : 1.f;
     const bool accu = (splits == 1) && accumulate;
+    if (dbg & 1) {
+        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[7][3][3]), "v"(acc[3][1][2]));
+        return;
+    }
     if (m0 + P_BM <= M && n0 + P_BN <= N)
         p_store_f32<true, false>(acc, stg, al, zero4, nullptr, 0, accu, out, ldo, m0 + wr * 128,
                                  n0 + wc * 64, M, N, lane);
