@@ -360,6 +360,236 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
 }
 
 // =====================================================================================
+// Round 5: the K-SPLIT form of the same product (plain operands, full or clamped tiles).
+//
+// What the ablations of the kernel above showed (tools/build_variant.sh -DTN256_ABL, profiles/r05a): its K-loop is
+// not bound by the transposed reads (reads + skeleton alone: 0.2 us per K-tile) but by two things that add up —
+// the four-phase skeleton around the MFMAs (1.67 us per K-tile with MFMAs only: 8 intervals of 16 MFMAs + ~110
+// cycles of barrier / wait overhead each, where the NT kernel's two-phase form has 4 of 32) and the LDS-DMA stream
+// (1.6 us per K-tile with the DMA only), whose requests were 128-byte (A) and 64-byte (B) pieces of a row: a
+// half-tile was "half of the tile's COLUMNS over all 64 k-rows", the NT kernel's split, which suits operands that
+// are contiguous along k.  These operands are contiguous along m / n, so here a stage is "32 K-ROWS of all 256
+// columns": a row is one contiguous 512-byte run, a DMA piece two whole rows.
+//
+//  * stage = 32 k-rows of A (16 KiB) + 32 k-rows of B (16 KiB); ring of 4 stages (A stages at 0 .. 64 KiB, B stages
+//    at 64 .. 128 KiB, so that every fragment address is a loop-invariant VGPR + a 16-bit immediate);
+//  * ONE uniform phase per stage: {LOAD: 24 ds_read_b64_tr_b16 (8 A + 4 B fragments: the k extent of a stage IS the
+//    32 of one MFMA) + the DMA of stage s + 3 (two A pieces, two B pieces per wave) + the counted wait for stage
+//    s + 1 + lgkmcnt(0); s_barrier; MMA: 32 MFMAs; s_barrier} — the two wave rows one barrier apart as before;
+//    48 fragment registers instead of 64, reads balanced 24 / 24 instead of 24 / 8 / 16 / 0;
+//  * hazards (interval I_n between barriers n - 1 and n; wr = 0 runs LOAD(s) in I_2s and MMA(s) in I_2s+1, wr = 1
+//    one interval later):
+//      WAR  LOAD(s) issues stage s + 3 = s - 1 (mod 4) over what LOAD(s - 1) read; every LOAD ends with
+//           lgkmcnt(0) before its barrier, so either group's reads of LOAD(s - 1) are complete at least one
+//           barrier before either group's LOAD(s);
+//      RAW  each wave waits at the end of LOAD(s) until all but its 8 youngest pieces (stages s + 2, s + 3) have
+//           landed, i.e. its pieces of stage s + 1; wr = 0 reads stage s + 1 in I_2s+2, after the barrier that
+//           ends wr = 1's LOAD(s) in I_2s+1.
+// Image of a stage half: k-row r at r * 512 B, 32-byte unit u (16 m- or n-values) at position u ^ k_swz(r): the 32
+// lanes of a ds_read_b64_tr_b16 group read 8 rows x 32 B and k_swz takes 8 distinct values on them (conflict-free).
+// Same accumulator layout, same per-accumulator summation order (k ascending) as the kernel above: results are
+// bit-identical, so SSL4GIE_TN256K=0 (A/B timing) changes nothing else.
+DEVI int k_swz(int k) { return (k & 3) | ((k >> 1) & 4); }
+
+template <bool COLSUM>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn256k_kernel(
+    const bf16_t* __restrict__ At, long long ldat, const bf16_t* __restrict__ Bt, long long ldbt,
+    float* __restrict__ C, long long ldc, float* __restrict__ slabs, int M, int N, int K,
+    int tiles_n, int ntiles, int splits, float alpha, int accumulate, float* __restrict__ colsum,
+    float* __restrict__ colsum_part, TnExtras ex) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool tn_m_inner_ok = ex.m_inner != 0;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int all_tiles = ntiles + ex.total_tiles;
+    const int split = bid / all_tiles;
+    int tile = bid % all_tiles;
+    if (tile >= ntiles) {  // grouped launch: this workgroup belongs to a later product (uniform)
+        const int rel = tile - ntiles;
+#pragma unroll
+        for (int i = 0; i < TN_GROUP_MAX - 1; ++i) {
+            if (i < ex.n && rel >= ex.p[i].tile0 && rel < ex.p[i].tile0 + ex.p[i].ntiles) {
+                tile = rel - ex.p[i].tile0;
+                At = (const bf16_t*)ex.p[i].At; ldat = ex.p[i].ldat;
+                Bt = (const bf16_t*)ex.p[i].Bt; ldbt = ex.p[i].ldbt;
+                C = ex.p[i].C; ldc = ex.p[i].ldc; slabs = ex.p[i].slabs;
+                M = ex.p[i].M; N = ex.p[i].N; tiles_n = ex.p[i].tiles_n;
+                colsum = ex.p[i].colsum; colsum_part = ex.p[i].colsum_part;
+                alpha = ex.p[i].alpha; accumulate = ex.p[i].accumulate;
+            }
+        }
+    }
+    const int tiles_m = (M + P_BM - 1) / P_BM;
+    const bool m_inner = tiles_m < tiles_n && tn_m_inner_ok;  // (tile walk: see the kernel above)
+    const int m0 = (m_inner ? tile % tiles_m : tile / tiles_n) * P_BM;
+    const int n0 = (m_inner ? tile / tiles_m : tile % tiles_n) * P_BN;
+    const int nkt = K / P_BK;
+    const int kt0 = (int)((long long)nkt * split / splits);
+    const int kt1 = (int)((long long)nkt * (split + 1) / splits);
+    const int total_kt = kt1 - kt0;
+    const int nph = 2 * total_kt;  // 32-row stages
+
+    // ---- LDS-DMA stream.  Piece j (0, 1) of this wave in a stage half: LDS rows 4 wave + 2 j + (lane >> 5), 16-byte
+    // slot lane & 31 of the row; the slot holds the logical chunk whose swizzled position it is.
+    unsigned va0, va1, vb0, vb1;
+    {
+        auto offs = [&](int j, bool is_a) -> unsigned {
+            const int kr = wave * 4 + j * 2 + (lane >> 5);
+            const int slot = lane & 31;
+            int ch = (((slot >> 1) ^ k_swz(kr)) << 1) + (slot & 1) + ((is_a ? m0 : n0) >> 3);
+            const int last = ((is_a ? M : N) >> 3) - 1;  // last valid 16-byte chunk of a row
+            ch = ch < last ? ch : last;
+            return (unsigned)(((long long)kr * (is_a ? ldat : ldbt) + ch * 8) * 2);
+        };
+        va0 = offs(0, true); va1 = offs(1, true);
+        vb0 = offs(0, false); vb1 = offs(1, false);
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + wave * 2048);
+    const char* baseA = (const char*)(At + (size_t)kt0 * P_BK * ldat);
+    const char* baseB = (const char*)(Bt + (size_t)kt0 * P_BK * ldbt);
+    const long long stepA = 64LL * ldat, stepB = 64LL * ldbt;  // 32 rows, in bytes
+    int s_ph = 0;  // stream cursor (stage index)
+    auto issue = [&](auto STc) {
+        constexpr int ST = decltype(STc)::value;  // ring slot of the stage being issued
+        if (s_ph < nph && !(TN256_ABL & 4)) {
+            const unsigned da = lds0 + ST * 16384, db = lds0 + 65536 + ST * 16384;
+            p_glds2(baseA, va0, va1, da, da + 1024);
+            p_glds2(baseB, vb0, vb1, db, db + 1024);
+            if (!(TN256_ABL & 16)) {  // (bit 4: the stream re-reads its first stage — an L2-resident DMA stream)
+                baseA += stepA;
+                baseB += stepB;
+            }
+        }
+        ++s_ph;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // ---- fragment addresses: lane (g = l >> 4, q = (l & 15) >> 2, p = l & 3) reads row 8 g + q (+ 4 for the second
+    // read) of the stage, 8 bytes at p * 8 of the swizzled 32-byte unit
+    const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+    const int frow = (8 * fg + fq) * 512 + fp * 8, fsw = k_swz(8 * fg + fq);
+    unsigned aoff[8], boff[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) aoff[mi] = (unsigned)(frow + (((wr * 8 + mi) ^ fsw) << 5));
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) boff[ni] = (unsigned)(65536 + frow + (((wc * 4 + ni) ^ fsw) << 5));
+    bf16x8 dbg_z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dbg_z[j] = (__bf16)(0.001f * (float)(lane + j));
+    auto frag = [&](unsigned off, int imm) -> bf16x8 {
+        if (TN256_ABL & 2) return dbg_z;
+        typedef __attribute__((address_space(3))) s16x4* lp_t;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(smem + off + imm));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(smem + off + imm + 2048));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    bf16x8 a[8], b[4];
+    f32x4 accb[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    const bool do_cs = COLSUM && (n0 == 0) && colsum != nullptr;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    // one phase on ring slot ST (the stage it issues, s + 3, lives in slot (ST + 3) & 3)
+    auto phase = [&](auto STc, int s) {
+        constexpr int ST = decltype(STc)::value;
+        // ---------------- LOAD
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b[ni] = frag(boff[ni], ST * 16384);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) a[mi] = frag(aoff[mi], ST * 16384);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(std::integral_constant<int, (ST + 3) & 3>{});
+        if (s + 3 < nph) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- MMA
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (COLSUM && !(TN256_ABL & 8)) {
+            if (do_cs) {
+                auto cs = [&](const bf16x8& lo, const bf16x8& hi) {
+                    accb[0] = P_MFMA(ones, lo, accb[0]);
+                    accb[1] = P_MFMA(ones, hi, accb[1]);
+                };
+                if (wc == 0) cs(a[0], a[4]);
+                else if (wc == 1) cs(a[1], a[5]);
+                else if (wc == 2) cs(a[2], a[6]);
+                else cs(a[3], a[7]);
+            }
+        }
+        if constexpr (!(TN256_ABL & 8)) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = P_MFMA(b[ni], a[mi], acc[mi][ni]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    if (total_kt > 0) {
+        issue(I0{}); issue(I1{}); issue(I2{});
+        if (nph > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage 0 landed (nph is even: >= 2)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        int s = 0;
+        for (; s + 3 < nph; s += 4) {
+            phase(I0{}, s);
+            phase(I1{}, s + 1);
+            phase(I2{}, s + 2);
+            phase(I3{}, s + 3);
+        }
+        if (s < nph) {  // an odd number of K-tiles: two more stages, slots 0 and 1
+            phase(I0{}, s);
+            phase(I1{}, s + 1);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+    }
+
+    if constexpr (COLSUM) {  // D[n][m] is the same for every n: lanes 0..15 hold m = l, register 0
+        if (do_cs && lane < 16) {
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm) {
+                const int m = m0 + wr * 128 + qm * 64 + wc * 16 + lane;
+                if (m < M) {
+                    if (splits == 1) colsum[m] = accumulate ? colsum[m] + accb[qm][0] : accb[qm][0];
+                    else colsum_part[(size_t)split * M + m] = accb[qm][0];
+                }
+            }
+        }
+    }
+    const f32x4 zero4 = {0, 0, 0, 0};
+    char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
+    float* out = (splits == 1) ? C : slabs + (size_t)split * M * N;
+    const long long ldo = (splits == 1) ? ldc : N;
+    const float al = (splits == 1) ? alpha : 1.f;
+    const bool accu = (splits == 1) && accumulate;
+    if (m0 + P_BM <= M && n0 + P_BN <= N)
+        p_store_f32<true, false>(acc, stg, al, zero4, nullptr, 0, accu, out, ldo, m0 + wr * 128,
+                                 n0 + wc * 64, M, N, lane);
+    else
+        p_store_f32<false, false>(acc, stg, al, zero4, nullptr, 0, accu, out, ldo, m0 + wr * 128,
+                                  n0 + wc * 64, M, N, lane);
+}
+
+// =====================================================================================
 // host side
 // =====================================================================================
 static int tn256_mode() {  // SSL4GIE_TN256: "0" never, "1" whenever possible, unset = heuristic
@@ -560,6 +790,31 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, 
     const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
     // a lone plain product whose tiles M x N does not fill (ResNet's narrow 1x1 weight gradients)
     const bool partial = n == 1 && cv == 0 && (d->M % P_BM != 0 || d->N % P_BN != 0);
+    // plain operands, no skipped fragment blocks: the k-split kernel (SSL4GIE_TN256K=0: the column-split one; the
+    // results are bit-identical, the knob exists for A/B timing)
+    static int ksplit = -1;
+    if (ksplit < 0) { const char* s = getenv("SSL4GIE_TN256K"); ksplit = (s && s[0] == '0') ? 0 : 1; }
+    if (ksplit && cv == 0 && !partial) {
+#define K_LAUNCH(CS_)                                                                              \
+    do {                                                                                           \
+        auto kfn = gemm_bf16_tn256k_kernel<CS_>;                                                   \
+        static bool attr_set = false;                                                              \
+        if (!attr_set) {                                                                           \
+            HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES)); \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        hipLaunchKernelGGL(kfn, grid, block, P_LDS_BYTES, st, (const bf16_t*)d->A, d->sAk,         \
+                           (const bf16_t*)d->B, d->sBk, (float*)d->C, d->ldc, slabs, d->M, d->N,   \
+                           d->K, tn, tm * tn, splits, d->alpha, d->accumulate, d->colsum_a,        \
+                           colsum_part, sec);                                                      \
+    } while (0)
+        if (any_colsum) K_LAUNCH(true);
+        else K_LAUNCH(false);
+#undef K_LAUNCH
+        LAUNCH_CHECK();
+        return 0;
+    }
     if (any_colsum) {
         if (cv == 0) Q_LAUNCH(true, 0);
         else if (cv == 1) Q_LAUNCH(true, 1);
