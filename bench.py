@@ -219,7 +219,7 @@ def mae_nt_algorithmic_bytes(B, enc=(50, 768, 3072, 12), dec=(197, 512, 2048, 8)
     return total, launches
 
 
-def cpu_baseline(steps=8, warmup=2, b=8):
+def cpu_baseline(steps=10, warmup=3, b=8):  # 3 warm-up + 10 timed steps
     """CPU oracle step (fwd + bwd + AdamW) on the host cores; bounded sample (~10-30 s)."""
     from oracle import mae_ref, synth
     torch.set_num_threads(host_cores())
@@ -249,6 +249,81 @@ def cpu_baseline(steps=8, warmup=2, b=8):
                       f"CPU oracle (oracle/mae_ref.py), {warmup} warm-up steps"}
 
 
+PROF_KIND_NAMES = ["gemm_bf16_nt", "gemm_bf16_tn", "attn_fwd_bf16", "attn_bwd_bf16", "gemm_generic",
+                   "batchnorm", "layernorm"]
+PROF_HBM_KINDS = {"batchnorm", "layernorm"}   # these carry algorithmic BYTES in the profiler's work slot
+
+
+def roofline_pass(step, a, workload):
+    """`--prof-steps` more steps of the workload with the library's launch profiler on (HIP events on the launch
+    stream around every launch of the heavy kernel kinds; outside the timed region, every stream folded back so
+    that a launch has the chip to itself) -> the `roofline` object of the bench line for the kind with the largest
+    summed duration: bound "mfma" (GEMM / attention kinds: algorithmic FLOPs / duration against 2.5 PFLOP/s) or
+    "hbm" (BatchNorm / LayerNorm entry points: algorithmic bytes / duration against 8 TB/s)."""
+    if a.prof_steps <= 0:
+        return None
+    from ssl4gie_amd import _lib
+    from ssl4gie_amd import engine as _engine
+    L = _lib.load()
+    kinds = PROF_KIND_NAMES
+    nk = _lib.PROF_KINDS
+    L.ssl4gie_set_wgrad_stream(0)
+    prev_side = _engine.set_wgrad_side(False)   # ... and the single layers' one (engine.wgrad_fork)
+    _lib.check(L.ssl4gie_prof_begin(6000 * a.prof_steps), "prof_begin")
+    for _ in range(a.prof_steps):
+        step()
+    ms = (ctypes.c_double * nk)()
+    fl = (ctypes.c_double * nk)()
+    nl = (ctypes.c_longlong * nk)()
+    _lib.check(L.ssl4gie_prof_collect(ms, fl, nl), "prof_collect")
+    L.ssl4gie_prof_end()
+    L.ssl4gie_set_wgrad_stream(0 if os.environ.get("SSL4GIE_WGRAD_STREAM") == "0" else 1)
+    _engine.set_wgrad_side(prev_side)
+    per = {}
+    for i, k in enumerate(kinds):
+        if not nl[i]:
+            continue
+        rate = fl[i] / max(ms[i], 1e-9) / 1e9  # TFLOP/s, or TB/s for the byte kinds
+        per[k] = {"launches_per_step": nl[i] // a.prof_steps, "ms_per_step": round(ms[i] / a.prof_steps, 3),
+                  "avg_launch_us": round(1e3 * ms[i] / max(nl[i], 1), 2)}
+        per[k]["GBs" if k in PROF_HBM_KINDS else "tflops"] = round(rate * (1e3 if k in PROF_HBM_KINDS else 1), 1)
+    dom = max(range(nk), key=lambda i: ms[i])
+    name = kinds[dom]
+    rate = fl[dom] / max(ms[dom], 1e-9) / 1e9
+    # HBM bytes per launch of that kernel kind from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
+    # the gfx950 note + WRITE_SIZE); measured for the MAE workload's kinds only, null otherwise
+    traffic = None
+    if workload == "mae":
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch"].get(name)
+        except Exception:
+            traffic = None
+    if name in PROF_HBM_KINDS:
+        return {"bound": "hbm", "kernel": name, "achieved": round(rate * 1e3, 1), "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": round(rate * 1e3 / PEAK_HBM_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(fl[dom] / max(nl[dom], 1)),
+                "avg_launch_us": per[name]["avg_launch_us"], "launches_per_step": per[name]["launches_per_step"],
+                "kernels": per}
+    # the same kernel against the HBM roof (these GEMMs sit near the ridge: K = 512 / 768 makes the epilogue
+    # traffic first-order): bytes per launch / average launch duration / 8 TB/s
+    hbm = None
+    if name == "gemm_bf16_nt" and workload == "mae":
+        alg_b, alg_n = mae_nt_algorithmic_bytes(a.batch)
+        avg_s = 1e-3 * ms[dom] / max(nl[dom], 1)
+        hbm = {"algorithmic_bytes_per_launch": round(alg_b / alg_n),
+               "achieved_algorithmic_GBs": round(alg_b / alg_n / avg_s / 1e9, 1),
+               "achieved_measured_GBs": round(traffic / avg_s / 1e9, 1) if traffic else None,
+               "peak_GBs": PEAK_HBM_GBS,
+               "frac_algorithmic": round(alg_b / alg_n / avg_s / 1e9 / PEAK_HBM_GBS, 4),
+               "frac_measured": round(traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4) if traffic else None}
+    return {"bound": "mfma", "kernel": name, "achieved": round(rate, 1), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(rate / PEAK_BF16_TFLOPS, 4), "hbm_roof": hbm, "traffic": traffic,
+            "traffic_unit": "HBM bytes/launch (profiles/pmc_traffic.json)",
+            "flops_per_launch": round(fl[dom] / max(nl[dom], 1)), "avg_launch_us": per[name]["avg_launch_us"],
+            "launches_per_step": per[name]["launches_per_step"], "kernels": per}
+
+
 def timed_steps(step, a, world, dev, ddp=None):
     """the driver's timing contract: W untimed warm-up steps, then exactly K steps bracketed by a
     barrier + torch.cuda.synchronize() on both sides; returns (last loss, MAX over ranks of the
@@ -265,12 +340,26 @@ def timed_steps(step, a, world, dev, ddp=None):
     loss = None
     for _ in range(a.warmup):
         loss = step()
+    # per-step durations beside the contract's one interval ("hipEvents around each step, report
+    # median"): an event on the step's stream at every step boundary — recorded inside the timed region, never
+    # waited for there
+    cuda = dev.type == "cuda"
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if cuda else None
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        if cuda:
+            evs[i].record()
         loss = step()
+    if cuda:
+        evs[a.steps].record()
     fence()
     dt = time.perf_counter() - t0
+    a.median_ms_per_step = None
+    if cuda:
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
+        n = len(per)
+        a.median_ms_per_step = round(per[n // 2] if n % 2 else 0.5 * (per[n // 2 - 1] + per[n // 2]), 3)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -321,12 +410,16 @@ def bench_depth(a):
         return loss
 
     loss, dt, verify = timed_steps(step, a, world, dev, ddp)
+    roof = roofline_pass(step, a, a.workload)
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         ips = B * world * a.steps / dt
         print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "images/sec (fwd+bwd+AdamW) ViT-B + DPT depth finetune 224x224 (BASELINE.json configs[3])",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "ViT_from_MAE(dense='depth') + DPT_decoder + SSI loss(alpha=0.1) + "
                                    "AdamW(1e-4), synthetic img + depth resident in HBM",
@@ -380,12 +473,16 @@ def bench_moco(a):
         return loss
 
     loss, dt, verify = timed_steps(step, a, world, dev, ddp)
+    roof = roofline_pass(step, a, a.workload)
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         ips = B * world * a.steps / dt
         print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "image pairs/sec (fwd+bwd+LARS) MoCo-v3 ResNet50 224x224 (BASELINE.json configs[2])",
             "value": round(ips, 1), "unit": "image pairs/sec", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "MoCo_ResNet(resnet50, 256, 4096, T=1.0), m=0.99, two synthetic views "
                                    "resident in HBM, LARS",
@@ -431,12 +528,16 @@ def bench_vit(a):
         return loss
 
     loss, dt, verify = timed_steps(step, a, world, dev, ddp)
+    roof = roofline_pass(step, a, a.workload)
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         ips = B * world * a.steps / dt
         print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "images/sec (fwd+bwd+AdamW) ViT-B 224x224 linear-head finetune, un-masked trunk",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "ViT_from_MAE(head=True, num_classes=6) + cross entropy + AdamW(1e-4), "
                                    "synthetic images resident in HBM",
@@ -482,6 +583,9 @@ def bench_det(a):
         return loss
 
     loss, dt, verify = timed_steps(step, a, world, dev, ddp)
+    roof = roofline_pass(step, a, a.workload)
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         ips = B * world * a.steps / dt
         # GEMM-shaped MACs per image: 12 blocks x 4096 tokens x 12 D^2, windowed attention
@@ -493,7 +597,8 @@ def bench_det(a):
         print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "images/sec (fwd+bwd+AdamW) detection ViT-B backbone + ViTDet FPN 1024x1024 (SURVEY 8f-1)",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "VisionTransformer_from_Any(det=True, fixed_size=1024) + ViTDet_FPN, "
                                    "synthetic images resident in HBM, quadratic loss on the pyramid maps",
@@ -549,6 +654,9 @@ def bench_bt(a):
         return loss
 
     loss, dt, verify = timed_steps(step, a, world, dev, ddp)
+    roof = roofline_pass(step, a, a.workload)
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         ips = B * world * a.steps / dt
         # 212.44 GFLOP per image (two views, trunk + projector, fwd+bwd) + the three
@@ -557,7 +665,8 @@ def bench_bt(a):
         print(json.dumps({**dp_info(ddp, a.steps + a.warmup, verify), 
             "metric": "images/sec (two views, fwd+bwd+LARS) Barlow Twins ViT-B 224x224 (BASELINE.json configs[4])",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "BarlowTwins(ViT-B trunk, projector 8192-8192-8192, lambda 0.0051), two "
                                    "synthetic views resident in HBM, LARS; own specification (absent "
@@ -695,60 +804,7 @@ def main():
     loss, dt, verify = timed_steps(step, a, world, dev, ddp)
     final_loss = float(loss.detach())
 
-    # ---- roofline pass (instrumented; outside the timed region)
-    L = _lib.load()
-    roof = None
-    kinds = ["gemm_bf16_nt", "gemm_bf16_tn", "attn_fwd_bf16", "attn_bwd_bf16", "gemm_generic"]
-    if a.prof_steps > 0:
-        # per-kernel durations are taken with each launch alone on the chip: the weight-gradient
-        # side stream (ssl4gie_set_wgrad_stream) is folded back for these steps only
-        L.ssl4gie_set_wgrad_stream(0)
-        from ssl4gie_amd import engine as _engine
-        prev_side = _engine.set_wgrad_side(False)   # ... and the single layers' one (engine.wgrad_fork)
-        _lib.check(L.ssl4gie_prof_begin(2000 * a.prof_steps), "prof_begin")
-        for _ in range(a.prof_steps):
-            step()
-        ms = (ctypes.c_double * 5)()
-        fl = (ctypes.c_double * 5)()
-        nl = (ctypes.c_longlong * 5)()
-        _lib.check(L.ssl4gie_prof_collect(ms, fl, nl), "prof_collect")
-        L.ssl4gie_prof_end()
-        L.ssl4gie_set_wgrad_stream(0 if os.environ.get("SSL4GIE_WGRAD_STREAM") == "0" else 1)
-        _engine.set_wgrad_side(prev_side)
-        per = {k: {"launches_per_step": nl[i] // a.prof_steps,
-                   "ms_per_step": round(ms[i] / a.prof_steps, 3),
-                   "avg_launch_us": round(1e3 * ms[i] / max(nl[i], 1), 2),
-                   "tflops": round(fl[i] / max(ms[i], 1e-9) / 1e9, 1)}
-               for i, k in enumerate(kinds) if nl[i]}
-        dom = max(range(5), key=lambda i: ms[i])
-        ach = fl[dom] / max(ms[dom], 1e-9) / 1e9
-        # HBM bytes per launch of that kernel kind from the committed rocprofv3 --pmc passes
-        # (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE); null if no PMC file travels along
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"].get(kinds[dom])
-        except Exception:
-            traffic = None
-        # the same kernel against the HBM roof (these GEMMs sit near the ridge: K = 512 / 768 makes
-        # the epilogue traffic first-order): bytes per launch / average launch duration / 8 TB/s
-        hbm = None
-        if kinds[dom] == "gemm_bf16_nt" and a.workload == "mae":
-            alg_b, alg_n = mae_nt_algorithmic_bytes(a.batch)
-            avg_s = 1e-3 * ms[dom] / max(nl[dom], 1)
-            hbm = {"algorithmic_bytes_per_launch": round(alg_b / alg_n),
-                   "achieved_algorithmic_GBs": round(alg_b / alg_n / avg_s / 1e9, 1),
-                   "achieved_measured_GBs": round(traffic / avg_s / 1e9, 1) if traffic else None,
-                   "peak_GBs": PEAK_HBM_GBS,
-                   "frac_algorithmic": round(alg_b / alg_n / avg_s / 1e9 / PEAK_HBM_GBS, 4),
-                   "frac_measured": round(traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4) if traffic else None}
-        roof = {"bound": "mfma", "kernel": kinds[dom], "achieved": round(ach, 1),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "hbm_roof": hbm,
-                "traffic": traffic, "traffic_unit": "HBM bytes/launch (profiles/pmc_traffic.json)",
-                "flops_per_launch": round(fl[dom] / max(nl[dom], 1)),
-                "avg_launch_us": per[kinds[dom]]["avg_launch_us"],
-                "launches_per_step": per[kinds[dom]]["launches_per_step"], "kernels": per}
+    roof = roofline_pass(step, a, "mae")
     if world > 1:
         dist.barrier()
 
@@ -757,6 +813,7 @@ def main():
         line = {
             "metric": METRIC, "value": round(ips, 1), "unit": "images/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "median_ms_per_step": a.median_ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "ViT-B MAE pretrain (mae_vit_base_patch16, norm_pix_loss, "

@@ -14,7 +14,7 @@
  *   - returns 0 on success, SSL4GIE_EARG (1000) for an invalid argument, otherwise a hipError_t;
  *   - callable from any host thread; the only mutable process-wide settings are the execution
  *     options ssl4gie_set_wgrad_stream / ssl4gie_set_compute_cus and the profiler;
- *   - ssl4gie_abi_version() = 5 (1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`; 2: before
+ *   - ssl4gie_abi_version() = 6 (5: before SSL4GIE_PROF_KINDS grew from 5 to 7 — the profiler's arrays; 1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`; 2: before
  *     ssl4gie_block_bwd's `accumulate` became a flag word and the grouped / deferred weight-gradient
  *     entry points existed; 3: before the direct transport's error word / time-out / all-gather,
  *     ssl4gie_bn_combine_stats and ssl4gie_debug_nt256_stamps existed — additions only; 4: before
@@ -623,7 +623,7 @@ int ssl4gie_map_layernorm_bwd(const void* x, const void* dy, const float* w, con
  * kinds: 0 bf16 NT GEMM, 1 bf16 TN GEMM (kernel only, not its slab reduction), 2 fused attention
  * fwd, 3 fused attention bwd, 4 generic f32-MFMA GEMM.  flops are algorithmic (2MNK; attention
  * 4 B H N^2 hd forward, 10 B H N^2 hd backward). */
-#define SSL4GIE_PROF_KINDS 5
+#define SSL4GIE_PROF_KINDS 7 /* 0 NT GEMM, 1 TN GEMM, 2 / 3 attention fwd / bwd, 4 generic GEMM (FLOPs); 5 BatchNorm, 6 LayerNorm (algorithmic BYTES in the `flops` slot) */
 int ssl4gie_prof_begin(int max_launches);
 int ssl4gie_prof_collect(double* ms, double* flops, long long* launches);
 int ssl4gie_prof_end(void);

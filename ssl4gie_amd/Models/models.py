@@ -264,6 +264,11 @@ class ViTDet_FPN(EngineModule):
             if isinstance(mod, nn.LayerNorm) and len(mod.normalized_shape) == 3:
                 for q in (mod.weight, mod.bias):
                     q.data = q.data.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+        # state_dict() keeps returning ALIASES of these parameters (logical (C, H, W) shape, channels-last strides):
+        # `model.state_dict()[k].copy_(v)` — the idiom the tests and many loaders use — must keep writing the
+        # parameter.  Consumers that need contiguous tensors (safetensors.save_file, `.view(-1)`) take
+        # ssl4gie_amd.checkpoints.contiguous_state_dict(model); loading goes through copy_, which keeps the layout
+        # ("state_dict layout").
 
     # ------------------------------------------------------------------ building blocks
     def _c1(self, x, conv):

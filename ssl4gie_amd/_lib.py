@@ -21,7 +21,9 @@ if _dbg == "1" or _dbg.startswith("x"):  # "x<tag>": a tools/build_variant.sh ex
 
 # the one copy of the ABI revision on the Python side: build(), the tests and load() compare the
 # library's ssl4gie_abi_version() with it (include/ssl4gie_hip.h documents the history)
-ABI_VERSION = 5
+ABI_VERSION = 6
+
+PROF_KINDS = 7  # SSL4GIE_PROF_KINDS: entries of the launch profiler's arrays
 
 F32, BF16 = 0, 1
 BWD_ACCUMULATE, BWD_DEFER_WGRAD, BWD_NO_JOIN = 1, 2, 4

@@ -242,3 +242,11 @@ def load_augreg_npz(model, path):
         if k in own and tuple(own[k].shape) != tuple(v.shape):
             raise ValueError(f"{k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}")
     return load_matching(model, sd)
+
+
+def contiguous_state_dict(module):
+    """state_dict() with every entry contiguous: the (C, H, W) LayerNorm tables of ViTDet_FPN are stored
+    channels-last (Models/models.py) and their state_dict entries alias them, strides included — fine for
+    torch.save / load_state_dict, but safetensors.save_file rejects non-contiguous tensors and `.view(-1)` on such
+    an entry raises.  The copies no longer alias the parameters."""
+    return {k: (v if v.is_contiguous() else v.contiguous()) for k, v in module.state_dict().items()}

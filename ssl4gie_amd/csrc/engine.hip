@@ -19,7 +19,7 @@
 #include <mutex>
 #include "prof.h"
 
-extern "C" int ssl4gie_abi_version(void) { return 5; }
+extern "C" int ssl4gie_abi_version(void) { return 6; }
 
 namespace { extern int g_wgrad_stream; }
 // 1: block weight gradients on the library's side stream (default), 0: everything on the caller's

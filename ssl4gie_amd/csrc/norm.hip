@@ -7,6 +7,7 @@
 //
 // Replaces: torch.nn.LayerNorm(eps=1e-6) at Models/mae/models_mae.py:227, Models/models.py:384,498
 #include "common.h"
+#include "prof.h"
 #include "ssl4gie_hip.h"
 #include "internal.h"
 
@@ -296,6 +297,7 @@ extern "C" int ssl4gie_layernorm_fwd(const float* x, const float* gamma, const f
     REQUIRE(y_dtype == SSL4GIE_F32 || y_dtype == SSL4GIE_BF16);
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_LN, (double)rows * cols * (4 + (y_dtype == SSL4GIE_BF16 ? 2 : 4)), st);  // x fp32 -> y
     dim3 grid((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK), block(256);
 #define LN_FWD(NV)                                                                              \
     if (y_dtype == SSL4GIE_BF16)                                                                \
@@ -331,6 +333,9 @@ extern "C" int ssl4gie_layernorm_bwd(const void* dy, int dy_dtype, const float* 
     REQUIRE(!dx_lp || lp_dtype == dy_dtype);
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    // dy, x fp32 (+ the residual gradient fp32) -> dx fp32 (+ its operand-type copy)
+    const double ln_es = dy_dtype == SSL4GIE_BF16 ? 2 : 4;
+    ProfScope prof(PROF_LN, (double)rows * cols * (ln_es + 4 + (dres ? 4 : 0) + 4 + (dx_lp ? ln_es : 0)), st);
     const int nb = ln_bwd_blocks(rows);
     dim3 grid(nb), block(256);
 #define LN_BWD(NV)                                                                             \

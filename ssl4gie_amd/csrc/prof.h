@@ -4,8 +4,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// kinds 0-4 carry FLOPs in `flops`; the HBM-bound kinds 5 (BatchNorm entry points) and 6 (LayerNorm) carry their
+// ALGORITHMIC BYTES there (every tensor the op must read once / write once) — bench.py prices them against 8 TB/s
 enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_ATTN_FWD = 2, PROF_ATTN_BWD = 3,
-       PROF_GEMM_GENERIC = 4, PROF_KINDS = 5 };
+       PROF_GEMM_GENERIC = 4, PROF_BN = 5, PROF_LN = 6, PROF_KINDS = 7 };
 
 struct ProfState {
     bool on;

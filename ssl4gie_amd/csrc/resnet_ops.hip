@@ -13,6 +13,7 @@
 //   maxpool3x3s2     forward with argmax byte, backward in gather form
 //   avgpool          global average per image and its gradient
 #include "common.h"
+#include "prof.h"
 #include "ssl4gie_hip.h"
 #include "internal.h"
 
@@ -808,6 +809,8 @@ extern "C" int ssl4gie_bn_fwd(const void* x, const float* gamma, const float* be
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace;  // workspace: [coef 3C][partials parts x 2C][sums 2C][pivot C]
     const long long total = rows * C;
+    // algorithmic bytes: (statistics pass: x) + apply: x (+ res) -> y
+    ProfScope prof(PROF_BN, (double)total * (dtype == SSL4GIE_BF16 ? 2 : 4) * ((training ? 1 : 0) + 2 + (res ? 1 : 0)), st);
     if (!training) {  // evaluation: mean / rstd are INPUTS (running statistics prepared by the caller)
         hipLaunchKernelGGL(bn_fwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd,
                            gamma, beta, coef, C);
@@ -845,6 +848,12 @@ static int bn_bwd_impl(const void* dy, const void* y, const void* x, const float
                        float* workspace, int dtype, long long rows, int C, hipStream_t st) {
     const int parts = bn_parts(rows, C);
     dim3 grid(bn_strips(C, dtype), parts), block(256);
+    // algorithmic bytes: reduce reads dy, x (+ the ReLU output when the mask comes from it; the bit map is 1/16 of
+    // a tensor) and writes dres; apply reads the gradient, x (+ the ReLU output) and writes dx
+    const double bn_es = dtype == SSL4GIE_BF16 ? 2 : 4;
+    const bool bn_masked = relu && dres;
+    ProfScope prof(PROF_BN, (double)rows * C * bn_es * ((2 + ((relu && xmask == 0) ? 1 : 0) + (xmask == 2 ? 0.0625 : 0) + (dres ? 1 : 0)) +
+                                                       (2 + ((relu && xmask == 0 && !bn_masked) ? 1 : 0) + 1)), st);
     float* coef = workspace;
     float* partial = workspace + 3 * (size_t)C;
     float* mcoef = xmask == 1 ? partial + (size_t)parts * 2 * C : nullptr;  // the forward's `sums` slot: free here
@@ -1060,6 +1069,7 @@ static int bn_fwd_partials_impl(const void* x, const float* partial, int parts, 
     REQUIRE(x && partial && parts > 0 && y && mean && rstd && workspace && rdt(dtype) && rows > 0 &&
             C > 0 && C % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_BN, (double)rows * C * (dtype == SSL4GIE_BF16 ? 2 : 4) * (2 + (res ? 1 : 0)), st);  // x (+ res) -> y
     float* coef = workspace;
     float* scratch = workspace + 3 * (size_t)C;  // >= BN_FOLD x 2C floats by construction of the size
     const float* pp; int np;

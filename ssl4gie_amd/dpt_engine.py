@@ -205,7 +205,7 @@ class Conv3x3Fn(torch.autograd.Function):
         dy = dy.contiguous()
         dy2 = dy.view(-1, Cout)
         (tw, tb), acc, rets = sink.plan([weight, bias])
-        side = wgrad_fork(dy, x, weight, bias) if tw is not None else None
+        side = wgrad_fork(sink, (weight, bias), dy, x, weight, bias) if tw is not None else None
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             Conv3x3Fn._wgrad(tw, tb, acc, dy2, x, stride, relu_in, ld, Cin, Cout)
         dx = None

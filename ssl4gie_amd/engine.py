@@ -615,7 +615,7 @@ class GradJoin:
 # The caller's stream joins at the end of the backward pass (autograd-engine call-backs); operands are kept alive
 # until then.  DataParallel's communication stream waits for this stream before every bucket (parallel._wait_wgrad_stream).
 _WGRAD_SIDE = os.environ.get("SSL4GIE_CONV_WGRAD_STREAM", "1") != "0"
-_WG = {"stream": None, "keep": []}
+_WG = {"stream": None}
 
 
 def set_wgrad_side(on: bool) -> bool:
@@ -629,18 +629,33 @@ def set_wgrad_side(on: bool) -> bool:
 def _wgrad_join():
     if _WG["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_WG["stream"])
-    _WG["keep"].clear()
 
 
-def wgrad_fork(*keep):
-    """-> the weight-gradient stream (forked from the current one) or None; `keep` stays alive until the join"""
-    if not _WGRAD_SIDE or not keep or keep[0] is None or not keep[0].is_cuda:
+def wgrad_fork(sink, params, *operands):
+    """-> the weight-gradient stream (forked from the current one) or None.
+
+    The fork is taken only when nothing can read the gradient tensors on the caller's stream before the join at the
+    end of the backward pass: the targets must be views of the gradient arena (autograd's AccumulateGrad
+    then keeps the returned view by reference — no kernel), the parameters must carry no tensor hooks (a hook reads
+    the gradient at once, on the caller's stream), and the pass must not build a graph (create_graph differentiates
+    through the returned tensors).  Otherwise the product runs on the caller's stream as before.  `operands` are
+    handed to the allocator with record_stream: their memory is not reused before the side stream has passed this
+    point, and each layer's tensors can be released as soon as its node is done (no list kept until the join)."""
+    if not _WGRAD_SIDE or not operands or operands[0] is None or not operands[0].is_cuda:
+        return None
+    live = [p for p in params if p is not None and p.requires_grad]
+    arena = getattr(sink, "arena", None)
+    if arena is None or not live or not all(arena.owns(p) for p in live):
+        return None
+    if torch.is_grad_enabled() or any(getattr(p, "_backward_hooks", None) for p in live):
         return None
     if _WG["stream"] is None:
         _WG["stream"] = torch.cuda.Stream()
     side = _WG["stream"]
     side.wait_stream(torch.cuda.current_stream())
-    _WG["keep"] += [k for k in keep if k is not None]
+    for t in operands:
+        if t is not None and t.is_cuda:
+            t.record_stream(side)
     from torch.autograd import Variable
     Variable._execution_engine.queue_callback(_wgrad_join)   # idempotent: one per use, all run at the end of the pass
     return side
@@ -696,7 +711,7 @@ class LinearFn(torch.autograd.Function):
                 ctx.join.deposit(dx)
                 dx = None
         if tw is not None:
-            side = wgrad_fork(dy2, x2, weight, bias)   # beside the data-gradient chain when the option is on
+            side = wgrad_fork(ctx.sink, (weight, bias), dy2, x2, weight, bias)   # beside the data-gradient chain when safe
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 ops.linear_bwd_weight(dy2, x2, out=tw, accumulate=acc, bias_out=tb)
         elif tb is not None:

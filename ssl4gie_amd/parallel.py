@@ -429,9 +429,15 @@ class DataParallel(nn.Module):
                 # first pass after construction / relearn() — on every rank alike, so the agreement is a
                 # collective all of them join: parameters whose hook fired on no rank do not take part in
                 # this graph
-                self._unused = self._agree_unused([s == self._step for s in self._stamp])
-                self._expected, self._learnt = list(self._uses), True
-                self._build_plan()
+                unused = self._agree_unused([s == self._step for s in self._stamp])
+                if not all(unused):
+                    self._unused = unused
+                    self._expected, self._learnt = list(self._uses), True
+                    self._build_plan()
+                # else: a pass in which no hook fired on any rank (closed by finish() / an optimizer pre-step hook
+                # over leftover handles) says nothing about the graph — learning from it would mark every
+                # parameter unused and move all traffic to the un-overlapped tail for good; the next
+                # real pass learns instead, on every rank alike (the agreement above is rank-uniform)
         self._drain()
         self.n_passes += 1
         self._n_at_pass_start = self.n_collectives

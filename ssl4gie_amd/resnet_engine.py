@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from .dpt_engine import _derived, _pad_cols, _write_grad
-from .engine import GradSink, LPCache
+from .engine import weights_epoch, GradSink, LPCache
 
 
 class _StemCols:
@@ -306,7 +306,13 @@ class BatchNormFn(torch.autograd.Function):
             y, _, _ = ops.bn_fwd(x2, g, b, r2, None, None, 0.0, bn.eps, relu, False, mean, rstd)
         if training and bn.num_batches_tracked is not None:
             _count_batch(bn)
-        ctx.save_for_backward(x2, bits if bits is not None else (y if relu else None), gamma, beta, mean, rstd)
+        # the mask-from-x backward rebuilds the ReLU mask from gamma / beta as they are AT BACKWARD TIME: it is only
+        # valid while no optimizer has stepped since this forward — checked there against this stamp;
+        # that path never reads the ReLU output, so it is not saved for it either
+        xmask = relu and res is None and _XMASK and bits is None
+        ctx.wepoch = weights_epoch()
+        ctx.save_for_backward(x2, bits if bits is not None else (y if (relu and not xmask) else None), gamma, beta,
+                              mean, rstd)
         ctx.cfg = (shp, relu, res is not None, sink, training, sync, group, total)
         return y.view(shp)
 
@@ -325,6 +331,9 @@ class BatchNormFn(torch.autograd.Function):
             dx, dres = ops.bn_bwd_bits(dy2, y, x2, gd, mean, rstd, tg, tb, acc)   # `y` holds the forward's bit map
         elif not sync and relu and not has_res and _XMASK:
             # the ReLU mask from x and the forward's coefficients: the ReLU output is not read again
+            if weights_epoch() != ctx.wepoch:
+                raise RuntimeError("BatchNorm parameters were updated between this forward and its backward: the "
+                                   "ReLU mask rebuilt from them would disagree with the forward (set SSL4GIE_BN_XMASK=0)")
             dx, dres = ops.bn_bwd_xmask(dy2, x2, gd, beta.detach() if beta is not None else None, mean, rstd,
                                         tg, tb, acc), None
         elif not sync:
@@ -332,6 +341,9 @@ class BatchNormFn(torch.autograd.Function):
         else:
             import torch.distributed as dist
             xm = relu and not has_res and _XMASK   # mask rebuilt from x and the (global) forward coefficients
+            if xm and weights_epoch() != ctx.wepoch:
+                raise RuntimeError("BatchNorm parameters were updated between this forward and its backward "
+                                   "(set SSL4GIE_BN_XMASK=0)")
             bd = beta.detach() if beta is not None else None
             if xm:
                 sums, dres = ops.bn_bwd_reduce_xmask(dy2, x2, gd, bd, mean, rstd), None

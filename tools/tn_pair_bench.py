@@ -52,7 +52,7 @@ def run(mode):
         L = _lib.load()
         _lib.check(L.ssl4gie_prof_begin(4 * ITERS + 8), "prof_begin")
         for i in range(ITERS): fn(i)
-        ms = (C.c_double * 5)(); flp = (C.c_double * 5)(); nl = (C.c_longlong * 5)()
+        ms = (C.c_double * _lib.PROF_KINDS)(); flp = (C.c_double * _lib.PROF_KINDS)(); nl = (C.c_longlong * _lib.PROF_KINDS)()
         _lib.check(L.ssl4gie_prof_collect(ms, flp, nl), "prof_collect")
         L.ssl4gie_prof_end()
         kus = ms[1] / max(1, nl[1]) * 1e3
