@@ -317,7 +317,17 @@ def roofline_pass(step, a, workload):
                "peak_GBs": PEAK_HBM_GBS,
                "frac_algorithmic": round(alg_b / alg_n / avg_s / 1e9 / PEAK_HBM_GBS, 4),
                "frac_measured": round(traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4) if traffic else None}
+    # the largest HBM-bound kind beside it (MoCo-R50: the BatchNorm passes are 1/3 of the kernel time)
+    hb = [i for i, k in enumerate(kinds) if k in PROF_HBM_KINDS and nl[i]]
+    hbm_kernel = None
+    if hb:
+        j = max(hb, key=lambda i: ms[i])
+        r = fl[j] / max(ms[j], 1e-9) / 1e6  # GB/s
+        hbm_kernel = {"bound": "hbm", "kernel": kinds[j], "achieved": round(r, 1), "peak": PEAK_HBM_GBS,
+                      "unit": "GB/s", "frac": round(r / PEAK_HBM_GBS, 4), "ms_per_step": round(ms[j] / a.prof_steps, 3),
+                      "algorithmic_bytes_per_step": round(fl[j] / a.prof_steps)}
     return {"bound": "mfma", "kernel": name, "achieved": round(rate, 1), "peak": PEAK_BF16_TFLOPS,
+            "hbm_bound_kernel": hbm_kernel,
             "unit": "TFLOP/s", "frac": round(rate / PEAK_BF16_TFLOPS, 4), "hbm_roof": hbm, "traffic": traffic,
             "traffic_unit": "HBM bytes/launch (profiles/pmc_traffic.json)",
             "flops_per_launch": round(fl[dom] / max(nl[dom], 1)), "avg_launch_us": per[name]["avg_launch_us"],

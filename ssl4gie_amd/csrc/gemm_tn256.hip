@@ -612,6 +612,11 @@ bool ssl4gie_internal_tn256_ok(const ssl4gie_gemm_desc* d) {
     if ((long long)d->K * d->sAk * 2 >= (1LL << 32) || (long long)d->K * d->sBk * 2 >= (1LL << 32))
         return false;  // 32-bit per-lane byte offsets are relative to a per-K-tile base: generous
     if (mode == 1) return true;
+    // (round 5, measured and not changed: the narrow long-contraction products of ResNet50's layer1 — dW [256, 64],
+    // [64, 256], [64, 64], [128, 256] over 802 816 pixels — and the MLP heads' short ones stay on the 128-tile
+    // kernel: 98 / 98 / 70 / 121 us there (5.2 TB/s) against 158 / 120 / 108 / 140 us on the partial-tile path
+    // here, tools/tn_small_bench.py, profiles/r05_tn_small_routing.log; the "206 us" those launches showed in the
+    // round-4 MoCo profile was concurrency with the data-gradient chain, not the kernel)
     return d->K >= 16 * P_BK && (long long)d->M * d->N >= 128 * 128 * 4;
 }
 

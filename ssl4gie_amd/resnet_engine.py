@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from .dpt_engine import _derived, _pad_cols, _write_grad
-from .engine import weights_epoch, GradSink, LPCache
+from .engine import touched_since, weights_epoch, GradSink, LPCache
 
 
 class _StemCols:
@@ -265,6 +265,17 @@ _BN_BITS = __import__("os").environ.get("SSL4GIE_BN_BITS", "1") != "0"
 _XMASK = __import__("os").environ.get("SSL4GIE_BN_XMASK", "1") != "0"
 
 
+def _bn_params_moved(epoch, gamma, beta):
+    """whether gamma / beta were rewritten since `epoch` (engine.touched_since: MoCo's EMA update between the base
+    encoder's forward and its backward moves the MOMENTUM encoder only and does not count; an optimizer step does)"""
+    if weights_epoch() == epoch:
+        return False
+    moved = touched_since(epoch)
+    if moved is None:
+        return True
+    return any(p is not None and id(p) in moved for p in (gamma, beta))
+
+
 class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d / BatchNorm1d / SyncBatchNorm over the rows of a [..., C] tensor, (+ residual)
     (+ ReLU).  With an nn.SyncBatchNorm holder and world_size > 1 the statistics are global: local
@@ -331,7 +342,7 @@ class BatchNormFn(torch.autograd.Function):
             dx, dres = ops.bn_bwd_bits(dy2, y, x2, gd, mean, rstd, tg, tb, acc)   # `y` holds the forward's bit map
         elif not sync and relu and not has_res and _XMASK:
             # the ReLU mask from x and the forward's coefficients: the ReLU output is not read again
-            if weights_epoch() != ctx.wepoch:
+            if _bn_params_moved(ctx.wepoch, gamma, beta):
                 raise RuntimeError("BatchNorm parameters were updated between this forward and its backward: the "
                                    "ReLU mask rebuilt from them would disagree with the forward (set SSL4GIE_BN_XMASK=0)")
             dx, dres = ops.bn_bwd_xmask(dy2, x2, gd, beta.detach() if beta is not None else None, mean, rstd,
@@ -341,7 +352,7 @@ class BatchNormFn(torch.autograd.Function):
         else:
             import torch.distributed as dist
             xm = relu and not has_res and _XMASK   # mask rebuilt from x and the (global) forward coefficients
-            if xm and weights_epoch() != ctx.wepoch:
+            if xm and _bn_params_moved(ctx.wepoch, gamma, beta):
                 raise RuntimeError("BatchNorm parameters were updated between this forward and its backward "
                                    "(set SSL4GIE_BN_XMASK=0)")
             bd = beta.detach() if beta is not None else None

@@ -33,6 +33,9 @@ Fixtures written:
                       the statement sequence of train_depth.py:35-48 (BASELINE.json configs[3]), B = 2
   g14_moco_curve.npz  50-step loss curve of the reference MoCo_ResNet + LARS (builder.py:75-96, main_moco.py),
                       128 x 128 views, B = 16, 1-process gloo (BASELINE.json configs[2])
+  g14_moco_fp64.npz   the same reference classes converted to double: 10-step loss curve, step-0 gradients and the
+                      per-tensor error of the reference's own fp32 gradients against them (the parity gate of
+                      tests/test_gpu_curves.py: the fp32 engine must be no further from fp64 than the reference's fp32)
 """
 from __future__ import annotations
 
@@ -770,6 +773,67 @@ def g14_moco_curve(steps=50):
     print("g14 first/last", losses[0], losses[-1])
 
 
+def g14_moco_fp64(steps=10):
+    """The fp64 evaluation of G14's first steps: the SAME reference classes (MoCo_ResNet, LARS) as g14_moco_curve,
+    converted to double (`m.double()`, double views; LARS on double parameters), same keyed weights, same views —
+    the ground truth both fp32 arithmetics (the reference's own CPU fp32 of G14 and the engine's) are measured
+    against by tests/test_gpu_curves.py: "no worse than the reference's own fp32".  Stores the 10-step loss curve,
+    every gradient of step 0 (norms, small tensors in full, slices of the large ones, as G14) and, per tensor, the
+    reference-fp32 error against it (relative L2, the measure of tools/g14_conditioning.py)."""
+    import torch.distributed as dist
+    from functools import partial
+    import_reference_models()
+    import torchvision.models as tvm
+    ref_b = _load_by_path("ref_builder", os.path.join(REF, "Models", "moco_v3", "moco", "builder.py"))
+    ref_o = _load_by_path("ref_lars", os.path.join(REF, "Models", "moco_v3", "moco", "optimizer.py"))
+    g14 = np.load(os.path.join(HERE, "g14_moco_curve.npz"))
+    torch.manual_seed(0)
+    m = ref_b.MoCo_ResNet(partial(tvm.resnet50, zero_init_residual=True), 256, 1024, 1.0)
+    load_keyed(m, seed=61)
+    with torch.no_grad():
+        for pb, pm in zip(m.base_encoder.parameters(), m.momentum_encoder.parameters()):
+            pm.copy_(pb)
+    assert synth.state_dict_digest(m.state_dict()) == str(g14["digest"])  # the weights G14 ran with, then widened
+    m.double()
+    m.train()
+    opt = ref_o.LARS(m.parameters(), lr=0.02, weight_decay=1e-6, momentum=0.9)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29535")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    views = synth.moco_views(b=16, size=128)
+    losses, extra = [], {}
+    try:
+        for it in range(steps):
+            x1, x2 = views[it % len(views)]
+            loss = m(x1.double(), x2.double(), 0.99)
+            opt.zero_grad()
+            loss.backward()
+            if it == 0:
+                pack_grads(extra, "step0/", [(k, p) for k, p in m.named_parameters() if p.requires_grad])
+            opt.step()
+            losses.append(float(loss))
+            print(f"  g14-fp64 step {it}: {losses[-1]:.9f}   (reference fp32: {float(g14['losses'][it]):.9f})", flush=True)
+    finally:
+        torch.Tensor.cuda = real_cuda
+        dist.destroy_process_group()
+    # per tensor: the reference's own fp32 gradient (G14) against this one
+    names = extra["step0/grad_names"].tolist()
+    assert names == g14["step0/grad_names"].tolist()
+    ref_err = []
+    for k in names:
+        key = f"step0/grad/{k}" if f"step0/grad/{k}" in extra else f"step0/gslice/{k}"
+        a, b = np.asarray(g14[key], dtype=np.float64), np.asarray(extra[key], dtype=np.float64)
+        ref_err.append(float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300)))
+    np.savez_compressed(os.path.join(HERE, "g14_moco_fp64.npz"), losses=np.array(losses, dtype=np.float64),
+                        ref_fp32_losses=np.asarray(g14["losses"][:steps], dtype=np.float64),
+                        ref_fp32_grad_err=np.array(ref_err, dtype=np.float64), digest=np.array(str(g14["digest"])),
+                        steps=np.array(steps), **extra)
+    e = np.array(ref_err)
+    print(f"g14-fp64: reference fp32 vs fp64 gradients: median {np.median(e):.3e} max {e.max():.3e}; "
+          f"losses fp64 {losses[0]:.9f} .. {losses[-1]:.9f}")
+
+
 def g15_det_curve(steps=30):
     """the reference's own VisionTransformer_from_Any(det=True) trunk (models.py:155-210 windowed
     blocks, :310-338) at 512 x 512 (1024 tokens, four 256-token windows), B = 1, trained for 30 steps: tokens
@@ -811,7 +875,7 @@ def main():
         "g5tiny": lambda: g5_tiny(ref_mae), "g5vitb": lambda: g5_vitb(ref_mae),
         "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi, "g8": g8_moco, "g9": g9_dpt_seg,
         "g3b": g3b_moco_sincos, "g10": g10_det, "g11": g11_vit_api, "g12": g12_resnet_dec,
-        "g13": g13_depth_curve, "g14": g14_moco_curve, "g15": g15_det_curve,
+        "g13": g13_depth_curve, "g14": g14_moco_curve, "g14fp64": g14_moco_fp64, "g15": g15_det_curve,
         "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
             **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
             "g5_curve_tiny.npz"),

@@ -226,7 +226,8 @@ def test_g14_moco_curve_first_step_oracle_fp64():
         if k.startswith("momentum_encoder.") and "running" not in k and "num_batches" not in k:
             sd32[k] = sd32[kb].clone()
     assert synth.state_dict_digest(sd32) == str(g["digest"])
-    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}
+    sd = {k: (v.double().requires_grad_(k.startswith(("base_encoder.", "predictor.")) and "running" not in k)
+              if v.is_floating_point() else v) for k, v in sd32.items()}
     x1, x2 = synth.moco_views(b=16, size=128)[0]
     x1, x2 = x1.double(), x2.double()
 
@@ -234,13 +235,30 @@ def test_g14_moco_curve_first_step_oracle_fp64():
         sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
         return moco_ref.mlp_forward(sub, "fc.", resnet_ref.resnet50_pooled(sub, x))
 
+    pred = {k[len("predictor."):]: v for k, v in sd.items() if k.startswith("predictor.")}
+    q1 = moco_ref.mlp_forward(pred, "", enc("base_encoder.", x1))
+    q2 = moco_ref.mlp_forward(pred, "", enc("base_encoder.", x2))
     with torch.no_grad():
-        pred = {k[len("predictor."):]: v for k, v in sd.items() if k.startswith("predictor.")}
-        q1 = moco_ref.mlp_forward(pred, "", enc("base_encoder.", x1))
-        q2 = moco_ref.mlp_forward(pred, "", enc("base_encoder.", x2))
         k1, k2 = enc("momentum_encoder.", x1), enc("momentum_encoder.", x2)
-        loss = moco_ref.contrastive_loss(q1, k2, 1.0) + moco_ref.contrastive_loss(q2, k1, 1.0)
+    loss = moco_ref.contrastive_loss(q1, k2, 1.0) + moco_ref.contrastive_loss(q2, k1, 1.0)
     assert abs(float(loss) - float(g["losses"][0])) < 1e-5 * float(g["losses"][0])
+    # ... and against the reference classes THEMSELVES evaluated in fp64 (g14_moco_fp64.npz, the ground truth of the
+    # MoCo parity gates in test_gpu_curves.py): loss and every step-0 gradient, double against double
+    g64 = load_golden("g14_moco_fp64.npz")
+    assert str(g64["digest"]) == str(g["digest"])
+    assert abs(float(loss) - float(g64["losses"][0])) < 1e-10 * float(g64["losses"][0])
+    loss.backward()
+    worst = 0.0
+    for k in g64["step0/grad_names"].tolist():
+        t = sd[k].grad
+        if f"step0/grad/{k}" in g64.files:
+            r = torch.from_numpy(g64[f"step0/grad/{k}"])
+        else:
+            r, t = torch.from_numpy(g64[f"step0/gslice/{k}"]), t.reshape(t.shape[0], -1)[:8, :64]
+        e = float((t - r).norm() / (r.norm() + 1e-300))
+        worst = max(worst, e)
+        assert e < 1e-7, (k, e)
+    print(f"fp64 oracle vs fp64 reference, step-0 gradients: worst relative L2 error {worst:.2e}")
 
 
 def test_g15_det_curve_first_step_oracle():
