@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
         if (!loader) return;
         if (s_ktg < total_kt && dbg != 7) {
             const unsigned dst = lds0 + (s_ktg & 1) * P_BUF + J * P_HALF;
-            const bf16_t* base = ((J & 1) ? A : B) + (size_t)s_kt * P_BK;
+            const bf16_t* base = ((J & 1) ? A : B) + (size_t)(dbg == 11 ? 0 : s_kt) * P_BK;  // (debug library, 11: every K-tile re-reads K-tile 0 — an L2-resident operand stream, timing only)
             if constexpr (CONV != 0 && (J & 1)) {
                 const unsigned va = vo[J][0], vb = vo[J][1];
                 const unsigned ya = yo[J >> 1][0], yb = yo[J >> 1][1];

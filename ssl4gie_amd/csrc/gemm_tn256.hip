@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256_kernel(
 // bit-identical, so SSL4GIE_TN256K=0 (A/B timing) changes nothing else.
 DEVI int k_swz(int k) { return (k & 3) | ((k >> 1) & 4); }
 
-template <bool COLSUM>
+template <bool COLSUM, int RING>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256k_kernel(
     const bf16_t* __restrict__ At, long long ldat, const bf16_t* __restrict__ Bt, long long ldbt,
     float* __restrict__ C, long long ldc, float* __restrict__ slabs, int M, int N, int K,
@@ -447,6 +447,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256k_kernel(
         vb0 = offs(0, false); vb1 = offs(1, false);
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + wave * 2048);
+    // ring slots: A stages 0-3 at 0 .. 64 KiB, B stages 0-3 at 64 .. 128 KiB; RING == 5: a fifth stage in the 32 KiB the
+    // epilogue's staging area occupies AFTER the loop (A at 128 KiB, B at 144 KiB)
+    auto a_slot = [](int t) -> unsigned { return t < 4 ? (unsigned)t * 16384u : 131072u; };
+    auto b_slot = [](int t) -> unsigned { return t < 4 ? 65536u + (unsigned)t * 16384u : 147456u; };
     const char* baseA = (const char*)(At + (size_t)kt0 * P_BK * ldat);
     const char* baseB = (const char*)(Bt + (size_t)kt0 * P_BK * ldbt);
     const long long stepA = 64LL * ldat, stepB = 64LL * ldbt;  // 32 rows, in bytes
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256k_kernel(
     auto issue = [&](auto STc) {
         constexpr int ST = decltype(STc)::value;  // ring slot of the stage being issued
         if (s_ph < nph && !(TN256_ABL & 4)) {
-            const unsigned da = lds0 + ST * 16384, db = lds0 + 65536 + ST * 16384;
+            const unsigned da = lds0 + a_slot(ST), db = lds0 + b_slot(ST);
             p_glds2(baseA, va0, va1, da, da + 1024);
             p_glds2(baseB, vb0, vb1, db, db + 1024);
             if (!(TN256_ABL & 16)) {  // (bit 4: the stream re-reads its first stage — an L2-resident DMA stream)
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256k_kernel(
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
 
     // ---- fragment addresses: lane (g = l >> 4, q = (l & 15) >> 2, p = l & 3) reads row 8 g + q (+ 4 for the second
     // read) of the stage, 8 bytes at p * 8 of the swizzled 32-byte unit
@@ -481,6 +486,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256k_kernel(
     bf16x8 dbg_z;
 #pragma unroll
     for (int j = 0; j < 8; ++j) dbg_z[j] = (__bf16)(0.001f * (float)(lane + j));
+    unsigned aoff4[8], boff4[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) aoff4[mi] = aoff[mi] + 131072u;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) boff4[ni] = boff[ni] + 81920u;   // 147456 = 65536 + 81920
     auto frag = [&](unsigned off, int imm) -> bf16x8 {
         if (TN256_ABL & 2) return dbg_z;
         typedef __attribute__((address_space(3))) s16x4* lp_t;
@@ -507,13 +517,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256k_kernel(
     auto phase = [&](auto STc, int s) {
         constexpr int ST = decltype(STc)::value;
         // ---------------- LOAD
+        // (slot 4 of the five-stage ring lies beyond a 16-bit immediate from the slot-0 addresses: its own base registers)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) b[ni] = frag(boff[ni], ST * 16384);
+        for (int ni = 0; ni < 4; ++ni) b[ni] = ST < 4 ? frag(boff[ni], ST * 16384) : frag(boff4[ni], 0);
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) a[mi] = frag(aoff[mi], ST * 16384);
+        for (int mi = 0; mi < 8; ++mi) a[mi] = ST < 4 ? frag(aoff[mi], ST * 16384) : frag(aoff4[mi], 0);
         __builtin_amdgcn_sched_barrier(0);
-        issue(std::integral_constant<int, (ST + 3) & 3>{});
-        if (s + 3 < nph) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        issue(std::integral_constant<int, (ST + RING - 1) % RING>{});
+        // stage s + 1 must have landed: all but this wave's pieces of the stages after it may stay in flight
+        if (s + RING - 1 < nph) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING - 2)) : "memory");
+        else if (RING == 5 && s + 3 < nph) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (s + 2 < nph) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -545,20 +559,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn256k_kernel(
 
     if (total_kt > 0) {
         issue(I0{}); issue(I1{}); issue(I2{});
-        if (nph > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage 0 landed (nph is even: >= 2)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (RING == 5) issue(I3{});
+        // stage 0 landed: the later ones (nph is even: >= 2) may stay in flight
+        if (nph >= RING - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // nph == 2: stage 1 may
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();
         int s = 0;
-        for (; s + 3 < nph; s += 4) {
-            phase(I0{}, s);
-            phase(I1{}, s + 1);
-            phase(I2{}, s + 2);
-            phase(I3{}, s + 3);
-        }
-        if (s < nph) {  // an odd number of K-tiles: two more stages, slots 0 and 1
-            phase(I0{}, s);
-            phase(I1{}, s + 1);
+        if constexpr (RING == 4) {
+            for (; s + 3 < nph; s += 4) {
+                phase(I0{}, s);
+                phase(I1{}, s + 1);
+                phase(I2{}, s + 2);
+                phase(I3{}, s + 3);
+            }
+            if (s < nph) {  // an odd number of K-tiles: two more stages, slots 0 and 1
+                phase(I0{}, s);
+                phase(I1{}, s + 1);
+            }
+        } else {
+            // one loop body of five guarded phases (wave-uniform conditions): a separate tail of up to four phases
+            // made the register allocator migrate the accumulators between the copies (256 VGPRs + spills)
+            for (; s < nph; s += 5) {
+                phase(I0{}, s);
+                if (s + 1 < nph) phase(I1{}, s + 1);
+                if (s + 2 < nph) phase(I2{}, s + 2);
+                if (s + 3 < nph) phase(I3{}, s + 3);
+                if (s + 4 < nph) phase(I4{}, s + 4);
+            }
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
     }
@@ -798,11 +826,11 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, 
     // plain operands, no skipped fragment blocks: the k-split kernel (SSL4GIE_TN256K=0: the column-split one; the
     // results are bit-identical, the knob exists for A/B timing)
     static int ksplit = -1;
-    if (ksplit < 0) { const char* s = getenv("SSL4GIE_TN256K"); ksplit = (s && s[0] == '0') ? 0 : 1; }
+    if (ksplit < 0) { const char* s = getenv("SSL4GIE_TN256K"); ksplit = !s ? 1 : (s[0] == '0' ? 0 : (s[0] == '5' ? 5 : 1)); }
     if (ksplit && cv == 0 && !partial) {
-#define K_LAUNCH(CS_)                                                                              \
+#define K_LAUNCH(CS_, RING_)                                                                          \
     do {                                                                                           \
-        auto kfn = gemm_bf16_tn256k_kernel<CS_>;                                                   \
+        auto kfn = gemm_bf16_tn256k_kernel<CS_, RING_>;                                            \
         static bool attr_set = false;                                                              \
         if (!attr_set) {                                                                           \
             HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
@@ -814,8 +842,13 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, 
                            d->K, tn, tm * tn, splits, d->alpha, d->accumulate, d->colsum_a,        \
                            colsum_part, sec);                                                      \
     } while (0)
-        if (any_colsum) K_LAUNCH(true);
-        else K_LAUNCH(false);
+        // SSL4GIE_TN256K=5: a five-stage ring (the fifth stage in the epilogue's staging area: one more stage in
+        // flight, 24 more address registers) — built, bit-identical, measured NULL against the four-stage ring
+        // (pair launches 589 vs 586-591 us, MAE step 22.08 vs 22.09-22.13 ms same-box: profiles/r05j): the
+        // stream's cost is not latency a deeper ring would cover (an L2-RESIDENT stream makes the kernel 14 % faster,
+        // profiles/r05b, so it is the L2 -> LDS path under load)
+        if (ksplit == 5) { if (any_colsum) K_LAUNCH(true, 5); else K_LAUNCH(false, 5); }
+        else { if (any_colsum) K_LAUNCH(true, 4); else K_LAUNCH(false, 4); }
 #undef K_LAUNCH
         LAUNCH_CHECK();
         return 0;
