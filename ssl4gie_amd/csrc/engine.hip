@@ -82,6 +82,11 @@ namespace {
 // folds everything back onto the caller's stream — used when per-kernel durations are measured.
 struct SideStream {
     hipStream_t s = nullptr;
+    // SSL4GIE_WGRAD_STREAMS=2 (round 5): the (proj, qkv) pair of a block on a second weight-gradient stream, so that
+    // the two pair launches of a block — and those of neighbouring blocks — can be in flight together with fewer,
+    // longer workgroups each; ev2: 0..3 completion under the caller's slot, 4 join, 5 fork
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // 0..4: fork / join points of ssl4gie_block_bwd; 5: fork of ssl4gie_wgrad_group;
     // 6..9: completion of the group launched with slot 0..3 (ssl4gie_wgrad_wait)
     hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -118,6 +123,16 @@ SideStream* side_stream() {
                 return nullptr;
             }
         }
+        static int two = -1;
+        if (two < 0) { const char* e = getenv("SSL4GIE_WGRAD_STREAMS"); two = (e && e[0] == '2') ? 1 : 0; }
+        if (two) {
+            hipStream_t st2 = nullptr;
+            if (hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) == hipSuccess) {
+                bool ok = true;
+                for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreateWithFlags(&ss->ev2[i], hipEventDisableTiming) == hipSuccess;
+                if (ok) ss->s2 = st2; else (void)hipStreamDestroy(st2);
+            }
+        }
         ss->s = st;
     }
     return ss;
@@ -127,7 +142,7 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t esize(int dt) { return dt == SSL4GIE_BF16 ? 2 : 4; }
 
 struct BwdLayout {
-    size_t du, dh, dxmid, dxmid_lp, dattn, dqkv, ln_ws, gemm_ws, attn_ws, total;
+    size_t du, dh, dxmid, dxmid_lp, dattn, dqkv, ln_ws, gemm_ws, gemm_ws2, attn_ws, total;
     size_t gemm_ws_bytes;
 };
 
@@ -175,6 +190,7 @@ BwdLayout bwd_layout(const ssl4gie_block_dims* d) {
     }
     L.gemm_ws_bytes = g;
     L.gemm_ws = o; o += align_up(g);
+    L.gemm_ws2 = o; o += align_up(g);  // the (proj, qkv) pair's own slabs: it may run beside the (fc2, fc1) pair
     L.attn_ws = o; o += align_up(ssl4gie_attn_workspace_bytes(d->dtype, d->B, d->N, d->H, d->D / d->H));
     L.total = o;
     return L;
@@ -277,6 +293,7 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     void* dqkv = ws + L.dqkv;
     float* ln_ws = (float*)(ws + L.ln_ws);
     void* gws = ws + L.gemm_ws;
+    void* gws2 = ws + L.gemm_ws2;
     const void* dy = (dt == SSL4GIE_F32) ? (const void*)dx_out : dx_out_lp;
     ssl4gie_gemm_desc e, wg, wg2;
     // weight gradients go to the side stream when there is one (see SideStream)
@@ -318,12 +335,21 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     // ---- attention
     RC(ssl4gie_attn_bwd(a->qkv, a->attn, dattn, a->lse, dqkv, dt, d->B, d->N, d->H, D / d->H,
                         ws + L.attn_ws, stream));
-    // ---- dW_proj and dW_qkv as one paired launch
+    // ---- dW_proj and dW_qkv as one paired launch (on the second weight-gradient stream when there is one)
+    bool used_s2 = false;
     if (!defer) {
-        RC(fork());
+        void* wstb = wst;
+        if (ss && ss->s2) {
+            HIP_RET(hipEventRecord(ss->ev2[5], main_st));
+            HIP_RET(hipStreamWaitEvent(ss->s2, ss->ev2[5], 0));
+            wstb = (void*)ss->s2;
+            used_s2 = true;
+        } else {
+            RC(fork());
+        }
         wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
         wg2 = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
-        RC(ssl4gie_gemm_tn_pair(&wg, &wg2, gws, L.gemm_ws_bytes, wst));
+        RC(ssl4gie_gemm_tn_pair(&wg, &wg2, gws2, L.gemm_ws_bytes, wstb));
     }
     // ---- qkv
     memset(&e, 0, sizeof(e));
@@ -335,10 +361,15 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
                              accumulate, ln_ws, T, D, stream));
     if (ss && no_join) {  // completion under the caller's slot: ssl4gie_wgrad_wait(slot, stream) before reuse
         HIP_RET(hipEventRecord(ss->ev[6 + slot], ss->s));
+        if (ss->s2) HIP_RET(hipEventRecord(ss->ev2[slot], ss->s2));  // (recorded even when unused: the wait is unconditional)
         ss->slot_used[slot] = true;
     } else if (ss) {  // join: the caller's stream continues after the last weight gradient
         HIP_RET(hipEventRecord(ss->ev[4], ss->s));
         HIP_RET(hipStreamWaitEvent(main_st, ss->ev[4], 0));
+        if (used_s2) {
+            HIP_RET(hipEventRecord(ss->ev2[4], ss->s2));
+            HIP_RET(hipStreamWaitEvent(main_st, ss->ev2[4], 0));
+        }
     }
     return 0;
 }
@@ -381,5 +412,6 @@ extern "C" int ssl4gie_wgrad_wait(int slot, void* stream) {
     SideStream* ss = side_stream();
     if (!ss || !ss->slot_used[slot]) return 0;
     HIP_RET(hipStreamWaitEvent((hipStream_t)stream, ss->ev[6 + slot], 0));
+    if (ss->s2) HIP_RET(hipStreamWaitEvent((hipStream_t)stream, ss->ev2[slot], 0));
     return 0;
 }

@@ -720,10 +720,14 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
 // convolutions: up to 256 splits of a 64 KiB tile): 64 float4 columns x 4 slab groups per block — group g sums
 // slabs g, g + 4, g + 8, ... in that order, then the four group sums are added in group order (fixed order:
 // deterministic), so four times as many loads are in flight as with one thread per column.
-__global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* __restrict__ slabs,
-                                                               float* __restrict__ C, long long ldc, int M, int N,
-                                                               int splits, float alpha, int accumulate) {
-    __shared__ f32x4 part[3][64];
+// G slab groups per block (4, or 16 from 128 slabs on: a dW [256, 64] tile over 802 816 pixels has 256 slabs and only
+// 4096 float4 columns — with 4 groups 64 blocks each summed 64 slabs per thread, eight loads at a time: 30 us of
+// latency for 17 MB; with 16 groups a thread sums 16, round 5)
+template <int G>
+__global__ __launch_bounds__(64 * G) void slab_reduce_wide_kernel(const float* __restrict__ slabs,
+                                                                  float* __restrict__ C, long long ldc, int M, int N,
+                                                                  int splits, float alpha, int accumulate) {
+    __shared__ f32x4 part[G - 1][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const size_t i4 = (size_t)blockIdx.x * 64 + c;
     const size_t total4 = (size_t)M * N / 4;
@@ -733,19 +737,20 @@ __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* __re
     if (ok)
     {
         int k = g;
-        for (; k + 28 < splits; k += 32) {  // eight of this group's slabs in flight, added in slab order
+        for (; k + 7 * G < splits; k += 8 * G) {  // eight of this group's slabs in flight, added in slab order
             f32x4 a[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = ld4(slabs + (size_t)(k + 4 * u) * slab + idx);
+            for (int u = 0; u < 8; ++u) a[u] = ld4(slabs + (size_t)(k + G * u) * slab + idx);
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += a[u];
         }
-        for (; k < splits; k += 4) s += ld4(slabs + (size_t)k * slab + idx);
+        for (; k < splits; k += G) s += ld4(slabs + (size_t)k * slab + idx);
     }
     if (g > 0) part[g - 1][c] = s;
     __syncthreads();
     if (g != 0 || !ok) return;
-    s += part[0][c]; s += part[1][c]; s += part[2][c];
+#pragma unroll
+    for (int w = 0; w < G - 1; ++w) s += part[w][c];
     s *= alpha;
     const int m = (int)(idx / N), n = (int)(idx % N);
     float* o = C + (size_t)m * ldc + n;
@@ -757,8 +762,12 @@ static int launch_slab_reduce(const float* slabs, float* C, long long ldc, int M
                               int accumulate, const float* cs_part, float* cs_out, bool fused_cs, hipStream_t st) {
     const size_t total4 = (size_t)M * N / 4;
     if (splits >= 32 && !fused_cs) {
-        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, slabs, C,
-                           ldc, M, N, splits, alpha, accumulate);
+        if (splits >= 128)
+            hipLaunchKernelGGL(slab_reduce_wide_kernel<16>, dim3((unsigned)((total4 + 63) / 64)), dim3(1024), 0, st,
+                               slabs, C, ldc, M, N, splits, alpha, accumulate);
+        else
+            hipLaunchKernelGGL(slab_reduce_wide_kernel<4>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, slabs,
+                               C, ldc, M, N, splits, alpha, accumulate);
         LAUNCH_CHECK();
         return 0;
     }
