@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include "prof.h"
+#include "internal.h"
 
 extern "C" int ssl4gie_abi_version(void) { return 6; }
 
@@ -142,7 +143,7 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t esize(int dt) { return dt == SSL4GIE_BF16 ? 2 : 4; }
 
 struct BwdLayout {
-    size_t du, dh, dxmid, dxmid_lp, dattn, dqkv, ln_ws, gemm_ws, gemm_ws2, attn_ws, total;
+    size_t du, dh, dxmid, dxmid_lp, dattn, dqkv, ln_ws, ln_ws1, gemm_ws, gemm_ws2, attn_ws, total;
     size_t gemm_ws_bytes;
 };
 
@@ -176,6 +177,7 @@ BwdLayout bwd_layout(const ssl4gie_block_dims* d) {
     L.dattn = o; o += align_up(T * D * es);
     L.dqkv = o; o += align_up(T * 3 * D * es);
     L.ln_ws = o; o += align_up(ssl4gie_layernorm_bwd_workspace_bytes((int)T, (int)D));
+    L.ln_ws1 = o; o += align_up(ssl4gie_layernorm_bwd_workspace_bytes((int)T, (int)D));  // LN1's own partials: LN2's are still being summed on the side stream
     size_t g = 0;
     // the weight gradients run as two pairs: (fc2, fc1) and (proj, qkv)
     const int dims[4][2] = {{(int)D, (int)F}, {(int)F, (int)D}, {(int)D, (int)D}, {(int)(3 * D), (int)D}};
@@ -292,6 +294,7 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     void* dattn = ws + L.dattn;
     void* dqkv = ws + L.dqkv;
     float* ln_ws = (float*)(ws + L.ln_ws);
+    float* ln_ws1 = (float*)(ws + L.ln_ws1);
     void* gws = ws + L.gemm_ws;
     void* gws2 = ws + L.gemm_ws2;
     const void* dy = (dt == SSL4GIE_F32) ? (const void*)dx_out : dx_out_lp;
@@ -325,9 +328,14 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     e.C = dh; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
     RC(linear_bwd_data(du, w->wfc1, w->wfc1_t, T, F, D, dt, e, stream));
     // ---- LN2 (adds the residual gradient dx_out)
+    // with a weight-gradient stream the second stage of both LayerNorm backward passes (the sum of the per-block
+    // dgamma / dbeta partials: a 6-us launch the data-gradient chain would wait for, 40 per MAE step) runs there
+    static int ln_side_on = -1;  // SSL4GIE_LN_SIDE=0: the reductions stay on the caller's stream (A/B timing; same results)
+    if (ln_side_on < 0) { const char* e = getenv("SSL4GIE_LN_SIDE"); ln_side_on = (e && e[0] == '0') ? 0 : 1; }
+    const bool ln_side = ss != nullptr && ln_side_on;
     RC(ssl4gie_layernorm_bwd(dh, dt, a->xmid, w->ln2_g, a->mean2, a->rstd2, dx_out, dxmid,
-                             dt == SSL4GIE_F32 ? nullptr : dxmid_lp, dt, g->ln2_g, g->ln2_b,
-                             accumulate, ln_ws, T, D, stream));
+                             dt == SSL4GIE_F32 ? nullptr : dxmid_lp, dt, ln_side ? nullptr : g->ln2_g,
+                             ln_side ? nullptr : g->ln2_b, accumulate, ln_ws, T, D, stream));
     // ---- proj
     memset(&e, 0, sizeof(e));
     e.C = dattn; e.ldc = D; e.dtype_c = dt; e.epilogue = SSL4GIE_EPI_NONE;
@@ -347,6 +355,8 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
         } else {
             RC(fork());
         }
+        if (ln_side)  // (the stream it is enqueued on has just waited for the caller's: LN2's partials are there)
+            RC(ssl4gie_internal_ln_reduce(ln_ws, g->ln2_g, g->ln2_b, T, D, accumulate, (hipStream_t)wstb));
         wg = wgrad_desc(D, D, T, dxmid_lp, a->attn, g->wproj, g->bproj, dt, accumulate);
         wg2 = wgrad_desc(3 * D, D, T, dqkv, a->h1, g->wqkv, g->bqkv, dt, accumulate);
         RC(ssl4gie_gemm_tn_pair(&wg, &wg2, gws2, L.gemm_ws_bytes, wstb));
@@ -357,8 +367,12 @@ extern "C" int ssl4gie_block_bwd(const ssl4gie_block_dims* d, const ssl4gie_bloc
     RC(linear_bwd_data(dqkv, w->wqkv, w->wqkv_t, T, 3 * D, D, dt, e, stream));
     // ---- LN1 (adds the residual gradient dxmid)
     RC(ssl4gie_layernorm_bwd(dh, dt, x_in, w->ln1_g, a->mean1, a->rstd1, dxmid, dx_in,
-                             dt == SSL4GIE_F32 ? nullptr : dx_in_lp, dt, g->ln1_g, g->ln1_b,
-                             accumulate, ln_ws, T, D, stream));
+                             dt == SSL4GIE_F32 ? nullptr : dx_in_lp, dt, ln_side ? nullptr : g->ln1_g,
+                             ln_side ? nullptr : g->ln1_b, accumulate, ln_side ? ln_ws1 : ln_ws, T, D, stream));
+    if (ln_side) {
+        RC(fork());
+        RC(ssl4gie_internal_ln_reduce(ln_ws1, g->ln1_g, g->ln1_b, T, D, accumulate, ss->s));
+    }
     if (ss && no_join) {  // completion under the caller's slot: ssl4gie_wgrad_wait(slot, stream) before reuse
         HIP_RET(hipEventRecord(ss->ev[6 + slot], ss->s));
         if (ss->s2) HIP_RET(hipEventRecord(ss->ev2[slot], ss->s2));  // (recorded even when unused: the wait is unconditional)

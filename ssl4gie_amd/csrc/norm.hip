@@ -365,6 +365,16 @@ extern "C" int ssl4gie_layernorm_bwd(const void* dy, int dy_dtype, const float* 
     return 0;
 }
 
+int ssl4gie_internal_ln_reduce(const float* workspace, float* dgamma, float* dbeta, int rows, int cols,
+                               int accumulate, hipStream_t st) {
+    if (rows == 0 || !dgamma || !dbeta) return 0;
+    const int nb = ln_bwd_blocks(rows);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * cols + 63) / 64), dim3(64 * RP_WAVES), 0, st, workspace,
+                       dgamma, dbeta, cols, nb, 2 * cols, (size_t)2 * cols, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 static bool colsum_narrow(int cols) { return cols <= 128 && cols % 4 == 0 && ((cols / 4) & (cols / 4 - 1)) == 0; }
 static int colsum_parts(int rows, int cols) {
     const int cap = colsum_narrow(cols) ? 2048 : 256;  // narrow rows: partials are tiny, so more blocks
