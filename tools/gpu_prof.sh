@@ -5,6 +5,8 @@ tag=${1:-r01}; shift || true
 # per-kernel durations are taken with every launch alone on the chip (as bench.py's HIP-event pass
 # does): the block executor's weight-gradient side stream is folded back unless WGRAD_STREAM=1
 export SSL4GIE_WGRAD_STREAM=${WGRAD_STREAM:-0}
+# ... and so is the single layers' weight-gradient stream of the ResNet / DPT paths (engine.wgrad_fork)
+export SSL4GIE_CONV_WGRAD_STREAM=${WGRAD_STREAM:-0}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out

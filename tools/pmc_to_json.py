@@ -8,7 +8,7 @@ import re
 import sys
 
 KINDS = {"gemm_bf16_nt": ("gemm_bf16_nt256_kernel", "gemm_bf16_nt_kernel"),
-         "gemm_bf16_tn": ("gemm_bf16_tn256_kernel", "gemm_bf16_tn_kernel"),
+         "gemm_bf16_tn": ("gemm_bf16_tn256k_kernel", "gemm_bf16_tn256_kernel", "gemm_bf16_tn_kernel"),
          "attn_fwd_bf16": ("attn_fwd_bf16_kernel", "attn_long_fwd_kernel"),
          "attn_bwd_bf16": ("attn_bwd_bf16_kernel", "attn_long_bwd_dq_kernel", "attn_long_bwd_dkv_kernel")}
 
