@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     // pixel, chunk included, and yo[0][*] / yo[1][*] its coordinates (y0 << 16 | x0 & 0xffff)
     unsigned yo[2][2];
     static_assert(CONV == 0 || ROLE == 0, "the gathered operand keeps the two-piece ownership");
-    static_assert(NJ == 4 || (NJ == 3 && ROLE == 0 && CONV == 0), "256 x 192: plain operands, ROLE 0");
+    static_assert(NJ == 4 || ((NJ == 3 || NJ == 2) && ROLE == 0 && CONV == 0), "256 x 192 / 256 x 128: plain operands, ROLE 0");
     constexpr int WN = 16 * NJ;   // columns per wave
     constexpr int BN = 4 * WN;    // columns per tile
 #pragma unroll
@@ -221,7 +221,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
                 };
                 p_glds2v(src(va, ya), src(vb, yb), dst, dst + 1024);
             } else {
-                if constexpr (NJ == 3 && J == 2) {
+                if constexpr (NJ == 2 && J == 2) {
+                    // 256 x 128 tile: the wave's 32 columns are all in B_h0 — no second B half-tile
+                } else if constexpr (NJ == 3 && J == 2) {
                     p_glds1(base, vo[J][0], dst - pbase * 1024 + wave * 1024);
                 } else if constexpr (ROLE == 0) {
                     p_glds2(base, vo[J][0], vo[J][1], dst, dst + 1024);
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     // the K-loop's counted wait: K-tile T + 1 has landed, three half-tiles of K-tile T + 2 may stay in flight
     auto stream_wait = [&](bool more) {
         if (!loader) return;
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ == 3 ? 5 : 3 * NP) : "memory");
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ == 3 ? 5 : (NJ == 2 ? 4 : 3 * NP)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     using I0 = std::integral_constant<int, 0>;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     bf16x8 a[4][2], b0[2][2], b1[2][2];
-    constexpr int NI1 = NJ == 3 ? 1 : 2;  // 16-column blocks in the second B half-tile
+    constexpr int NI1 = NJ == 3 ? 1 : (NJ == 2 ? 0 : 2);  // 16-column blocks in the second B half-tile
 
     // row blocks [MI0, MI1) of quadrant (QM, QN): 16-row x 16-column MFMA tiles over both K-steps of the K-tile
     auto mm = [&](auto QMc, auto QNc, auto MI0c, auto MI1c, bf16x8 (&bb)[2][2]) {
@@ -314,7 +316,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) a[mi][ks] = p_relu8(a[mi][ks]);
         }
-        if constexpr (NJ == 4) {
+        if constexpr (NJ == 2) {  // quadrants (0,0) and (1,0) only: 16 MFMAs in P0 and in P3 (Pa and Pb of the two-phase form)
+            if constexpr (PH == 0) mm(I0{}, I0{}, I0{}, I4{}, b0);
+            if constexpr (PH == 3) mm(I1{}, I0{}, I0{}, I4{}, b0);
+        } else if constexpr (NJ == 4) {
             if constexpr (PH == 0) mm(I0{}, I0{}, I0{}, I4{}, b0);
             if constexpr (PH == 1) mm(I0{}, I1{}, I0{}, I4{}, b1);
             if constexpr (PH == 2) mm(I1{}, I1{}, I0{}, I4{}, b1);
@@ -625,6 +630,21 @@ bool ssl4gie_internal_nt256_ok(const ssl4gie_gemm_desc* d) {
 // tile costs about 0.78 of a 256-wide one (3/4 of the MFMAs and of the epilogue, shorter phases pipeline a
 // little worse; tools/gemm_bench.py).  N = 768 at M = 12800 (ViT-B proj / fc2 and their data gradients):
 // 150 tiles = one round at 62 % of the chip  ->  200 tiles = one round of 0.78.
+// Round 5: a 256 x 128 tile (NJ = 2) for the narrow products of ResNet50 (N = 64 / 128: layer1 / layer2 conv1 and the
+// data gradients into them): one column tile either way, but half (N = 128) or two thirds (N = 64 on the 192-wide
+// tile) of the MFMAs of an HBM-streaming product were spent on columns that do not exist; exists for the epilogue
+// kinds those products use (plain / bias, + statistics, + aux add, affine + aux + ReLU).
+static bool nt256_nj2_mode(const ssl4gie_gemm_desc* d) {
+#ifdef SSL4GIE_DEBUG_KNOBS
+    return false;
+#else
+    static int on = -1;  // SSL4GIE_NT256_NJ2=0: never (A/B timing; same results)
+    if (on < 0) { const char* s = getenv("SSL4GIE_NT256_NJ2"); on = (s && s[0] == '0') ? 0 : 1; }
+    if (!on || d->conv || d->dtype_c != SSL4GIE_BF16) return false;
+    const int ep = d->epilogue;
+    return ep == SSL4GIE_EPI_NONE || ep == SSL4GIE_EPI_BIAS || ep == SSL4GIE_EPI_ADD_AUX || ep == SSL4GIE_EPI_AFFINE_AUX_RELU;
+#endif
+}
 static int nt256_pick_nj(const ssl4gie_gemm_desc* d, int cus) {
     if (d->conv) return 4;
 #ifdef SSL4GIE_DEBUG_KNOBS
@@ -638,7 +658,9 @@ static int nt256_pick_nj(const ssl4gie_gemm_desc* d, int cus) {
     const long long tm = (d->M + P_BM - 1) / P_BM;
     const long long r256 = (tm * ((d->N + 255) / 256) + cus - 1) / cus;
     const long long r192 = (tm * ((d->N + 191) / 192) + cus - 1) / cus;
-    return (double)r192 * 0.78 < (double)r256 ? 3 : 4;
+    int nj = (double)r192 * 0.78 < (double)r256 ? 3 : 4;
+    if (d->N <= 128 && nt256_nj2_mode(d)) nj = 2;  // one column tile whatever the width: the narrowest that holds N
+    return nj;
 }
 
 int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
@@ -710,6 +732,15 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         else P_LAUNCH_R(TC_, MODE_, 0, false, NT256_DEFAULT_ROLE, 4, NT256_DEFAULT_PH2);   \
     } while (0)
 #endif
+#ifdef SSL4GIE_DEBUG_KNOBS
+#define P_LAUNCH2(TC_, MODE_) P_LAUNCH(TC_, MODE_)
+#else
+#define P_LAUNCH2(TC_, MODE_) /* the epilogue kinds that also exist on the 256 x 128 tile (nt256_nj2_mode) */ \
+    do {                                                                                   \
+        if (nj == 2) P_LAUNCH_R(TC_, MODE_, 0, false, 0, 2, NT256_DEFAULT_PH2);            \
+        else P_LAUNCH(TC_, MODE_);                                                         \
+    } while (0)
+#endif
 #define P_LAUNCH_C(TC_, MODE_, CONV_) P_LAUNCH_S(TC_, MODE_, CONV_, false)
 #ifdef SSL4GIE_DEBUG_KNOBS
 #define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_)                            \
@@ -736,6 +767,9 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     if (d->colstats) {  // bf16, plain epilogue (checked by nt256_ok)
         const int cv = d->conv ? (d->conv->relu ? 2 : 1) : 0;
         if (cv == 0 && nj == 3) P_LAUNCH_R(bf16_t, SSL4GIE_EPI_NONE, 0, true, 0, 3, NT256_DEFAULT_PH2);
+#ifndef SSL4GIE_DEBUG_KNOBS
+        else if (cv == 0 && nj == 2) P_LAUNCH_R(bf16_t, SSL4GIE_EPI_NONE, 0, true, 0, 2, NT256_DEFAULT_PH2);
+#endif
         else if (cv == 0) P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 0, true);
         else if (cv == 1) P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 1, true);
         else P_LAUNCH_S(bf16_t, SSL4GIE_EPI_NONE, 2, true);
@@ -748,14 +782,14 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         else P_LAUNCH_C(bf16_t, SSL4GIE_EPI_NONE, 1);
     } else if (d->dtype_c == SSL4GIE_BF16) {
         switch (d->epilogue) {
-            case SSL4GIE_EPI_BIAS: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS); break;
+            case SSL4GIE_EPI_BIAS: P_LAUNCH2(bf16_t, SSL4GIE_EPI_BIAS); break;
             case SSL4GIE_EPI_BIAS_GELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU); break;
             case SSL4GIE_EPI_DGELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_DGELU); break;
             case SSL4GIE_EPI_BIAS_GELU_GRAD: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU_GRAD); break;
             case SSL4GIE_EPI_MUL_AUX: P_LAUNCH(bf16_t, SSL4GIE_EPI_MUL_AUX); break;
-            case SSL4GIE_EPI_ADD_AUX: P_LAUNCH(bf16_t, SSL4GIE_EPI_ADD_AUX); break;
-            case SSL4GIE_EPI_AFFINE_AUX_RELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_AFFINE_AUX_RELU); break;
-            case SSL4GIE_EPI_NONE: P_LAUNCH(bf16_t, SSL4GIE_EPI_NONE); break;
+            case SSL4GIE_EPI_ADD_AUX: P_LAUNCH2(bf16_t, SSL4GIE_EPI_ADD_AUX); break;
+            case SSL4GIE_EPI_AFFINE_AUX_RELU: P_LAUNCH2(bf16_t, SSL4GIE_EPI_AFFINE_AUX_RELU); break;
+            case SSL4GIE_EPI_NONE: P_LAUNCH2(bf16_t, SSL4GIE_EPI_NONE); break;
             default: return ARG_ERR;
         }
     } else {
@@ -767,6 +801,7 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         }
     }
 #undef P_LAUNCH
+#undef P_LAUNCH2
 #undef P_LAUNCH_C
 #undef P_LAUNCH_S
 #undef P_LAUNCH_R
