@@ -593,7 +593,6 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, (AttnBwdU<HD, NKT>::
     }
 }
 
-
 // ------------------------------------------------------------------ streaming kernels (N > 128)
 // Streaming ("flash") variants for sequences that do not fit the whole-head kernels above (N > 256):
 // the detection backbone's global blocks (N = 4096; reference models.py:281-285,310-336) and other
