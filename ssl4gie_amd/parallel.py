@@ -559,10 +559,12 @@ def syncbn_exchange(process_group=None, max_channels: int = 8192):
 
 
 def comm_cus() -> int:
-    """CUs left to the communication kernels in data-parallel runs (SSL4GIE_COMM_CUS, default 32:
-    the MAE step time is flat between 208 and 256 compute CUs, profiles/r01o_*)"""
+    """CUs left to the communication kernels in data-parallel runs (SSL4GIE_COMM_CUS, default 24: the persistent GEMM
+    grids take whole rounds of tiles, and with the round-5 kernels the MAE step costs 22.24 ms at 232 and 240 compute
+    CUs, 22.27 at 248, 22.5 at 208 / 216 but 22.8-23.0 at 224 — the former default of 32 sat on the one bad
+    count: the decoder's fc1 / qkv products go from 7 / 5 rounds of tiles to 8 / 6; profiles/r05t_compute_cus_sweep.log)"""
     import os
-    return max(0, min(128, int(os.environ.get("SSL4GIE_COMM_CUS", "32"))))
+    return max(0, min(128, int(os.environ.get("SSL4GIE_COMM_CUS", "24"))))
 
 
 def init_from_env(backend: Optional[str] = None):
