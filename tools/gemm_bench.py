@@ -38,6 +38,9 @@ if os.environ.get("PROBE"):
           ("tall_k2k", 50432, 512, 2048, "none"), ("wide", 12800, 3072, 768, "none"),
           ("wide_k3k", 12800, 3072, 3072, "none")]
     TN = []
+if os.environ.get("GEMM_CASES"):  # comma-separated names
+    keep = set(os.environ["GEMM_CASES"].split(","))
+    NT = [c for c in NT if c[0] in keep]; TN = [c for c in TN if c[0] in keep]
 tot_ms = tot_fl = 0
 for name, T, n, k, ep in NT:
     x = (torch.randn(T, k, device=dev) * 0.5).bfloat16()
