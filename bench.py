@@ -357,14 +357,20 @@ def timed_steps(step, a, world, dev, ddp=None):
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if cuda else None
     fence()
     t0 = time.perf_counter()
+    host = []
     for i in range(a.steps):
         if cuda:
             evs[i].record()
+        h0 = time.perf_counter()
         loss = step()
+        host.append(time.perf_counter() - h0)
     if cuda:
         evs[a.steps].record()
     fence()
     dt = time.perf_counter() - t0
+    # host time inside step(): the first timed step starts on an idle GPU with empty queues, so its host time is the
+    # pure enqueue cost of a step (no back-pressure from a full queue); well under ms_per_step = the GPU is the bound
+    a.host_enqueue_ms = round(1e3 * host[0], 3) if host else None
     a.median_ms_per_step = None
     if cuda:
         per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
@@ -429,7 +435,7 @@ def bench_depth(a):
             "metric": "images/sec (fwd+bwd+AdamW) ViT-B + DPT depth finetune 224x224 (BASELINE.json configs[3])",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
+            "median_ms_per_step": a.median_ms_per_step, "host_enqueue_ms": a.host_enqueue_ms, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "ViT_from_MAE(dense='depth') + DPT_decoder + SSI loss(alpha=0.1) + "
                                    "AdamW(1e-4), synthetic img + depth resident in HBM",
@@ -492,7 +498,7 @@ def bench_moco(a):
             "metric": "image pairs/sec (fwd+bwd+LARS) MoCo-v3 ResNet50 224x224 (BASELINE.json configs[2])",
             "value": round(ips, 1), "unit": "image pairs/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
+            "median_ms_per_step": a.median_ms_per_step, "host_enqueue_ms": a.host_enqueue_ms, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "MoCo_ResNet(resnet50, 256, 4096, T=1.0), m=0.99, two synthetic views "
                                    "resident in HBM, LARS",
@@ -547,7 +553,7 @@ def bench_vit(a):
             "metric": "images/sec (fwd+bwd+AdamW) ViT-B 224x224 linear-head finetune, un-masked trunk",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
+            "median_ms_per_step": a.median_ms_per_step, "host_enqueue_ms": a.host_enqueue_ms, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "ViT_from_MAE(head=True, num_classes=6) + cross entropy + AdamW(1e-4), "
                                    "synthetic images resident in HBM",
@@ -608,7 +614,7 @@ def bench_det(a):
             "metric": "images/sec (fwd+bwd+AdamW) detection ViT-B backbone + ViTDet FPN 1024x1024 (SURVEY 8f-1)",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
+            "median_ms_per_step": a.median_ms_per_step, "host_enqueue_ms": a.host_enqueue_ms, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "VisionTransformer_from_Any(det=True, fixed_size=1024) + ViTDet_FPN, "
                                    "synthetic images resident in HBM, quadratic loss on the pyramid maps",
@@ -676,7 +682,7 @@ def bench_bt(a):
             "metric": "images/sec (two views, fwd+bwd+LARS) Barlow Twins ViT-B 224x224 (BASELINE.json configs[4])",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "median_ms_per_step": a.median_ms_per_step, "roofline": roof, "higher_is_better": True,
+            "median_ms_per_step": a.median_ms_per_step, "host_enqueue_ms": a.host_enqueue_ms, "roofline": roof, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "BarlowTwins(ViT-B trunk, projector 8192-8192-8192, lambda 0.0051), two "
                                    "synthetic views resident in HBM, LARS; own specification (absent "
@@ -823,7 +829,7 @@ def main():
         line = {
             "metric": METRIC, "value": round(ips, 1), "unit": "images/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "median_ms_per_step": a.median_ms_per_step,
+            "median_ms_per_step": a.median_ms_per_step, "host_enqueue_ms": a.host_enqueue_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",
             "config": {"workload": "ViT-B MAE pretrain (mae_vit_base_patch16, norm_pix_loss, "
