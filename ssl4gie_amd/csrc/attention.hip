@@ -311,79 +311,26 @@ template <int NKT> struct AttnBwdWaves {
 // tiles a wave works on at once (see "U tiles per wave" in the kernel): 2 where the LDS images leave room for one
 // workgroup per CU anyway, i.e. hd 64 from 10 tiles on (4 images x 160 rows x 128 B = 80 KB)
 template <int HD, int NKT> struct AttnBwdU { static constexpr int value = (HD == 64 && NKT >= 10) ? 2 : 1; };
-// HT as in the forward kernel: the last pair of key tiles (phase A) / query tiles (phase B) is a single tile
-template <int HD, int NKT, bool HT>
-__global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, (AttnBwdU<HD, NKT>::value == 2 ? 2 : 4)) void attn_bwd_bf16_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-    int N, int H, float scale) {
-    constexpr int NPAD = NKT * 16, RB = HD * 2, KS = HD / 32, DT = HD / 16, CPR = HD / 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Kimg = smem;
-    char* Vimg = smem + NPAD * RB;
-    char* Qimg = smem + 2 * NPAD * RB;
-    char* Oimg = smem + 3 * NPAD * RB;  // dO
-    float* lse_s = (float*)(smem + 4 * NPAD * RB);
-    float* del_s = lse_s + NPAD;  // -delta
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    // consecutive (b, h) ids share an XCD: with hd = 32 two neighbouring heads share every 128-B
-    // line of the packed qkv rows, so the second one hits in that XCD's L2
-    const int bh = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = bh / H, h = bh % H;
-    const int D = H * HD;
-    const long long rs = 3LL * D;
-    const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
-    const bf16_t* ob = out + (size_t)b * N * D + h * HD;
-    const bf16_t* dob = dout + (size_t)b * N * D + h * HD;
-    bf16_t* dqb = dqkv + (size_t)b * N * rs + h * HD;
-    const float* lrow = lse + ((size_t)b * H + h) * N;
-    const float LOG2E = 1.44269504088896340736f;
-    const float c = scale * LOG2E;
-
-    constexpr int ATTN_BWD_WAVES = AttnBwdWaves<NKT>::value, NTH = 64 * ATTN_BWD_WAVES;
-    constexpr int BWD_U = AttnBwdU<HD, NKT>::value;
-    // ---------------- prologue: stage K, V, Q, dO; delta and lse rows.  EVERY global load of the prologue is issued
-    // before the first LDS write — one HBM round trip per workgroup instead of three (Q/K/V, then dO/O, then lse:
-    // with two workgroups per CU nothing hides them, and this kernel's time follows its bytes: profiles/r04dd)
-    {
-        constexpr int TOTAL = NPAD * CPR, IT = (TOTAL + NTH - 1) / NTH;  // TOTAL % 64 == 0: wave-uniform guards
-        static_assert(NTH >= NPAD, "one lse row per thread");
-        u32x4 kk[IT], vk[IT], qq[IT], vv[IT], oo[IT];
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
-            const bool ok = idx < TOTAL && row < N;
-            const size_t off = (size_t)row * rs + ch * 8, offo = (size_t)row * D + ch * 8;
-            const u32x4 z = {0, 0, 0, 0};
-            kk[i] = ok ? *(const u32x4*)(qb + D + off) : z;
-            vk[i] = ok ? *(const u32x4*)(qb + 2 * D + off) : z;
-            qq[i] = ok ? *(const u32x4*)(qb + off) : z;
-            vv[i] = ok ? *(const u32x4*)(dob + offo) : z;
-            oo[i] = ok ? *(const u32x4*)(ob + offo) : z;
-        }
-        const float lv = tid < N ? lrow[tid] : 0.f;
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
-            if (idx < TOTAL) {
-                *(u32x4*)(Kimg + img_off<HD>(row, ch)) = kk[i];
-                *(u32x4*)(Vimg + img_off<HD>(row, ch)) = vk[i];
-                *(u32x4*)(Qimg + img_off<HD>(row, ch)) = qq[i];
-                float dot = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    dot += __uint_as_float(vv[i][j] << 16) * __uint_as_float(oo[i][j] << 16);
-                    dot += __uint_as_float(vv[i][j] & 0xffff0000u) * __uint_as_float(oo[i][j] & 0xffff0000u);
-                }
-                *(u32x4*)(Oimg + img_off<HD>(row, ch)) = vv[i];
-#pragma unroll
-                for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);  // the row's CPR lanes
-                if (ch == 0) del_s[row] = -dot;  // kept negated: see softmax_bwd4
-            }
-        }
-        if (tid < NPAD) lse_s[tid] = tid < N ? lv * LOG2E : INFINITY;  // padded queries: P = 0
-    }
-    __syncthreads();
+// The two phases of the whole-head backward on staged LDS images (K, V, Q, dO, then lse and -delta rows), shared by the
+// one-head-per-workgroup kernel and the persistent prefetching kernel below.  `hook` lets the caller run code at two
+// points of phase B (wave-uniform, every wave of the workgroup reaches them once per head): after the wave's own K / V
+// fragments are in registers, and before each query pair.
+struct AttnBwdNoHook {
+    DEVI void after_kv_frags() const {}
+    DEVI void before_query_pair(int) const {}
+};
+template <int HD, int NKT, bool HT, class Hook>
+DEVI void attn_bwd_phases(char* smem, bf16_t* __restrict__ dqb, const int N, const long long rs, const int D,
+                          const float c, const float scale, const int tid, Hook&& hook) {
+    constexpr int NPAD = NKT * 16, RB = HD * 2, KS = HD / 32, DT = HD / 16;
+    constexpr int ATTN_BWD_WAVES = AttnBwdWaves<NKT>::value, BWD_U = AttnBwdU<HD, NKT>::value;
+    const char* Kimg = smem;
+    const char* Vimg = smem + NPAD * RB;
+    const char* Qimg = smem + 2 * NPAD * RB;
+    const char* Oimg = smem + 3 * NPAD * RB;  // dO
+    const float* lse_s = (const float*)(smem + 4 * NPAD * RB);
+    const float* del_s = lse_s + NPAD;  // -delta
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int nqt = (N + 15) >> 4;
 
     // U tiles per wave AT ONCE (register blocking).  hd 64 above 144 tokens needs > 80 KB of LDS: one workgroup per
@@ -513,10 +460,12 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, (AttnBwdU<HD, NKT>::
                 dv[u][dt] = f32x4{0, 0, 0, 0};
             }
         }
+        hook.after_kv_frags();  // the wave's own K / V fragments are in registers: it no longer reads the K / V images
         // HT: the last pair's second query tile is all padding — its scores are skipped (a wave-uniform branch, not
         // a peeled copy of the body: the copy costs registers and spills at hd 64) and its P / dS are zeros
 #pragma unroll 1
         for (int qp = 0; qp < NKT / 2; ++qp) {
+            hook.before_query_pair(qp);
             const bool full = !HT || qp < NKT / 2 - 1;
             const int qa = qp * 32 + 4 * g;
             // the dP accumulators start at -delta of their query rows (softmax_bwd4)
@@ -590,6 +539,219 @@ __global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, (AttnBwdU<HD, NKT>::
             }
         }
         if (NKT <= ATTN_BWD_WAVES * U) break;
+    }
+}
+
+// HT as in the forward kernel: the last pair of key tiles (phase A) / query tiles (phase B) is a single tile
+template <int HD, int NKT, bool HT>
+__global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, (AttnBwdU<HD, NKT>::value == 2 ? 2 : 4)) void attn_bwd_bf16_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+    int N, int H, float scale) {
+    constexpr int NPAD = NKT * 16, RB = HD * 2, CPR = HD / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kimg = smem;
+    char* Vimg = smem + NPAD * RB;
+    char* Qimg = smem + 2 * NPAD * RB;
+    char* Oimg = smem + 3 * NPAD * RB;  // dO
+    float* lse_s = (float*)(smem + 4 * NPAD * RB);
+    float* del_s = lse_s + NPAD;  // -delta
+    const int tid = threadIdx.x;
+    // consecutive (b, h) ids share an XCD: with hd = 32 two neighbouring heads share every 128-B
+    // line of the packed qkv rows, so the second one hits in that XCD's L2
+    const int bh = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bh / H, h = bh % H;
+    const int D = H * HD;
+    const long long rs = 3LL * D;
+    const bf16_t* qb = qkv + (size_t)b * N * rs + h * HD;
+    const bf16_t* ob = out + (size_t)b * N * D + h * HD;
+    const bf16_t* dob = dout + (size_t)b * N * D + h * HD;
+    bf16_t* dqb = dqkv + (size_t)b * N * rs + h * HD;
+    const float* lrow = lse + ((size_t)b * H + h) * N;
+    const float LOG2E = 1.44269504088896340736f;
+    const float c = scale * LOG2E;
+
+    constexpr int ATTN_BWD_WAVES = AttnBwdWaves<NKT>::value, NTH = 64 * ATTN_BWD_WAVES;
+    // ---------------- prologue: stage K, V, Q, dO; delta and lse rows.  EVERY global load of the prologue is issued
+    // before the first LDS write — one HBM round trip per workgroup instead of three (Q/K/V, then dO/O, then lse:
+    // with two workgroups per CU nothing hides them, and this kernel's time follows its bytes: profiles/r04dd)
+    {
+        constexpr int TOTAL = NPAD * CPR, IT = (TOTAL + NTH - 1) / NTH;  // TOTAL % 64 == 0: wave-uniform guards
+        static_assert(NTH >= NPAD, "one lse row per thread");
+        u32x4 kk[IT], vk[IT], qq[IT], vv[IT], oo[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
+            const bool ok = idx < TOTAL && row < N;
+            const size_t off = (size_t)row * rs + ch * 8, offo = (size_t)row * D + ch * 8;
+            const u32x4 z = {0, 0, 0, 0};
+            kk[i] = ok ? *(const u32x4*)(qb + D + off) : z;
+            vk[i] = ok ? *(const u32x4*)(qb + 2 * D + off) : z;
+            qq[i] = ok ? *(const u32x4*)(qb + off) : z;
+            vv[i] = ok ? *(const u32x4*)(dob + offo) : z;
+            oo[i] = ok ? *(const u32x4*)(ob + offo) : z;
+        }
+        const float lv = tid < N ? lrow[tid] : 0.f;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
+            if (idx < TOTAL) {
+                *(u32x4*)(Kimg + img_off<HD>(row, ch)) = kk[i];
+                *(u32x4*)(Vimg + img_off<HD>(row, ch)) = vk[i];
+                *(u32x4*)(Qimg + img_off<HD>(row, ch)) = qq[i];
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dot += __uint_as_float(vv[i][j] << 16) * __uint_as_float(oo[i][j] << 16);
+                    dot += __uint_as_float(vv[i][j] & 0xffff0000u) * __uint_as_float(oo[i][j] & 0xffff0000u);
+                }
+                *(u32x4*)(Oimg + img_off<HD>(row, ch)) = vv[i];
+#pragma unroll
+                for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);  // the row's CPR lanes
+                if (ch == 0) del_s[row] = -dot;  // kept negated: see softmax_bwd4
+            }
+        }
+        if (tid < NPAD) lse_s[tid] = tid < N ? lv * LOG2E : INFINITY;  // padded queries: P = 0
+    }
+    __syncthreads();
+    attn_bwd_phases<HD, NKT, HT>(smem, dqb, N, rs, D, c, scale, tid, AttnBwdNoHook{});
+}
+
+// PERSISTENT, PREFETCHING form for the shapes that leave room for ONE workgroup per CU (hd 64 from 10 tiles on: the four
+// images are 80-128 KB).  With one workgroup per CU nothing overlaps a head's operand round trip and its stores with
+// arithmetic: at N = 197 the staging + stores alone take 144 us and the phases alone 186 us of the kernel's 263
+// (profiles/r05o).  Here a workgroup walks heads first, first + grid, ... and fetches the NEXT head while phase B of the
+// current one runs, in two batches through 3 IT staging registers (48 VGPRs at N = 197):
+//   - after every wave holds its own K / V fragments (barrier 1) the K / V images are dead: the next head's K / V rows are
+//     loaded into registers, and written into the K / V images a few query pairs later;
+//   - from then on the same registers carry the next head's Q / dO / O rows (and its lse), which are written (with the new
+//     -delta rows) when the last wave has left phase B (barrier 2); barrier 3 opens the next head's phase A.
+// At hd 32 (two workgroups per CU, which overlap each other's round trips on their own) the same kernel is SLOWER
+// (N = 197: 176 -> 206 us; profiles/r05z): those shapes keep one workgroup per head.
+// The head id and the thread id enter the loaders as OPAQUE values: left to itself the compiler hoists the loop-invariant
+// lane offsets as 64-bit pairs and strength-reduces the addresses into per-lane induction variables — 20+ VGPRs held
+// across the phases, spills, and a vmcnt(0) behind each scratch reload, i.e. a wait on the prefetch itself.
+template <class F1, class F2> struct AttnBwdHook {
+    F1 f1; F2 f2;
+    DEVI void after_kv_frags() { f1(); }
+    DEVI void before_query_pair(int qp) { f2(qp); }
+};
+template <class F1, class F2> DEVI AttnBwdHook<F1, F2> attn_bwd_hook(F1 f1, F2 f2) { return AttnBwdHook<F1, F2>{f1, f2}; }
+template <int HD, int NKT, bool HT>
+__global__ __launch_bounds__(64 * AttnBwdWaves<NKT>::value, 2) void attn_bwd_pf_bf16_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+    int N, int H, float scale, int nheads) {
+    constexpr int NPAD = NKT * 16, RB = HD * 2, CPR = HD / 8;
+    constexpr int NTH = 64 * AttnBwdWaves<NKT>::value, TOTAL = NPAD * CPR, IT = (TOTAL + NTH - 1) / NTH;
+    constexpr int QSW = NKT / 4;  // query pair of phase B before which the staging registers change hands
+    static_assert(NTH >= NPAD, "one lse row per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kimg = smem;
+    char* Vimg = smem + NPAD * RB;
+    char* Qimg = smem + 2 * NPAD * RB;
+    char* Oimg = smem + 3 * NPAD * RB;  // dO
+    float* lse_s = (float*)(smem + 4 * NPAD * RB);
+    float* del_s = lse_s + NPAD;  // -delta
+    const int tid = threadIdx.x;
+    const int D = H * HD;
+    const long long rs = 3LL * D;
+    const float LOG2E = 1.44269504088896340736f;
+    const float c = scale * LOG2E;
+    const int first = xcd_remap(blockIdx.x, gridDim.x), stride = (int)gridDim.x;
+    u32x4 ra[IT], rb[IT], rc[IT];
+    float lv = 0.f;
+    // rows of the packed qkv tensor (which = 0 Q, 1 K, 2 V) and of out / dout; uniform base + 32-bit lane offset
+    auto load_kv = [&](const int bh_) {
+        int bh = __builtin_amdgcn_readfirstlane(bh_), t = tid;
+        asm volatile("" : "+s"(bh), "+v"(t));
+        const char* qb = (const char*)(qkv + (size_t)(bh / H) * N * rs + (bh % H) * HD);
+        const char* kb = qb + 2 * D, *vb = qb + 4 * D;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = t + i * NTH, row = idx / CPR, ch = idx % CPR;
+            const bool ok = idx < TOTAL && row < N;
+            const unsigned off = (unsigned)(row * (int)rs + ch * 8) * 2u;
+            const u32x4 z = {0, 0, 0, 0};
+            ra[i] = ok ? *(const u32x4*)(kb + off) : z;
+            rb[i] = ok ? *(const u32x4*)(vb + off) : z;
+        }
+    };
+    auto load_qoo = [&](const int bh_) {
+        int bh = __builtin_amdgcn_readfirstlane(bh_), t = tid;
+        asm volatile("" : "+s"(bh), "+v"(t));
+        const int b = bh / H, h = bh % H;
+        const char* qb = (const char*)(qkv + (size_t)b * N * rs + h * HD);
+        const char* ob = (const char*)(out + (size_t)b * N * D + h * HD);
+        const char* dob = (const char*)(dout + (size_t)b * N * D + h * HD);
+        const char* lb = (const char*)(lse + ((size_t)b * H + h) * N);
+        lv = t < N ? *(const float*)(lb + (unsigned)t * 4u) : 0.f;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = t + i * NTH, row = idx / CPR, ch = idx % CPR;
+            const bool ok = idx < TOTAL && row < N;
+            const unsigned off = (unsigned)(row * (int)rs + ch * 8) * 2u, offo = (unsigned)(row * D + ch * 8) * 2u;
+            const u32x4 z = {0, 0, 0, 0};
+            ra[i] = ok ? *(const u32x4*)(qb + off) : z;
+            rb[i] = ok ? *(const u32x4*)(dob + offo) : z;
+            rc[i] = ok ? *(const u32x4*)(ob + offo) : z;
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
+            if (idx < TOTAL) {
+                *(u32x4*)(Kimg + img_off<HD>(row, ch)) = ra[i];
+                *(u32x4*)(Vimg + img_off<HD>(row, ch)) = rb[i];
+            }
+        }
+    };
+    auto store_qoo = [&]() {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTH, row = idx / CPR, ch = idx % CPR;
+            if (idx < TOTAL) {
+                *(u32x4*)(Qimg + img_off<HD>(row, ch)) = ra[i];
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dot += __uint_as_float(rb[i][j] << 16) * __uint_as_float(rc[i][j] << 16);
+                    dot += __uint_as_float(rb[i][j] & 0xffff0000u) * __uint_as_float(rc[i][j] & 0xffff0000u);
+                }
+                *(u32x4*)(Oimg + img_off<HD>(row, ch)) = rb[i];
+#pragma unroll
+                for (int o = CPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);  // the row's CPR lanes
+                if (ch == 0) del_s[row] = -dot;  // kept negated: see softmax_bwd4
+            }
+        }
+        if (tid < NPAD) lse_s[tid] = tid < N ? lv * LOG2E : INFINITY;  // padded queries: P = 0
+    };
+    // the first head: nothing to hide its operands behind
+    load_kv(first);
+    store_kv();
+    load_qoo(first);
+    store_qoo();
+    __syncthreads();
+#pragma unroll 1
+    for (int bh = first; bh < nheads; bh += stride) {
+        const bool more = bh + stride < nheads;
+        bf16_t* dqb = dqkv + (size_t)(bh / H) * N * rs + (bh % H) * HD;
+        attn_bwd_phases<HD, NKT, HT>(smem, dqb, N, rs, D, c, scale, tid, attn_bwd_hook(
+            [&]() {
+                __syncthreads();  // barrier 1: no wave reads the K / V images of this head any more
+                if (more) load_kv(bh + stride);
+            },
+            [&](const int qp) {
+                if (qp == QSW && more) {
+                    store_kv();
+                    load_qoo(bh + stride);
+                }
+            }));
+        if (!more) break;
+        __syncthreads();  // barrier 2: every wave has left this head's Q / dO images and statistics rows
+        store_qoo();
+        __syncthreads();  // barrier 3
     }
 }
 
@@ -1044,6 +1206,39 @@ static int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int 
     LAUNCH_CHECK();
     return 0;
 }
+static bool attn_prefetch() {  // SSL4GIE_ATTN_PREFETCH=0: the one-head-per-workgroup kernel everywhere (A/B; same results)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SSL4GIE_ATTN_PREFETCH"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+template <int HD, int NKT, bool HT>
+static int launch_bwd_pf(const void* qkv, const void* out, const void* dout, const float* lse,
+                         void* dqkv, int B, int N, int H, float scale, hipStream_t st) {
+    constexpr int W = AttnBwdWaves<NKT>::value;
+    const size_t lds = (size_t)4 * NKT * 16 * HD * 2 + 2 * NKT * 16 * sizeof(float);
+    auto k = attn_bwd_pf_bf16_kernel<HD, NKT, HT>;
+    static int slots = 0;  // per instantiation: workgroups the chip holds at once
+    if (!slots) {
+        HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0, dev = 0, cus = 0;
+        HIP_RET(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, 64 * W, lds));
+        HIP_RET(hipGetDevice(&dev));
+        HIP_RET(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        slots = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);
+    }
+    REQUIRE(((N + 15) >> 4) >= W);  // every wave owns a tile in both phases: the hooks' barriers are reached by all
+    const int heads = B * H;
+    int grid = heads;
+    if (heads > slots) {  // every workgroup walks the same number of heads (+- 1)
+        const int rounds = (heads + slots - 1) / slots;
+        grid = (heads + rounds - 1) / rounds;
+    }
+    ProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * HD, st);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * W), lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale, heads);
+    LAUNCH_CHECK();
+    return 0;
+}
 template <int HD, int NKT, bool HT>
 static int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                       void* dqkv, int B, int N, int H, float scale, hipStream_t st) {
@@ -1184,6 +1379,10 @@ extern "C" int ssl4gie_attn_bwd(const void* qkv, const void* out, const void* do
         }
         REQUIRE(N <= 256);
 #define BWD_HT(HD_, NKT_)                                                                          \
+    if (HD_ == 64 && NKT_ >= 10 && attn_prefetch()) /* one workgroup per CU: persistent + prefetch */ \
+        return (N <= 16 * (NKT_ - 1) && attn_half_tail())                                              \
+                   ? launch_bwd_pf<64, (NKT_ >= 10 ? NKT_ : 10), true>(qkv, out, dout, lse, dqkv, B, N, H, scale, st) \
+                   : launch_bwd_pf<64, (NKT_ >= 10 ? NKT_ : 10), false>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);     \
     return (HD_ == 64 && N <= 16 * (NKT_ - 1) && attn_half_tail()) /* hd 32: measured no gain */   \
                ? launch_bwd<HD_, NKT_, HD_ == 64>(qkv, out, dout, lse, dqkv, B, N, H, scale, st)   \
                : launch_bwd<HD_, NKT_, false>(qkv, out, dout, lse, dqkv, B, N, H, scale, st)
