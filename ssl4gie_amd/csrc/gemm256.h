@@ -109,7 +109,26 @@ DEVI bf16x8 p_relu8(bf16x8 v) {
 // c ^ r (ds_write_b128 and ds_read_b128 conflict-free, tools/lds_bank_sim.py).
 // NJ: 16-column accumulator blocks per wave (4: 128 x 64 wave tile; 3: 128 x 48, the 256 x 192 variant — the
 // staging image keeps its 64-column geometry, lanes that would own columns 48 .. 63 stay idle).
-template <bool FULL, bool RESID, int NJ = 4>
+// Output stores of the epilogues can be NON-TEMPORAL (`nt`, chosen per launch: ssl4gie_internal_nt256_launch).  A round of
+// tiles writes 7.8 MB per XCD through a 4 MiB L2 and evicts the weight panels every workgroup re-reads in the next round
+// (dec.fc1: 157 MB read per launch against 36 MB algorithmic, profiles/r05_pmc_summary.txt); streamed past the L2 the
+// outputs leave them in place: dec.fc1 169 -> 152 us, dec.dfc2 144 -> 128, dec.proj 58 -> 53 (profiles/r05nt).  The
+// short encoder products (1-3 rounds of tiles, outputs the next kernel finds in cache) lose 1-4 % and keep plain stores;
+// non-temporal LOADS of the residual / aux tiles measured worse and are not used.
+// (A compile-time choice: behind a runtime flag the compiler merges the two stores and drops the hint.)
+template <bool NT, class V> DEVI void est(V* p, V v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool NT> DEVI void est4(float* p, f32x4 v) { est<NT>((f32x4*)p, v); }
+template <bool NT> DEVI void est4(bf16_t* p, f32x4 v) {
+    u32x2 r;
+    r[0] = pack_bf2(v[0], v[1]);
+    r[1] = pack_bf2(v[2], v[3]);
+    est<NT>((u32x2*)p, r);
+}
+
+template <bool FULL, bool RESID, int NJ = 4, bool NT = false>
 DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f32x4 bias_t /* columns gn .. gn + 3 */,
                       const float* __restrict__ residual, const long long ldr, const bool accumulate,
                       float* __restrict__ C, const long long ldc, int rbase, int cbase, int M, int N,
@@ -167,7 +186,7 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
             if (mine && (FULL || (gm < M && gn < N))) {
                 float* c = C + (size_t)gm * ldc + gn;
                 if (accumulate) w[q] += ld4(c);
-                st4(c, w[q]);
+                est4<NT>(c, w[q]);
             }
         }
         if constexpr (RESID) {
@@ -182,7 +201,7 @@ DEVI void p_store_f32(f32x4 (&acc)[8][4], char* stg, const float alpha, const f3
 // AUXF: 1 multiply by aux, 2 multiply by gelu'(aux), 3 zero where aux <= 0 (ReLU mask), 4 add aux,
 // 5 per-column affine, optional aux, optional ReLU: act(acc scale[n] + shift[n] (+ aux)) — the BatchNorm that
 // follows a 1x1 convolution (+ the bottleneck's residual add and ReLU) applied to the fp32 accumulators.
-template <bool FULL, int AUXF, int NJ = 4>
+template <bool FULL, int AUXF, int NJ = 4, bool NT = false>
 DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
                            const bf16_t* __restrict__ aux, bf16_t* __restrict__ C,
                            const long long ldc, int rbase, int cbase, int M, int N, int lane,
@@ -254,7 +273,7 @@ DEVI void p_store_bf16_aux(f32x4 (&acc)[8][4], char* stg, const float alpha,
             } else {
                 w[q] *= u;
             }
-            if (mine && (FULL || (gm < M && gn < N))) st4(C + (size_t)gm * ldc + gn, w[q]);
+            if (mine && (FULL || (gm < M && gn < N))) est4<NT>(C + (size_t)gm * ldc + gn, w[q]);
         }
         if (mt + PF < 8) fetch(mt + PF, ax[mt % PF]);
     }
@@ -286,7 +305,7 @@ DEVI float p_fold_lanes8(float v) {
 // (Round 4, measured and dropped: reading the whole residual tile FIRST, in the accumulator layout, and folding it
 // into the accumulators before a plain fp32 store phase — dec.proj 57 -> 65 us: two serial phases lose more than
 // the loads gain by not queueing behind stores; profiles/r04g_nt_epilogue_residual_first.log.)
-template <typename TC, int MODE, bool FULL, bool STATS, bool BIAS_LDS = false, int NJ = 4>
+template <typename TC, int MODE, bool FULL, bool STATS, bool BIAS_LDS = false, int NJ = 4, bool NT = false>
 DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                      const float* __restrict__ bias, const float* __restrict__ residual,
                      const long long ldr, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out2,
@@ -328,13 +347,13 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
     }
     if constexpr (BIAS_LDS) __builtin_amdgcn_sched_barrier(0);  // the reads above come before any write to `stg`
     if constexpr (sizeof(TC) == 2 && MODE == SSL4GIE_EPI_AFFINE_AUX_RELU) {
-        p_store_bf16_aux<FULL, 5, NJ>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane,
+        p_store_bf16_aux<FULL, 5, NJ, NT>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane,
                                       residual /* scale */, bias /* shift */, accumulate /* relu */);
     } else if constexpr (sizeof(TC) == 2 && (MODE == SSL4GIE_EPI_DGELU || MODE == SSL4GIE_EPI_MUL_AUX ||
                                       MODE == SSL4GIE_EPI_RELU_MASK_AUX || MODE == SSL4GIE_EPI_ADD_AUX)) {
         constexpr int AUXF = MODE == SSL4GIE_EPI_DGELU ? 2
                            : (MODE == SSL4GIE_EPI_RELU_MASK_AUX ? 3 : (MODE == SSL4GIE_EPI_ADD_AUX ? 4 : 1));
-        p_store_bf16_aux<FULL, AUXF, NJ>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane);
+        p_store_bf16_aux<FULL, AUXF, NJ, NT>(acc, stg, alpha, aux, (bf16_t*)C, ldc, rbase, cbase, M, N, lane);
     } else if constexpr (sizeof(TC) == 2) {
         // bf16: stage 16 rows x 64 columns (2 KiB), chunk c of row r at position c ^ (r & 7)
         const int R0 = lane >> 3, Cc = lane & 7;
@@ -388,7 +407,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                 const int R = R0 + 8 * hh;
                 const int gm = rbase + 16 * mt + R, gn = cbase + 8 * Cc;
                 if (mine && (FULL || (gm < M && gn < N))) {
-                    if (!STATS || dst) *(u32x4*)(dst + (size_t)gm * ldc + gn) = w[hh];  // STATS with C == NULL: statistics only
+                    if (!STATS || dst) est<NT>((u32x4*)(dst + (size_t)gm * ldc + gn), w[hh]);  // STATS with C == NULL: statistics only
                     if constexpr (STATS) {
                         if (stats && !(prio_mode & 8)) {  // (bit 3: debug-library ablation)
 #pragma unroll
@@ -433,8 +452,8 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                         const u32x4 wd = xp(dA, dB), wg = xp(gA, gB);
                         const int gn = cbase + 32 * np + 16 * (g4 & 1) + 8 * (g4 >> 1);
                         if (FULL || (gm < M && gn < N)) {
-                            *(u32x4*)((bf16_t*)C + (size_t)gm * ldc + gn) = wd;
-                            *(u32x4*)(out2 + (size_t)gm * ldc + gn) = wg;
+                            est<NT>((u32x4*)((bf16_t*)C + (size_t)gm * ldc + gn), wd);
+                            est<NT>((u32x4*)(out2 + (size_t)gm * ldc + gn), wg);
                         }
                     }
                     if (tstamp) tstamp[mt] = __builtin_amdgcn_s_memrealtime();
@@ -502,7 +521,7 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
         // (Round 4, measured and dropped: fp32 outputs straight from the accumulator layout — 16 rows x 64 B per
         // wave instruction, no LDS — are SLOWER than the transposed 4 rows x 256 B stores: dec.proj 101 -> 114 us,
         // epilogue issue 5.1 / 8.4 -> 9.8 / 12.9 us (wave 0 / wave 4); profiles/r04v_nt_f32_direct_vs_lds.log.)
-        p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL, NJ>(
+        p_store_f32<FULL, MODE == SSL4GIE_EPI_BIAS_RESIDUAL, NJ, NT>(
             acc, stg, alpha, bias_t, residual, ldr, MODE == SSL4GIE_EPI_NONE && accumulate, (float*)C,
             ldc, rbase, cbase, M, N, lane);
     }

@@ -13,6 +13,7 @@ struct EpiArgs {
     void* out2;
     int accumulate;
     float* colstats;  // optional (256x256 NT kernel, bf16 C, EPI_NONE): see ssl4gie_gemm_desc::colstats
+    int nt_store;     // 256x256 NT kernel: non-temporal output stores (gemm256.h est)
 };
 
 // Implicit 3x3 / pad-1 patch-matrix operand (ssl4gie_gemm_desc::conv): device-side geometry with

@@ -80,7 +80,8 @@ extern "C" int ssl4gie_debug_nt256_stamps(void*, size_t) { return ARG_ERR; }
 //       M = 12800: 150 tiles on 240 CUs -> 200 tiles of 3/4 the work).  Same four phases, barriers and LDS-DMA
 //       placement; the second B half-tile shrinks to 64 rows (one piece per wave, columns 48 wc + 32 .. 47) and
 //       the phases that use it run 8 MFMAs instead of 16.
-template <typename TC, int MODE, int CONV, bool STATS = false, int ROLE = 0, int NJ = 4, bool PH2 = false>
+template <typename TC, int MODE, int CONV, bool STATS = false, int ROLE = 0, int NJ = 4, bool PH2 = false,
+          bool NTS = false /* non-temporal output stores (gemm256.h est) */>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
     TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e,
@@ -556,11 +557,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             }
 #else
             if (full)
-                p_epilogue<TC, MODE, true, STATS, true, NJ>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                p_epilogue<TC, MODE, true, STATS, true, NJ, NTS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                   e_out2, e_accumulate, C, ldc, m0 + wr * 128,
                                                   n0 + wc * WN, M, N, lane, e_colstats);
             else
-                p_epilogue<TC, MODE, false, STATS, true, NJ>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                p_epilogue<TC, MODE, false, STATS, true, NJ, NTS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                    e_out2, e_accumulate, C, ldc, m0 + wr * 128,
                                                    n0 + wc * WN, M, N, lane, e_colstats);
 #endif
@@ -679,8 +680,12 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         wgs = (ntiles + rounds - 1) / rounds;
     }
     dim3 grid(wgs), block(512);
+    // non-temporal output stores for the long products (SSL4GIE_NT_STREAM_M = least M, default 32768; 0 always,
+    // -1 never): see gemm256.h est
+    static long long stream_m = -2;
+    if (stream_m == -2) { const char* s = getenv("SSL4GIE_NT_STREAM_M"); stream_m = s ? atoll(s) : 32768; }
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate,
-              d->colstats};
+              d->colstats, (stream_m >= 0 && d->M >= stream_m) ? 1 : 0};
     if (d->epilogue == SSL4GIE_EPI_AFFINE_AUX_RELU) {  // two borrowed slots (gemm256.h p_epilogue)
         e.residual = d->scale;
         e.accumulate = d->relu;
@@ -751,9 +756,18 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
 #else
 #define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_) P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, 0, 4, NT256_DEFAULT_PH2)
 #endif
+#ifdef SSL4GIE_DEBUG_KNOBS
+#define P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_) P_LAUNCH_K(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, false)
+#else  /* the streaming-store twin exists for the plain products only (no patch-matrix operand, no statistics) */
 #define P_LAUNCH_R(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_)                                        \
     do {                                                                                           \
-        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_>;            \
+        if (CONV_ == 0 && !(STATS_) && e.nt_store) P_LAUNCH_K(TC_, MODE_, 0, false, ROLE_, NJ_, PH2_, true); \
+        else P_LAUNCH_K(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, false);                       \
+    } while (0)
+#endif
+#define P_LAUNCH_K(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, NTS_)                                  \
+    do {                                                                                           \
+        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, NTS_>;      \
         static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
         if (!attr_set) {                                                                           \
             HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
