@@ -680,10 +680,10 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         wgs = (ntiles + rounds - 1) / rounds;
     }
     dim3 grid(wgs), block(512);
-    // non-temporal output stores for the long products (SSL4GIE_NT_STREAM_M = least M, default 32768; 0 always,
+    // non-temporal output stores for the long products (SSL4GIE_NT_STREAM_M = least M, default 16384; 0 always,
     // -1 never): see gemm256.h est
     static long long stream_m = -2;
-    if (stream_m == -2) { const char* s = getenv("SSL4GIE_NT_STREAM_M"); stream_m = s ? atoll(s) : 32768; }
+    if (stream_m == -2) { const char* s = getenv("SSL4GIE_NT_STREAM_M"); stream_m = s ? atoll(s) : 16384; }
     EpiArgs e{d->alpha, d->epilogue, d->bias, d->residual, d->ldr, d->aux, d->out2, d->accumulate,
               d->colstats, (stream_m >= 0 && d->M >= stream_m) ? 1 : 0};
     if (d->epilogue == SSL4GIE_EPI_AFFINE_AUX_RELU) {  // two borrowed slots (gemm256.h p_epilogue)
