@@ -259,6 +259,35 @@ def test_attention_bf16_fused(N, hd):
         assert rel_err(got[:, :, i], ref[:, :, i]) < 3e-2, f"d{name}"
 
 
+@pytest.mark.parametrize("B,N,H", [(30, 197, 12), (43, 197, 12), (27, 256, 12), (25, 160, 12), (64, 224, 6)])
+def test_attention_bf16_backward_persistent_prefetch_is_per_head_exact(B, N, H):
+    """hd 64 above 144 tokens: with more heads than the chip holds workgroups the backward walks several heads per
+    workgroup and fetches the next head while it finishes the current one (attn_bwd_pf_bf16_kernel).  A head's result
+    must not depend on where in that walk it was computed: the whole batch at once == the same heads in launches of
+    8 images (at most 96 heads: one head per workgroup, no prefetch), bit for bit; and the whole batch is right
+    against the double-precision reference on a few images."""
+    from ssl4gie_amd import ops
+    hd = 64
+    qkv = (torch.randn(B, N, 3 * H * hd, generator=G(11)) * 1.5).to(BF).to(DEV)
+    do = torch.randn(B, N, H * hd, generator=G(12)).to(BF).to(DEV)
+    o, lse = ops.attn_fwd(qkv, B, N, H, hd)
+    full = ops.attn_bwd(qkv, o, do, lse, B, N, H, hd)
+    for b0 in range(0, B, 8):
+        b1 = min(B, b0 + 8)
+        part = ops.attn_bwd(qkv[b0:b1].contiguous(), o[b0:b1].contiguous(), do[b0:b1].contiguous(),
+                            lse[b0:b1].contiguous(), b1 - b0, N, H, hd)
+        assert torch.equal(part, full[b0:b1]), f"images {b0}..{b1 - 1}"
+    for b in (0, B // 2, B - 1):  # first, a middle and the last image: first / later / last head of a walk
+        t = qkv[b:b + 1].double().cpu().requires_grad_(True)
+        o_ref, _ = _attn_ref(t, 1, N, H, hd)
+        o_ref.backward(do[b:b + 1].double().cpu())
+        D = H * hd
+        ref = t.grad.reshape(1, N, 3, D)
+        got = full[b:b + 1].float().cpu().reshape(1, N, 3, D)
+        for i, name in enumerate("qkv"):
+            assert rel_err(got[:, :, i], ref[:, :, i]) < 3e-2, f"image {b} d{name}"
+
+
 @pytest.mark.parametrize("B,N,H", [(2, 512, 3), (1, 1024, 2), (1, 4096, 1)])
 def test_attention_bf16_long_sequences(B, N, H):
     """streaming kernels (N % 128 == 0, hd 64): the detection backbone's global attention"""
