@@ -22,6 +22,7 @@
 #include "common.h"
 #include "ssl4gie_hip.h"
 #include "prof.h"
+int ssl4gie_internal_compute_cus();  // gemm.hip: CUs the persistent grids are sized for (ssl4gie_set_compute_cus)
 
 #include <math.h>
 #include <stdlib.h>
@@ -1212,21 +1213,28 @@ static bool attn_prefetch() {  // SSL4GIE_ATTN_PREFETCH=0: the one-head-per-work
     return on != 0;
 }
 template <int HD, int NKT, bool HT>
+static int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                      void* dqkv, int B, int N, int H, float scale, hipStream_t st);
+template <int HD, int NKT, bool HT>
 static int launch_bwd_pf(const void* qkv, const void* out, const void* dout, const float* lse,
                          void* dqkv, int B, int N, int H, float scale, hipStream_t st) {
     constexpr int W = AttnBwdWaves<NKT>::value;
     const size_t lds = (size_t)4 * NKT * 16 * HD * 2 + 2 * NKT * 16 * sizeof(float);
     auto k = attn_bwd_pf_bf16_kernel<HD, NKT, HT>;
-    static int slots = 0;  // per instantiation: workgroups the chip holds at once
-    if (!slots) {
+    // workgroups one CU holds at once: a pure function of the kernel and the (single) architecture, so the benign
+    // race of two host threads computing it twice writes the same value.  The persistent grid covers the
+    // CUs the compute kernels may use (ssl4gie_set_compute_cus: data-parallel runs keep a few for the
+    // communication kernels, which these long-lived workgroups would otherwise occupy).
+    static int per_cu = 0;
+    if (!per_cu) {
         HIP_RET(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int per_cu = 0, dev = 0, cus = 0;
-        HIP_RET(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, 64 * W, lds));
-        HIP_RET(hipGetDevice(&dev));
-        HIP_RET(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        slots = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);
+        int v = 0;
+        HIP_RET(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, (const void*)k, 64 * W, lds));
+        per_cu = v < 1 ? 1 : v;
     }
-    REQUIRE(((N + 15) >> 4) >= W);  // every wave owns a tile in both phases: the hooks' barriers are reached by all
+    if (((N + 15) >> 4) < W)  // a wave without a tile would miss the hooks' barriers: the one-head kernel handles it
+        return launch_bwd<HD, NKT, HT>(qkv, out, dout, lse, dqkv, B, N, H, scale, st);
+    const int slots = per_cu * ssl4gie_internal_compute_cus();
     const int heads = B * H;
     int grid = heads;
     if (heads > slots) {  // every workgroup walks the same number of heads (+- 1)

@@ -293,6 +293,45 @@ DEVI float p_fold_lanes8(float v) {
     return __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
 }
 
+// ---- GELU pair by table (TAB epilogues of the 256 x 256 NT kernel) --------------------------------------------
+// The reference applies GELU to the half-precision output of fc1 (autocast; timm Mlp, Models/mae/models_mae.py:39-41,
+// 53-55), so Phi and gelu' are functions of the bf16-rounded pre-activation: 2 x 2048 distinct arguments with
+// 2^-12 <= |x| < 16 (gelu_table.h, tools/gen_gelu_table.py), 1/2 below, 0 / 1 above — which the clamped index
+// delivers.  The 16-KiB table sits in the epilogue staging area (unused by the lane-exchange form of the pair
+// epilogue); one ds_read_b32 per element replaces exp2 + rcp + the 5-term polynomial of gelu_grad4_fast
+// (24 VALU + 4 quarter-rate ops per pair -> 15): the LDS pipe is idle in this epilogue, the VALU was its bound.
+// gelu = u * Phi(bf16(u)) with u the fp32 sum (v_fma_mix reads the fp16 Phi in place); gelu' comes out of the
+// table already in bf16.  tests/test_gpu_gelu_table.py checks both against tools/gen_gelu_table.emulate bit for bit.
+#define P_TAB_BYTES 16384
+struct GeluTabQ { f32x4 u; unsigned e[4]; };
+DEVI void p_gelu_tab_read(const f32x4 u, const char* tab, GeluTabQ& q) {
+    typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+    q.u = u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned p = pack_bf2(u[2 * h], u[2 * h + 1]);
+        const u16x2_t m = __builtin_bit_cast(u16x2_t, p & 0x7fff7fffu);
+        u16x2_t t = __builtin_elementwise_sub_sat(m, (u16x2_t)(unsigned short)0x3980);   // v_pk_sub_u16 clamp
+        t = __builtin_elementwise_min(t, (u16x2_t)(unsigned short)2047);                   // v_pk_min_u16
+        const unsigned T = (((p >> 4) & 0x08000800u) | __builtin_bit_cast(unsigned, t)) << 2;  // sign -> bit 11; byte offsets
+        q.e[2 * h] = *(const unsigned*)(tab + (T & 0xffffu));
+        q.e[2 * h + 1] = *(const unsigned*)(tab + (T >> 16));
+    }
+}
+DEVI float p_mix_lo16(float x, unsigned e) {  // x * fp16(e[15:0])
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(x), "v"(e));
+    return r;
+}
+// packed results of the four elements: g[0..1] = gelu (columns 0-1, 2-3), d[0..1] = gelu'
+DEVI void p_gelu_tab_finish(const GeluTabQ& q, unsigned (&d)[2], unsigned (&g)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        g[h] = pack_bf2(p_mix_lo16(q.u[2 * h], q.e[2 * h]), p_mix_lo16(q.u[2 * h + 1], q.e[2 * h + 1]));
+        d[h] = __builtin_amdgcn_perm(q.e[2 * h + 1], q.e[2 * h], 0x07060302u);
+    }
+}
+
 // ---- epilogue of one wave's 128 x 64 sub-tile ---------------------------------------------------
 // acc[mt][nt]: rows rbase + 16 mt + (l & 15), columns cbase + 16 nt + 4 (l >> 4) + 0..3
 // STATS (bf16 C, plain epilogue): per-column sums and sums of squares of the STORED (bf16-rounded)
@@ -305,7 +344,7 @@ DEVI float p_fold_lanes8(float v) {
 // (Round 4, measured and dropped: reading the whole residual tile FIRST, in the accumulator layout, and folding it
 // into the accumulators before a plain fp32 store phase — dec.proj 57 -> 65 us: two serial phases lose more than
 // the loads gain by not queueing behind stores; profiles/r04g_nt_epilogue_residual_first.log.)
-template <typename TC, int MODE, bool FULL, bool STATS, bool BIAS_LDS = false, int NJ = 4, bool NT = false>
+template <typename TC, int MODE, bool FULL, bool STATS, bool BIAS_LDS = false, int NJ = 4, bool NT = false, bool TAB = false>
 DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                      const float* __restrict__ bias, const float* __restrict__ residual,
                      const long long ldr, const bf16_t* __restrict__ aux, bf16_t* __restrict__ out2,
@@ -313,7 +352,8 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
                      int M, int N, int lane, float* __restrict__ colstats,
                      unsigned long long* tstamp = nullptr /* debug library: per-row-block time stamps */,
                      const int prio_mode = P_EPI_PRIO_MODE /* debug library: s_setprio policy of the GELU epilogues */,
-                     const bool xpose_swap = P_EPI_XPOSE_SWAP /* GELU pair: lane exchange instead of the LDS transposition */) {
+                     const bool xpose_swap = P_EPI_XPOSE_SWAP /* GELU pair: lane exchange instead of the LDS transposition */,
+                     const char* tab = nullptr /* TAB: the (Phi, gelu') table in LDS (p_gelu_tab_read) */) {
     // EPI_AFFINE_AUX_RELU borrows two slots: `residual` carries scale[N], `accumulate` the ReLU flag (EpiArgs
     // is filled that way by the launcher)
     const int r16 = lane & 15, g4 = lane >> 4;
@@ -426,7 +466,53 @@ DEVI void p_epilogue(f32x4 (&acc)[8][4], char* stg, const float alpha,
         // blocks turns that into 8 consecutive columns (16 B) per lane, and a wave instruction then stores
         // 16 rows x 64 B.  No ds_write / ds_read, no lgkmcnt waits: the LDS round trip (write bandwidth is only
         // ~85 B/clk per CU) is what the pipelined form below still pays per block.
-        if constexpr (PAIR && NJ == 4) {
+        if constexpr (PAIR && NJ == 4 && TAB) {
+            static_assert(!STATS, "the table form exists for the GELU pair only");
+            // 16 steps of 8 elements (two 16-column blocks of one 16-row block); the table reads of step i + 1 are
+            // in flight while step i is multiplied, packed, exchanged and stored
+            GeluTabQ qa[2], qb[2];
+            auto rd = [&](int i, GeluTabQ& a, GeluTabQ& b) {
+                const int mt = i >> 1, np = i & 1;
+                p_gelu_tab_read(acc[mt][2 * np] * alpha + bias4[2 * np], tab, a);
+                p_gelu_tab_read(acc[mt][2 * np + 1] * alpha + bias4[2 * np + 1], tab, b);
+            };
+            rd(0, qa[0], qb[0]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int mt = i >> 1, np = i & 1;
+                if (i + 1 < 16) rd(i + 1, qa[(i + 1) & 1], qb[(i + 1) & 1]);
+                unsigned dA[2], gA[2], dB[2], gB[2];
+                p_gelu_tab_finish(qa[i & 1], dA, gA);
+                p_gelu_tab_finish(qb[i & 1], dB, gB);
+                auto xq = [&](const unsigned (&a)[2], const unsigned (&b)[2]) -> u32x4 {
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const u32x2 s2 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    return u32x4{s1[0], s2[0], s1[1], s2[1]};
+                };
+                const u32x4 wg = xq(gA, gB);
+                const int gm = rbase + 16 * mt + r16;
+                const int gn = cbase + 32 * np + 16 * (g4 & 1) + 8 * (g4 >> 1);
+                if constexpr (MODE == SSL4GIE_EPI_BIAS_GELU_GRAD) {
+                    const u32x4 wd = xq(dA, dB);
+                    if (FULL || (gm < M && gn < N)) {
+                        est<NT>((u32x4*)((bf16_t*)C + (size_t)gm * ldc + gn), wd);
+                        est<NT>((u32x4*)(out2 + (size_t)gm * ldc + gn), wg);
+                    }
+                } else {  // C = u (bf16), out2 = gelu
+                    const f32x4& uA = qa[i & 1].u;
+                    const f32x4& uB = qb[i & 1].u;
+                    const unsigned ua[2] = {pack_bf2(uA[0], uA[1]), pack_bf2(uA[2], uA[3])};
+                    const unsigned ub[2] = {pack_bf2(uB[0], uB[1]), pack_bf2(uB[2], uB[3])};
+                    const u32x4 wu = xq(ua, ub);
+                    if (FULL || (gm < M && gn < N)) {
+                        est<NT>((u32x4*)((bf16_t*)C + (size_t)gm * ldc + gn), wu);
+                        est<NT>((u32x4*)(out2 + (size_t)gm * ldc + gn), wg);
+                    }
+                }
+            }
+            return;
+        }
+        if constexpr (PAIR && NJ == 4 && !TAB) {
             if (xpose_swap) {
 #pragma unroll
                 for (int mt = 0; mt < 8; ++mt) {

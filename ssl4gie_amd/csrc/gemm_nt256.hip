@@ -40,6 +40,7 @@
 // Replaces the cuBLAS calls behind nn.Linear in timm Block / MAE decoder (reference
 // call sites Models/mae/models_mae.py:39-41,47,53-55,59; Models/models.py:171-173).
 #include "gemm256.h"
+#include "gelu_table.h"
 #include "prof.h"
 
 #include <stdio.h>
@@ -80,8 +81,11 @@ extern "C" int ssl4gie_debug_nt256_stamps(void*, size_t) { return ARG_ERR; }
 //       M = 12800: 150 tiles on 240 CUs -> 200 tiles of 3/4 the work).  Same four phases, barriers and LDS-DMA
 //       placement; the second B half-tile shrinks to 64 rows (one piece per wave, columns 48 wc + 32 .. 47) and
 //       the phases that use it run 8 MFMAs instead of 16.
+// TAB:  the GELU epilogues (SSL4GIE_EPI_BIAS_GELU, _GELU_GRAD) read Phi / gelu' from the 16-KiB table of
+//       gelu_table.h, brought into the staging area once per (persistent) workgroup by the first 16 LDS-DMA
+//       pieces of the stream; the bias rows then live behind it (256 B per wave).  NJ = 4, ROLE 0 only.
 template <typename TC, int MODE, int CONV, bool STATS = false, int ROLE = 0, int NJ = 4, bool PH2 = false,
-          bool NTS = false /* non-temporal output stores (gemm256.h est) */>
+          bool NTS = false /* non-temporal output stores (gemm256.h est) */, bool TAB = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
     TC* __restrict__ C, long long ldc, int M, int N, int K, int tiles_n, int ntiles, EpiArgs e,
@@ -137,6 +141,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     unsigned yo[2][2];
     static_assert(CONV == 0 || ROLE == 0, "the gathered operand keeps the two-piece ownership");
     static_assert(NJ == 4 || ((NJ == 3 || NJ == 2) && ROLE == 0 && CONV == 0), "256 x 192 / 256 x 128: plain operands, ROLE 0");
+    static_assert(!TAB || (NJ == 4 && ROLE == 0 && CONV == 0 && !STATS && sizeof(TC) == 2 &&
+                           (MODE == SSL4GIE_EPI_BIAS_GELU || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD)),
+                  "the table form exists for the GELU pair on the 256 x 256 tile");
     constexpr int WN = 16 * NJ;   // columns per wave
     constexpr int BN = 4 * WN;    // columns per tile
 #pragma unroll
@@ -335,6 +342,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     };
 
     // ------------------------------------------------------------------ prologue
+    if constexpr (TAB) {  // 16 pieces of 1 KiB, two per wave, older than every half-tile: the prologue's wait retires them
+        const unsigned tl = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + 2 * P_BUF + wave * 2048);
+        p_glds2(g_gelu_tab, (unsigned)(wave * 2048 + lane * 16), (unsigned)(wave * 2048 + 1024 + lane * 16), tl, tl + 1024);
+    }
     point_at(0);
     issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
     issue(I0{}); issue(I1{}); issue(I2{});
@@ -357,7 +368,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
     // the wr = 0 waves never wait on vmcnt in the K-loop, so they wait for this one DMA at the epilogue instead.
     constexpr bool HAS_BIAS = MODE == SSL4GIE_EPI_BIAS || MODE == SSL4GIE_EPI_BIAS_GELU ||
                               MODE == SSL4GIE_EPI_BIAS_RESIDUAL || MODE == SSL4GIE_EPI_BIAS_GELU_GRAD;
-    const unsigned stg_lds = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + 2 * P_BUF + wave * P_STG_WAVE);
+    const unsigned stg_lds = __builtin_amdgcn_readfirstlane(p_lds_addr(smem) + 2 * P_BUF +
+                                                            (TAB ? P_TAB_BYTES + wave * 256 : wave * P_STG_WAVE));
     auto issue_bias = [&](int ti) {
         if constexpr (HAS_BIAS) {
             if (e_bias) {
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
                 if (!loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (its own older stores, and the bias row)
             }
             stamp(c_ti - 1, 1);
-            char* stg = smem + 2 * P_BUF + wave * P_STG_WAVE;
+            char* stg = smem + 2 * P_BUF + (TAB ? P_TAB_BYTES + wave * 256 : wave * P_STG_WAVE);
             const bool full = m0 + P_BM <= M && n0 + BN <= N;
 #ifdef SSL4GIE_DEBUG_KNOBS
             // one instantiation per FULL; the ablation modes only change its arguments
@@ -557,13 +569,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt256_kernel(
             }
 #else
             if (full)
-                p_epilogue<TC, MODE, true, STATS, true, NJ, NTS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                p_epilogue<TC, MODE, true, STATS, true, NJ, NTS, TAB>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                   e_out2, e_accumulate, C, ldc, m0 + wr * 128,
-                                                  n0 + wc * WN, M, N, lane, e_colstats);
+                                                  n0 + wc * WN, M, N, lane, e_colstats, nullptr, P_EPI_PRIO_MODE,
+                                                  P_EPI_XPOSE_SWAP, smem + 2 * P_BUF);
             else
-                p_epilogue<TC, MODE, false, STATS, true, NJ, NTS>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
+                p_epilogue<TC, MODE, false, STATS, true, NJ, NTS, TAB>(acc, stg, e_alpha, e_bias, e_residual, e_ldr, e_aux,
                                                    e_out2, e_accumulate, C, ldc, m0 + wr * 128,
-                                                   n0 + wc * WN, M, N, lane, e_colstats);
+                                                   n0 + wc * WN, M, N, lane, e_colstats, nullptr, P_EPI_PRIO_MODE,
+                                                   P_EPI_XPOSE_SWAP, smem + 2 * P_BUF);
 #endif
             stamp(c_ti - 1, 2);
 #pragma unroll
@@ -715,6 +729,8 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         ph2 = k_ph2 != 0;
     }
 #endif
+    static int gelu_tab = -1;
+    if (gelu_tab < 0) { const char* s = getenv("SSL4GIE_GELU_TABLE"); gelu_tab = (s && s[0] == '0') ? 0 : 1; }
     ConvK ck{};
     if (d->conv) {
         const int rc = ssl4gie_internal_conv_k(d->conv, &ck);
@@ -746,6 +762,16 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         else P_LAUNCH(TC_, MODE_);                                                         \
     } while (0)
 #endif
+#ifdef SSL4GIE_DEBUG_KNOBS
+#define P_LAUNCH_G(MODE_) P_LAUNCH(bf16_t, MODE_)
+#else  /* the GELU pair on the 256 x 256 tile reads the table (SSL4GIE_GELU_TABLE=0: the polynomial form, A/B timing) */
+#define P_LAUNCH_G(MODE_)                                                                                \
+    do {                                                                                                  \
+        if (nj == 4 && gelu_tab && e.nt_store) P_LAUNCH_KT(bf16_t, MODE_, 0, false, 0, 4, NT256_DEFAULT_PH2, true, true);  \
+        else if (nj == 4 && gelu_tab) P_LAUNCH_KT(bf16_t, MODE_, 0, false, 0, 4, NT256_DEFAULT_PH2, false, true);          \
+        else P_LAUNCH(bf16_t, MODE_);                                                                     \
+    } while (0)
+#endif
 #define P_LAUNCH_C(TC_, MODE_, CONV_) P_LAUNCH_S(TC_, MODE_, CONV_, false)
 #ifdef SSL4GIE_DEBUG_KNOBS
 #define P_LAUNCH_S(TC_, MODE_, CONV_, STATS_)                            \
@@ -765,9 +791,10 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
         else P_LAUNCH_K(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, false);                       \
     } while (0)
 #endif
-#define P_LAUNCH_K(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, NTS_)                                  \
+#define P_LAUNCH_K(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, NTS_) P_LAUNCH_KT(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, NTS_, false)
+#define P_LAUNCH_KT(TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, NTS_, TAB_)                           \
     do {                                                                                           \
-        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, NTS_>;      \
+        auto kfn = gemm_bf16_nt256_kernel<TC_, MODE_, CONV_, STATS_, ROLE_, NJ_, PH2_, NTS_, TAB_>; \
         static bool attr_set = false; /* idempotent; a benign race only repeats the call */        \
         if (!attr_set) {                                                                           \
             HIP_RET(hipFuncSetAttribute((const void*)kfn,                                          \
@@ -797,9 +824,9 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
     } else if (d->dtype_c == SSL4GIE_BF16) {
         switch (d->epilogue) {
             case SSL4GIE_EPI_BIAS: P_LAUNCH2(bf16_t, SSL4GIE_EPI_BIAS); break;
-            case SSL4GIE_EPI_BIAS_GELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU); break;
+            case SSL4GIE_EPI_BIAS_GELU: P_LAUNCH_G(SSL4GIE_EPI_BIAS_GELU); break;
             case SSL4GIE_EPI_DGELU: P_LAUNCH(bf16_t, SSL4GIE_EPI_DGELU); break;
-            case SSL4GIE_EPI_BIAS_GELU_GRAD: P_LAUNCH(bf16_t, SSL4GIE_EPI_BIAS_GELU_GRAD); break;
+            case SSL4GIE_EPI_BIAS_GELU_GRAD: P_LAUNCH_G(SSL4GIE_EPI_BIAS_GELU_GRAD); break;
             case SSL4GIE_EPI_MUL_AUX: P_LAUNCH(bf16_t, SSL4GIE_EPI_MUL_AUX); break;
             case SSL4GIE_EPI_ADD_AUX: P_LAUNCH2(bf16_t, SSL4GIE_EPI_ADD_AUX); break;
             case SSL4GIE_EPI_AFFINE_AUX_RELU: P_LAUNCH2(bf16_t, SSL4GIE_EPI_AFFINE_AUX_RELU); break;
@@ -819,6 +846,8 @@ int ssl4gie_internal_nt256_launch(const ssl4gie_gemm_desc* d, hipStream_t st) {
 #undef P_LAUNCH_C
 #undef P_LAUNCH_S
 #undef P_LAUNCH_R
+#undef P_LAUNCH_G
+#undef P_LAUNCH_KT
     LAUNCH_CHECK();
     return 0;
 }

@@ -192,7 +192,10 @@ def touched_since(epoch: int):
 # any optimizer, fused or not — therefore advances the epoch.
 try:
     from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
-    _reg_post_hook(lambda _opt, _args, _kwargs: bump_weights_epoch())
+    # `touched`: the parameters this optimizer owns — a step of ANOTHER optimizer (a probe, a second model) between a
+    # BatchNorm forward and its backward must not trip the stale-parameter guards (resnet_engine._bn_params_moved)
+    _reg_post_hook(lambda opt, _args, _kwargs: bump_weights_epoch(
+        touched=[p for g in opt.param_groups for p in g["params"]]))
 except ImportError:  # torch < 2.0: callers must use ssl4gie_amd.optim or call bump_weights_epoch()
     pass
 
@@ -626,6 +629,9 @@ def set_wgrad_side(on: bool) -> bool:
     return prev
 
 
+SAFE_POST_ACC_HOOK_IDS = set()   # handle ids of post-accumulate-grad hooks that order themselves after the side stream
+
+
 def _wgrad_join():
     if _WG["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_WG["stream"])
@@ -649,6 +655,13 @@ def wgrad_fork(sink, params, *operands):
         return None
     if torch.is_grad_enabled() or any(getattr(p, "_backward_hooks", None) for p in live):
         return None
+    # a post-accumulate-grad hook of the user's (optimizer-in-backward, per-parameter clipping) reads the arena
+    # gradient on the caller's stream as soon as the node returns; DataParallel's own hook is safe (its comm stream
+    # waits on the side stream) and is recognised by its handle id
+    for p in live:
+        hooks = getattr(p, "_post_accumulate_grad_hooks", None)
+        if hooks and any(k not in SAFE_POST_ACC_HOOK_IDS for k in hooks):
+            return None
     if _WG["stream"] is None:
         _WG["stream"] = torch.cuda.Stream()
     side = _WG["stream"]

@@ -258,7 +258,7 @@ class ArenaAdamW(_ArenaOptimizer):
             torch.cuda.current_stream(a.data.device).wait_stream(self._stream)
         self.step_count += 1
         self._done, self._seen, self._tables = [], {}, None
-        bump_weights_epoch()
+        bump_weights_epoch(touched=[p for g in self.param_groups for p in g["params"]])
         if self._lp is not None:
             a.lp_flat_is_current()
 
@@ -289,4 +289,4 @@ class ArenaLARS(_ArenaOptimizer):
         _lib.check(L.ssl4gie_lars_arena(ptr(a.data), ptr(a.grad), ptr(self.mu), ptr(start), ptr(lr), ptr(wd),
                                         ptr(mat), S, self.momentum, self.trust, ptr(self._ws), a.numel,
                                         stream()), "lars_arena")
-        bump_weights_epoch()
+        bump_weights_epoch(touched=[p for g in self.param_groups for p in g["params"]])

@@ -195,8 +195,14 @@ class DataParallel(nn.Module):
         self._build_plan()
         self._reset_pass()
         if self.world > 1:
+            try:   # engine.wgrad_fork keeps its side stream beside THESE hooks (the comm stream waits on it)
+                from .engine import SAFE_POST_ACC_HOOK_IDS as safe_ids
+            except ImportError:  # toy models of the CPU tests do not load the engine
+                safe_ids = set()
             for _, _, p, _ in self._items:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_param))
+                h = p.register_post_accumulate_grad_hook(self._on_param)
+                safe_ids.add(h.id)
+                self._hooks.append(h)
 
     def _build_plan(self):
         """The slices of a pass as a pure function of (arena layout, bucket size, unused set): items are

@@ -414,11 +414,15 @@ class BnReluMaxPoolFn(torch.autograd.Function):
         y, arg = ops.maxpool3x3s2_fwd(x.contiguous(), coef, True)
         ctx.save_for_backward(x, gamma, beta, mean, rstd, arg)
         ctx.sink = sink
+        ctx.wepoch = weights_epoch()   # the backward rebuilds the ReLU mask from gamma / beta (see BatchNormFn)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, rstd, arg = ctx.saved_tensors
+        if _bn_params_moved(ctx.wepoch, gamma, beta):
+            raise RuntimeError("BatchNorm parameters were updated between this forward and its backward: the ReLU "
+                               "mask rebuilt from them would disagree with the forward (set SSL4GIE_STEM_POOL_FUSED=0)")
         B, H, W, C = x.shape
         dz = ops.maxpool3x3s2_bwd(dy.contiguous(), arg, H, W)
         (tg, tb), acc, rets = ctx.sink.plan([gamma, beta])
@@ -464,6 +468,7 @@ class BnReluConv3x3Fn(torch.autograd.Function):
         y, stats = r if want_stats else (r, None)
         ctx.save_for_backward(x, gamma, beta, mean, rstd, coef, weight)
         ctx.cfg = (sink, lp)
+        ctx.wepoch = weights_epoch()   # dx rebuilds the ReLU mask from gamma / beta, dW uses the saved `coef`
         if stats is not None:
             ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)
@@ -476,6 +481,9 @@ class BnReluConv3x3Fn(torch.autograd.Function):
         from .dpt_engine import _derived, _write_grad
         x, gamma, beta, mean, rstd, coef, weight = ctx.saved_tensors
         sink, lp = ctx.cfg
+        if _bn_params_moved(ctx.wepoch, gamma, beta):
+            raise RuntimeError("BatchNorm parameters were updated between this forward and its backward: the ReLU "
+                               "mask rebuilt from them would disagree with the forward (set SSL4GIE_BN_CONV_FUSED=0)")
         B, H, W, Cin = x.shape
         Cout = weight.shape[0]
         dt = x.dtype

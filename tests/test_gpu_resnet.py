@@ -183,6 +183,45 @@ def test_bn_relu_inside_the_direct_convolution_equals_the_separate_pass(B, H, W,
     resnet_engine._BN_CONV_FUSED = False
 
 
+@pytest.mark.parametrize("which", ["bn", "stem_pool", "bn_conv"])
+def test_optimizer_step_between_forward_and_backward_is_refused_only_for_its_own_parameters(which):
+    """The mask-from-x backwards rebuild the ReLU mask from gamma / beta as they are at backward time:
+    a step of the optimizer that OWNS them between forward and backward must raise in all three autograd nodes
+    (the fused optimizers do not bump Tensor._version), a step of an unrelated optimizer must not."""
+    from ssl4gie_amd.dpt_engine import Conv3x3Fn  # noqa: F401
+    from ssl4gie_amd.engine import GradSink, LPCache
+    from ssl4gie_amd import resnet_engine
+    from ssl4gie_amd.resnet_engine import BatchNormFn, BnReluConv3x3Fn, BnReluMaxPoolFn
+    B, H, W, C = 2, 16, 16, 64
+    x = (torch.randn(B, H, W, C, generator=G(5)) * 1.3 + 0.2).to(BF).to(DEV)
+    x2 = x.view(-1, C).float()
+    xp = torch.cat([x2, x2.new_zeros((-x2.shape[0]) % 128, C)]).view(-1, 128, C)
+    st = torch.stack([xp.sum(1), (xp * xp).sum(1)], 1).contiguous()
+    conv = torch.nn.Conv2d(C, C, 3, 1, 1, bias=False).to(DEV)
+    other = torch.nn.Parameter(torch.zeros(4, device=DEV))
+    other.grad = torch.ones_like(other)
+
+    def run(opt_of):
+        bn = torch.nn.BatchNorm2d(C).to(DEV)
+        xi = x.clone().requires_grad_(True)
+        if which == "bn":
+            y = BatchNormFn.apply(xi, bn.weight, bn.bias, None, bn, True, GradSink(None), st)
+        elif which == "stem_pool":
+            y = BnReluMaxPoolFn.apply(xi, bn.weight, bn.bias, bn, GradSink(None), st)
+        else:
+            y, _ = BnReluConv3x3Fn.apply(xi, bn.weight, bn.bias, bn, st, conv.weight, GradSink(None), LPCache(), False)
+        opt = torch.optim.SGD(opt_of(bn), lr=0.1)
+        for q in opt.param_groups[0]["params"]:
+            q.grad = torch.ones_like(q)
+        opt.step()
+        y.backward(torch.ones_like(y))
+        return xi.grad
+
+    assert run(lambda bn: [other]) is not None            # somebody else's step: the backward runs
+    with pytest.raises(RuntimeError, match="updated between"):
+        run(lambda bn: [bn.weight, bn.bias])              # gamma / beta rewritten: refused
+
+
 @pytest.mark.parametrize("rows,C", [(1531, 64), (4099, 256), (777, 1024)])
 def test_batchnorm_residual_relu_backward_from_the_bit_map(rows, C):
     """ssl4gie_bn_fwd_partials_bits / ssl4gie_bn_bwd_bits (the ReLU mask of bn3 as one bit per element) against
