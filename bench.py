@@ -94,6 +94,15 @@ def dp_verify(ddp, step, a, dev):
             "compute_cus": getattr(ddp, "compute_cus", None)}
 
 
+def tree_stamp():
+    """the commit libssl4gie_hip.so was built from (__graft_entry__.build() writes it; None when never stamped)"""
+    try:
+        with open(os.path.join(ROOT, "ssl4gie_amd", "_tree.txt")) as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
+
+
 def dp_exit_if_broken(verify, world):
     """after rank 0 has printed its line: every rank leaves with a failure code when the run did not prove
     itself (the verdict is all-reduced, so all ranks agree; the launcher reports the non-zero exit)"""
@@ -118,6 +127,8 @@ def dp_info(ddp, steps_run, verify=None):
                    "grad_collectives_per_step": round(snap[0] / n, 2),
                    "overlapped_with_backward_per_step": round(snap[1] / n, 2),
                    "late_params": snap[2], "transport": ddp.transport,
+                   "transport_probe": getattr(ddp, "transport_probe", None),
+                   "syncbn_probe": (list(__import__("ssl4gie_amd.parallel", fromlist=["x"]).SYNCBN_PROBE.values()) or [None])[0],
                    "passes_closed_in_backward": snap[3],
                    "syncbn_collectives_per_step": round(snap[4] / n, 1),
                    "syncbn_direct_exchanges_per_step": round(snap[5] / n, 1)}}
@@ -292,16 +303,18 @@ def roofline_pass(step, a, workload):
     rate = fl[dom] / max(ms[dom], 1e-9) / 1e9
     # HBM bytes per launch of that kernel kind from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
     # the gfx950 note + WRITE_SIZE); measured for the MAE workload's kinds only, null otherwise
-    traffic = None
+    traffic, traffic_from = None, None
     if workload == "mae":
-        try:
+        try:   # ONE committed file (tools/pmc_to_json.py), stamped with the tree its counters were taken on
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"].get(name)
+                pj = json.load(f)
+            traffic = pj["hbm_bytes_per_launch"].get(name)
+            traffic_from = {"file": "profiles/pmc_traffic.json", "tree": pj.get("tree"), "source": pj.get("source")}
         except Exception:
             traffic = None
     if name in PROF_HBM_KINDS:
         return {"bound": "hbm", "kernel": name, "achieved": round(rate * 1e3, 1), "peak": PEAK_HBM_GBS,
-                "unit": "GB/s", "frac": round(rate * 1e3 / PEAK_HBM_GBS, 4), "traffic": traffic,
+                "unit": "GB/s", "frac": round(rate * 1e3 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_from": traffic_from,
                 "algorithmic_bytes_per_launch": round(fl[dom] / max(nl[dom], 1)),
                 "avg_launch_us": per[name]["avg_launch_us"], "launches_per_step": per[name]["launches_per_step"],
                 "kernels": per}
@@ -328,7 +341,7 @@ def roofline_pass(step, a, workload):
                       "algorithmic_bytes_per_step": round(fl[j] / a.prof_steps)}
     return {"bound": "mfma", "kernel": name, "achieved": round(rate, 1), "peak": PEAK_BF16_TFLOPS,
             "hbm_bound_kernel": hbm_kernel,
-            "unit": "TFLOP/s", "frac": round(rate / PEAK_BF16_TFLOPS, 4), "hbm_roof": hbm, "traffic": traffic,
+            "unit": "TFLOP/s", "frac": round(rate / PEAK_BF16_TFLOPS, 4), "hbm_roof": hbm, "traffic": traffic, "traffic_from": traffic_from,
             "traffic_unit": "HBM bytes/launch (profiles/pmc_traffic.json)",
             "flops_per_launch": round(fl[dom] / max(nl[dom], 1)), "avg_launch_us": per[name]["avg_launch_us"],
             "launches_per_step": per[name]["launches_per_step"], "kernels": per}
@@ -841,6 +854,7 @@ def main():
             "images_per_sec_per_gpu": round(ips / world, 1),
             "model_mfma_frac": round(ips / world * GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS, 4),
             "final_loss": round(final_loss, 5),
+            "tree": tree_stamp(),
         }
         line.update(dp_info(ddp, a.steps + a.warmup, verify))
         if roof is not None:

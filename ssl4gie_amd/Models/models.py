@@ -264,11 +264,20 @@ class ViTDet_FPN(EngineModule):
             if isinstance(mod, nn.LayerNorm) and len(mod.normalized_shape) == 3:
                 for q in (mod.weight, mod.bias):
                     q.data = q.data.permute(1, 2, 0).contiguous().permute(2, 0, 1)
-        # state_dict() keeps returning ALIASES of these parameters (logical (C, H, W) shape, channels-last strides):
-        # `model.state_dict()[k].copy_(v)` — the idiom the tests and many loaders use — must keep writing the
-        # parameter.  Consumers that need contiguous tensors (safetensors.save_file, `.view(-1)`) take
-        # ssl4gie_amd.checkpoints.contiguous_state_dict(model); loading goes through copy_, which keeps the layout
-        # ("state_dict layout").
+        # state_dict() returns CONTIGUOUS COPIES of these tables (safetensors.save_file and `.view(-1)`
+        # reject the channels-last strides of an alias); every other entry still aliases its parameter.  Loading goes
+        # through load_state_dict / load_my_state_dict, i.e. copy_ into the parameter, which keeps the layout; the
+        # one idiom that no longer reaches these 18 tables is `model.state_dict()[k].copy_(v)` (INTEGRATION.md,
+        # "state_dict layout").
+        self._register_state_dict_hook(ViTDet_FPN._contiguous_tables)
+
+    @staticmethod
+    def _contiguous_tables(module, state_dict, prefix, local_metadata):
+        for k in list(state_dict):
+            v = state_dict[k]
+            if k.startswith(prefix) and torch.is_tensor(v) and not v.is_contiguous():
+                state_dict[k] = v.contiguous()
+        return state_dict
 
     # ------------------------------------------------------------------ building blocks
     def _c1(self, x, conv):
@@ -340,7 +349,9 @@ class ViT_from_MAE(_ViTBackbone):
 
     def load_my_state_dict(self, state_dict):
         """Copy every tensor whose name we own; ignore the rest (reference :417-425)."""
-        own = self.state_dict()
+        own = dict(self.named_parameters())
+        own.update(dict(self.named_buffers()))   # the tensors themselves: a state_dict entry may be a copy (ViTDet_FPN)
+        own = {k: v for k, v in own.items() if k in self.state_dict()}
         hits = 0
         with torch.no_grad():
             for name, value in state_dict.items():

@@ -245,8 +245,7 @@ def load_augreg_npz(model, path):
 
 
 def contiguous_state_dict(module):
-    """state_dict() with every entry contiguous: the (C, H, W) LayerNorm tables of ViTDet_FPN are stored
-    channels-last (Models/models.py) and their state_dict entries alias them, strides included — fine for
-    torch.save / load_state_dict, but safetensors.save_file rejects non-contiguous tensors and `.view(-1)` on such
-    an entry raises.  The copies no longer alias the parameters."""
+    """state_dict() with every entry contiguous.  Since round 6 ViTDet_FPN's own state_dict hook already returns
+    contiguous copies of its channels-last (C, H, W) LayerNorm tables (Models/models.py), so this is `state_dict()`
+    for every module of the package; kept for callers of the round-5 API and for foreign modules."""
     return {k: (v if v.is_contiguous() else v.contiguous()) for k, v in module.state_dict().items()}

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "ssl4gie_hip.h"
 #include "internal.h"
+#include <stdlib.h>
 
 template <typename T> struct Vec;  // 16-byte vector of T
 template <> struct Vec<bf16_t> {
@@ -216,6 +217,162 @@ __global__ __launch_bounds__(256) void bilinear2x_bwd_kernel(const T* __restrict
         }
     }
     *(typename Vec<T>::raw*)(dx + (((size_t)b * H + iy) * W + ix) * C + c) = pack<T>(acc);
+}
+
+// ---- 2 x 2 outputs per thread (round 6).  The forward above issues four 16-byte tap loads per 16-byte store and runs
+// at 3.2-3.5 TB/s on the depth step's maps: it is bound by the tap loads through the CU's texture path, not by HBM.
+// The outputs (2k, 2k + 1) x (2j, 2j + 1) take their taps from at most 3 x 3 input pixels: with
+// (y0a, y1a) = taps of row 2k and (y0b, y1b) of row 2k + 1, y0b is y0a or y1a and y1b is y1a or one further (the
+// source coordinate advances by less than 1/2 per output row; clamping at the border only merges indices), and the
+// same for columns.  Nine loads per four stores instead of sixteen; the selection below is by index comparison, so
+// no assumption about the rounding of the source coordinate is baked in, and every output is computed with exactly
+// the expressions of bilinear2x_fwd_kernel (bit-identical: tests/test_gpu_dpt.py).
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear2x_fwd22_kernel(const T* __restrict__ x, T* __restrict__ y, int H,
+                                                               int W, int C) {
+    constexpr int V = Vec<T>::N;
+    typedef typename Vec<T>::raw raw;
+    const unsigned cpr = (unsigned)(C / V), Wo = 2 * W;
+    const int Ho = 2 * H;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned j = t / cpr;  // output columns 2j, 2j + 1
+    if (j >= (unsigned)W) return;
+    const int c = (int)(t - j * cpr) * V;
+    const int k = blockIdx.y, b = blockIdx.z;
+    int y0a, y1a, y0b, y1b, x0a, x1a, x0b, x1b;
+    float wya, wyb, wxa, wxb;
+    bl_src(2 * k, H, Ho, y0a, y1a, wya);
+    bl_src(2 * k + 1, H, Ho, y0b, y1b, wyb);
+    bl_src(2 * (int)j, W, (int)Wo, x0a, x1a, wxa);
+    bl_src(2 * (int)j + 1, W, (int)Wo, x0b, x1b, wxb);
+    const T* base = x + (size_t)b * H * W * C + c;
+    const int rows[3] = {y0a, y1a, y1b}, cols[3] = {x0a, x1a, x1b};
+    raw tp[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) tp[r][q] = *(const raw*)(base + ((size_t)rows[r] * W + cols[q]) * C);
+    // rows of output row b: (y0b == y1a ? row 1 : row 0 [then y0b == y0a]), (y1b == y1a ? row 1 : row 2); uniform
+    const bool rb0 = y0b == y1a, rb1 = y1b == y1a;
+    const bool cb0 = x0b == x1a, cb1 = x1b == x1a;   // per lane
+    auto lerp_store = [&](const raw& r00, const raw& r01, const raw& r10, const raw& r11, float wx, float wy, int oy,
+                          unsigned ox) {
+        float f00[V], f01[V], f10[V], f11[V], o[V];
+        unpack<T>(r00, f00); unpack<T>(r01, f01); unpack<T>(r10, f10); unpack<T>(r11, f11);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float top = f00[i] * (1.f - wx) + f01[i] * wx;
+            const float bot = f10[i] * (1.f - wx) + f11[i] * wx;
+            o[i] = top * (1.f - wy) + bot * wy;
+        }
+        *(raw*)(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c) = pack<T>(o);
+    };
+    auto sel = [](bool p, const raw& a, const raw& bb) -> raw {
+        raw r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = p ? a[i] : bb[i];
+        return r;
+    };
+    // column taps of output column b, for each of the three rows
+    raw lb[3], rbv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        lb[r] = sel(cb0, tp[r][1], tp[r][0]);
+        rbv[r] = sel(cb1, tp[r][1], tp[r][2]);
+    }
+    const unsigned oxa = 2 * j, oxb = 2 * j + 1;
+    // output row a: rows (0, 1)
+    lerp_store(tp[0][0], tp[0][1], tp[1][0], tp[1][1], wxa, wya, 2 * k, oxa);
+    lerp_store(lb[0], rbv[0], lb[1], rbv[1], wxb, wya, 2 * k, oxb);
+    // output row b
+    const raw t0a = sel(rb0, tp[1][0], tp[0][0]), t1a = sel(rb0, tp[1][1], tp[0][1]);
+    const raw b0a = sel(rb1, tp[1][0], tp[2][0]), b1a = sel(rb1, tp[1][1], tp[2][1]);
+    lerp_store(t0a, t1a, b0a, b1a, wxa, wyb, 2 * k + 1, oxa);
+    const raw t0b = sel(rb0, lb[1], lb[0]), t1b = sel(rb0, rbv[1], rbv[0]);
+    const raw b0b = sel(rb1, lb[1], lb[2]), b1b = sel(rb1, rbv[1], rbv[2]);
+    lerp_store(t0b, t1b, b0b, b1b, wxb, wyb, 2 * k + 1, oxb);
+}
+// Backward, 2 x 2 INPUT pixels per thread: rows (2m, 2m + 1) x columns (2n, 2n + 1) collect from the output rows
+// 4m - 3 .. 4m + 5 and columns 4n - 3 .. 4n + 5 (nine candidates each, six of them with a non-zero coefficient in
+// the interior): 36 tap loads per four stores instead of 64.  Per input pixel the contributions are added in the
+// same (output row, output column) order with the same products cy * cx as in bilinear2x_bwd_kernel; a candidate
+// that does not touch the pixel adds a signed zero (finite gradients: bit-identical, tests/test_gpu_dpt.py).
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear2x_bwd22_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H,
+                                                               int W, int C) {
+    constexpr int V = Vec<T>::N;
+    typedef typename Vec<T>::raw raw;
+    const unsigned cpr = (unsigned)(C / V);
+    const int Ho = 2 * H, Wo = 2 * W;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned un = t / cpr;
+    if (2 * un >= (unsigned)W) return;
+    const int n = (int)un, c = (int)(t - un * cpr) * V;
+    const int m = blockIdx.y, b = blockIdx.z;
+    const int iya = 2 * m, iyb = 2 * m + 1, ixa = 2 * n, ixb = 2 * n + 1;   // iyb / ixb may lie outside (odd sizes)
+    float acc[2][2][V];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[r][q][i] = 0.f;
+    const int oy_lo = 4 * m - 3 > 0 ? 4 * m - 3 : 0, oy_hi = 4 * m + 5 < Ho - 1 ? 4 * m + 5 : Ho - 1;
+    const int ox_lo = 4 * n - 3 > 0 ? 4 * n - 3 : 0, ox_hi = 4 * n + 5 < Wo - 1 ? 4 * n + 5 : Wo - 1;
+    float cxa[9], cxb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int ox = ox_lo + k;
+        int x0, x1;
+        float wx;
+        bl_src(ox <= ox_hi ? ox : ox_hi, W, Wo, x0, x1, wx);
+        float a = 0.f, bq = 0.f;
+        if (x0 == ixa) a += 1.f - wx;
+        if (x1 == ixa) a += wx;
+        if (x0 == ixb) bq += 1.f - wx;
+        if (x1 == ixb) bq += wx;
+        cxa[k] = ox <= ox_hi ? a : 0.f;
+        cxb[k] = ox <= ox_hi ? bq : 0.f;
+    }
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        int y0, y1;
+        float wy;
+        bl_src(oy, H, Ho, y0, y1, wy);
+        float cya = 0.f, cyb = 0.f;
+        if (y0 == iya) cya += 1.f - wy;
+        if (y1 == iya) cya += wy;
+        if (y0 == iyb) cyb += 1.f - wy;
+        if (y1 == iyb) cyb += wy;
+        if (cya == 0.f && cyb == 0.f) continue;   // uniform over the block
+        const T* row = dy + (((size_t)b * Ho + oy) * Wo + ox_lo) * C + c;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float ca = cxa[k], cb = cxb[k];
+            if (ca == 0.f && cb == 0.f) continue;
+            float f[V];
+            unpack<T>(*(const raw*)(row + (size_t)k * C), f);
+            const float waa = cya * ca, wab = cya * cb, wba = cyb * ca, wbb = cyb * cb;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                acc[0][0][i] += waa * f[i];
+                acc[0][1][i] += wab * f[i];
+                acc[1][0][i] += wba * f[i];
+                acc[1][1][i] += wbb * f[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int iy = 2 * m + r, ix = 2 * n + q;
+            if (iy < H && ix < W) *(raw*)(dx + (((size_t)b * H + iy) * W + ix) * C + c) = pack<T>(acc[r][q]);
+        }
+}
+static bool bilinear22() {  // SSL4GIE_BILINEAR22=0: one output (input) pixel per thread again (A/B; same bits)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SSL4GIE_BILINEAR22"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
 }
 
 // ------------------------------------------------------------------ ConvTranspose2d(k = s) scatter
@@ -425,6 +582,16 @@ extern "C" int ssl4gie_bilinear2x_fwd(const void* x, void* y, int dtype, int B, 
     REQUIRE(x && y && dt_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && C % vecn(dtype) == 0);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(2 * H <= 65535 && B <= 65535);
+    if (bilinear22()) {
+        const unsigned per = (unsigned)W * (unsigned)(C / vecn(dtype));
+        const dim3 grid((per + 255) / 256, H, B), block(256);
+        if (dtype == SSL4GIE_BF16)
+            hipLaunchKernelGGL(bilinear2x_fwd22_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, H, W, C);
+        else
+            hipLaunchKernelGGL(bilinear2x_fwd22_kernel<float>, grid, block, 0, st, (const float*)x, (float*)y, H, W, C);
+        LAUNCH_CHECK();
+        return 0;
+    }
     const unsigned per_row = (unsigned)(2 * W) * (unsigned)(C / vecn(dtype));
     const dim3 grid((per_row + 255) / 256, 2 * H, B), block(256);
     if (dtype == SSL4GIE_BF16)
@@ -439,6 +606,16 @@ extern "C" int ssl4gie_bilinear2x_bwd(const void* dy, void* dx, int dtype, int B
     REQUIRE(dy && dx && dt_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && C % vecn(dtype) == 0);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(H <= 65535 && B <= 65535);
+    if (bilinear22()) {
+        const unsigned per = (unsigned)((W + 1) / 2) * (unsigned)(C / vecn(dtype));
+        const dim3 grid((per + 255) / 256, (H + 1) / 2, B), block(256);
+        if (dtype == SSL4GIE_BF16)
+            hipLaunchKernelGGL(bilinear2x_bwd22_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy, (bf16_t*)dx, H, W, C);
+        else
+            hipLaunchKernelGGL(bilinear2x_bwd22_kernel<float>, grid, block, 0, st, (const float*)dy, (float*)dx, H, W, C);
+        LAUNCH_CHECK();
+        return 0;
+    }
     const unsigned per_row = (unsigned)W * (unsigned)(C / vecn(dtype));
     const dim3 grid((per_row + 255) / 256, H, B), block(256);
     if (dtype == SSL4GIE_BF16)

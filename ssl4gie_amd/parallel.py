@@ -120,9 +120,23 @@ class DataParallel(nn.Module):
         # transport of the bucket all-reduce: RCCL (default) or the library's direct xGMI exchange
         self._direct = None
         self.compute_cus = None  # CUs the persistent GEMM grids are sized for (set below when CUs are reserved)
+        # SSL4GIE_ALLREDUCE = rccl (default) | direct | auto.  `auto` proves the choice on this node before the first
+        # step: a 64-MiB slice goes through both transports, the direct result must be bitwise equal on every rank
+        # and within 1e-6 of RCCL's, and direct is taken only if it is also faster (probe_transports; the verdict
+        # is agreed between the ranks, a failing direct path falls back in-process).  `transport_probe` keeps the
+        # record (bench.py prints it in the N > 1 lines).
+        self.transport_probe = None
         import os
-        if self._is_cuda and self.world > 1 and os.environ.get("SSL4GIE_ALLREDUCE", "rccl").lower() == "direct":
-            self._direct = DirectAllReduce(min(self.bucket_elems * 2, self._arena.grad.numel()), process_group)
+        mode = os.environ.get("SSL4GIE_ALLREDUCE", "rccl").lower()
+        if self._is_cuda and self.world > 1 and mode in ("direct", "auto"):
+            max_elems = min(self.bucket_elems * 2, self._arena.grad.numel())
+            if mode == "direct":
+                self._direct = DirectAllReduce(max_elems, process_group)
+            else:
+                fault = os.environ.get("SSL4GIE_AR_PROBE_FAULT")   # test hook: "<rank>" corrupts that rank's direct result
+                self._direct, self.transport_probe = probe_transports(
+                    process_group, self._arena.grad.device, lambda: DirectAllReduce(max_elems, process_group),
+                    n_elems=min(16 << 20, max_elems), fault_rank=int(fault) if fault not in (None, "") else None)
         if self._is_cuda and self.world > 1:
             # the 256x256 GEMM workgroups own a CU's whole LDS, so RCCL's kernels need CUs of their
             # own while a bucket is in flight: size the persistent GEMM grids for 256 - R CUs
@@ -483,6 +497,129 @@ class DataParallel(nn.Module):
         return t / self.world
 
 
+def choose_transport(records):
+    """The rank-uniform verdict of a transport probe: `records` = one dict per rank with `direct_ok` (the direct
+    path ran and matched the reference transport within tolerance), `checksum` (of the direct result: must be equal
+    on every rank — replicas that disagree bit-wise drift apart), `ref_ms`, `direct_ms`.  -> (chosen, reason) with
+    chosen in {"direct", "rccl"}; a pure function, every rank evaluates it on the same gathered list."""
+    if not all(r.get("direct_ok") for r in records):
+        bad = [i for i, r in enumerate(records) if not r.get("direct_ok")]
+        return "rccl", f"direct transport failed or mismatched on rank(s) {bad}: " + \
+            "; ".join(str(records[i].get("error", "mismatch")) for i in bad)
+    if len({r.get("checksum") for r in records}) != 1:
+        return "rccl", "direct results differ bit-wise between ranks"
+    ref = max(r["ref_ms"] for r in records)
+    direct = max(r["direct_ms"] for r in records)
+    if not direct < ref:
+        return "rccl", f"direct not faster ({direct:.3f} ms vs {ref:.3f} ms)"
+    return "direct", f"direct correct and faster ({direct:.3f} ms vs {ref:.3f} ms)"
+
+
+def probe_transports(process_group, device, make_direct, n_elems: int = 16 << 20, iters: int = 3,
+                     fault_rank=None, timeout_s: float = 20.0):
+    """SSL4GIE_ALLREDUCE=auto: all-reduce(mean) one test slice of `n_elems` floats through torch.distributed (RCCL on
+    the GPU) and through the handle `make_direct()` returns (csrc/allreduce.hip), compare, time both (max over
+    ranks), agree.  -> (direct handle or None, report dict).  Everything a rank can get wrong on its own — the
+    construction of the handle, a peer that does not answer within `timeout_s` (the sticky-error path), a wrong
+    sum — is caught, turned into direct_ok=False and exchanged through torch.distributed, so every rank reaches the
+    same verdict and carries on in this process with the transport that works."""
+    import time
+    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+    cuda = torch.device(device).type == "cuda"
+    gen = torch.Generator("cpu").manual_seed(9000 + rank)
+    x = torch.randn(min(n_elems, 1 << 22), generator=gen).repeat((n_elems + (1 << 22) - 1) // (1 << 22))[:n_elems].to(device)
+
+    def timed(fn):
+        """-> (ms per call, error or None); never raises and always reaches its barrier: the ranks' collective
+        sequences stay aligned whatever one of them runs into"""
+        err = None
+        try:
+            fn()  # warm-up (connections, first touch)
+            if cuda:
+                torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = e
+        dist.barrier(group=process_group)
+        t0 = time.perf_counter()
+        if err is None:
+            try:
+                for _ in range(iters):
+                    fn()
+                if cuda:
+                    torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                err = e
+        return 1e3 * (time.perf_counter() - t0) / iters, err
+
+    ref = x.clone()
+    dist.all_reduce(ref, group=process_group)
+    ref /= world
+    buf = x.clone()
+    ref_ms, _ = timed(lambda: dist.all_reduce(buf, group=process_group))
+    rec = {"direct_ok": False, "ref_ms": ref_ms, "direct_ms": float("inf"), "checksum": None}
+    direct = None
+    try:
+        direct = make_direct()
+    except Exception as e:  # noqa: BLE001 — any failure means "not this transport"
+        rec["error"] = f"init: {e}"
+
+    def agree(flag):  # the construction and every later stage are collective: all ranks go on, or none
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(flag), group=process_group)
+        return all(flags)
+
+    if agree(direct is not None):
+        valid = False
+        try:
+            if hasattr(direct, "set_timeout"):
+                direct.set_timeout(timeout_s)
+            y = x.clone()
+            direct.all_reduce_(y, 1.0 / world)
+            if cuda:
+                torch.cuda.synchronize()
+            direct.raise_if_failed()
+            if fault_rank is not None and rank == fault_rank:
+                y[n_elems // 2] += 1.0
+            err = float((y - ref).abs().max())
+            scale = float(ref.abs().max())
+            rec["max_abs_diff"] = err
+            rec["checksum"] = (int(y.view(torch.int32).to(torch.int64).sum()), float(y.double().sum()))
+            valid = err <= 1e-6 * max(scale, 1.0) and bool(torch.isfinite(y).all())
+            if not valid:
+                rec["error"] = f"max |direct - reference| = {err:.3e} (scale {scale:.3e})"
+        except Exception as e:  # noqa: BLE001
+            rec["error"] = f"run: {e}"
+        if agree(valid):
+            buf2 = x.clone()
+            ms, terr = timed(lambda: (direct.all_reduce_(buf2, 1.0 / world), direct.raise_if_failed()))
+            if terr is None:
+                rec["direct_ms"], rec["direct_ok"] = ms, True
+            else:
+                rec["error"] = f"timing: {terr}"
+        elif valid:
+            rec["direct_ok"] = True   # this rank's result was right; a peer's was not (its record says so)
+            rec["direct_ms"] = float("inf")
+    else:
+        rec.setdefault("error", "a peer could not create the handle")
+    recs = [None] * world
+    dist.all_gather_object(recs, rec, group=process_group)
+    chosen, reason = choose_transport(recs)
+    if chosen != "direct" and direct is not None:
+        try:
+            direct.close()
+        except Exception:  # noqa: BLE001
+            pass
+        direct = None
+    elif direct is not None and hasattr(direct, "set_timeout"):
+        import os
+        direct.set_timeout(float(os.environ.get("SSL4GIE_AR_TIMEOUT_S", "600")))
+    fin = lambda v: None if v is None or v != v or v == float("inf") else round(v, 3)
+    report = {"rccl_ms": fin(max(r["ref_ms"] for r in recs)),
+              "direct_ms": fin(max(r["direct_ms"] for r in recs)),
+              "mib": round(4 * n_elems / 2 ** 20, 1), "chosen": chosen, "reason": reason}
+    return direct, report
+
+
 class DirectAllReduce:
     """ssl4gie_allreduce_direct_* behind the interface DataParallel needs: one-hop reduce-scatter +
     all-gather over the node's xGMI links by peer-to-peer stores (csrc/allreduce.hip).  The IPC
@@ -547,20 +684,115 @@ class DirectAllReduce:
 
 
 _SYNCBN_EXCHANGE = {}
+SYNCBN_PROBE = {}   # id(process_group) -> report of the SSL4GIE_SYNCBN=auto probe
+
+
+def probe_syncbn(process_group, device, make_direct, channels: int = 2048, iters: int = 20, timeout_s: float = 20.0):
+    """SSL4GIE_SYNCBN=auto: one SyncBatchNorm record (2C + 1 floats) gathered through torch.distributed and through
+    the direct exchange; the direct result must equal the reference bit for bit on every rank (an all-gather only
+    moves data) and be faster.  Same never-raise, always-agree structure as probe_transports."""
+    import time
+    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+    cuda = torch.device(device).type == "cuda"
+    n = 2 * channels + 1
+    src = torch.randn(n, generator=torch.Generator("cpu").manual_seed(7000 + rank)).to(device)
+    ref = torch.empty(world * n, dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(ref, src, group=process_group)
+
+    def timed(fn):
+        err = None
+        try:
+            fn()
+            if cuda:
+                torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = e
+        dist.barrier(group=process_group)
+        t0 = time.perf_counter()
+        if err is None:
+            try:
+                for _ in range(iters):
+                    fn()
+                if cuda:
+                    torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                err = e
+        return 1e3 * (time.perf_counter() - t0) / iters, err
+
+    def agree(flag):
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(flag), group=process_group)
+        return all(flags)
+
+    out = torch.empty_like(ref)
+    ref_ms, _ = timed(lambda: dist.all_gather_into_tensor(out, src, group=process_group))
+    rec = {"direct_ok": False, "ref_ms": ref_ms, "direct_ms": float("inf"), "checksum": None}
+    direct = None
+    try:
+        direct = make_direct()
+    except Exception as e:  # noqa: BLE001
+        rec["error"] = f"init: {e}"
+    if agree(direct is not None):
+        valid = False
+        try:
+            if hasattr(direct, "set_timeout"):
+                direct.set_timeout(timeout_s)
+            got = torch.zeros_like(ref)
+            direct.all_gather_(src, got)
+            if cuda:
+                torch.cuda.synchronize()
+            direct.raise_if_failed()
+            valid = bool(torch.equal(got, ref))
+            rec["checksum"] = float(got.double().sum())
+            if not valid:
+                rec["error"] = "gathered records differ from torch.distributed's"
+        except Exception as e:  # noqa: BLE001
+            rec["error"] = f"run: {e}"
+        if agree(valid):
+            got2 = torch.empty_like(ref)
+            ms, terr = timed(lambda: (direct.all_gather_(src, got2), direct.raise_if_failed()))
+            if terr is None:
+                rec["direct_ms"], rec["direct_ok"] = ms, True
+            else:
+                rec["error"] = f"timing: {terr}"
+        elif valid:
+            rec["direct_ok"] = True
+    else:
+        rec.setdefault("error", "a peer could not create the handle")
+    recs = [None] * world
+    dist.all_gather_object(recs, rec, group=process_group)
+    chosen, reason = choose_transport(recs)
+    if chosen != "direct" and direct is not None:
+        try:
+            direct.close()
+        except Exception:  # noqa: BLE001
+            pass
+        direct = None
+    elif direct is not None and hasattr(direct, "set_timeout"):
+        import os
+        direct.set_timeout(float(os.environ.get("SSL4GIE_AR_TIMEOUT_S", "600")))
+    fin = lambda v: None if v is None or v != v or v == float("inf") else round(v, 4)
+    return direct, {"torch_ms": fin(max(r["ref_ms"] for r in recs)), "direct_ms": fin(max(r["direct_ms"] for r in recs)),
+                    "floats": n, "chosen": "direct" if chosen == "direct" else "torch.distributed", "reason": reason}
 
 
 def syncbn_exchange(process_group=None, max_channels: int = 8192):
-    """The node-local exchange SyncBatchNorm layers use when SSL4GIE_SYNCBN=direct: one DirectAllReduce
-    handle of its own (the layers run on the compute stream; the gradient slices have theirs on the comm
-    stream), created on first use — a collective, so every rank reaches it at the same layer.  None when
-    the option is off (torch.distributed carries the statistics then)."""
+    """The node-local exchange SyncBatchNorm layers use when SSL4GIE_SYNCBN=direct (or =auto and the probe picked
+    it): one DirectAllReduce handle of its own (the layers run on the compute stream; the gradient slices have
+    theirs on the comm stream), created on first use — a collective, so every rank reaches it at the same layer.
+    None when the option is off or the probe chose torch.distributed (which carries the statistics then)."""
     import os
-    if os.environ.get("SSL4GIE_SYNCBN", "").lower() != "direct" or not torch.cuda.is_available():
+    mode = os.environ.get("SSL4GIE_SYNCBN", "").lower()
+    if mode not in ("direct", "auto") or not torch.cuda.is_available():
         return None
     key = id(process_group)
     if key not in _SYNCBN_EXCHANGE:
         world = dist.get_world_size(process_group)
-        _SYNCBN_EXCHANGE[key] = DirectAllReduce(world * (2 * max_channels + 4), process_group)
+        make = lambda: DirectAllReduce(world * (2 * max_channels + 4), process_group)
+        if mode == "direct":
+            _SYNCBN_EXCHANGE[key] = make()
+        else:
+            _SYNCBN_EXCHANGE[key], SYNCBN_PROBE[key] = probe_syncbn(process_group, torch.device("cuda", torch.cuda.current_device()), make)
     return _SYNCBN_EXCHANGE[key]
 
 

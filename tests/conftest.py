@@ -45,9 +45,8 @@ def keyed_weights(module, seed, keys=None, digest=None, keep=()):
         assert sorted(own) == sorted(np.asarray(keys).tolist()), \
             set(own) ^ set(np.asarray(keys).tolist())
     sd = synth.keyed_state_dict({k: tuple(v.shape) for k, v in own.items()}, seed, keep=keep)
-    with torch.no_grad():
-        for k, v in sd.items():
-            own[k].copy_(v)
+    missing, unexpected = module.load_state_dict(sd, strict=False)   # (a state_dict entry may be a copy: ViTDet_FPN)
+    assert set(missing) <= set(keep) and not unexpected, (missing, unexpected)
     full = {k: v.detach().clone().cpu() for k, v in module.state_dict().items()}
     if digest is not None:
         assert synth.state_dict_digest(full) == str(digest), "weights differ from the generator's"

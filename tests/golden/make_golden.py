@@ -33,6 +33,10 @@ Fixtures written:
                       the statement sequence of train_depth.py:35-48 (BASELINE.json configs[3]), B = 2
   g14_moco_curve.npz  50-step loss curve of the reference MoCo_ResNet + LARS (builder.py:75-96, main_moco.py),
                       128 x 128 views, B = 16, 1-process gloo (BASELINE.json configs[2])
+  g16_frozen.npz      frozen=True (linear probe / frozen finetune, models.py:138-142,341-345,459-463): ViT_from_MAE head,
+                      ViT_from_MAE + DPT depth, ResNet_from_Any head — outputs, head / decoder gradients, no trunk gradients
+  g17_bf16_bars.npz   per-tensor error of the reference's own bf16-autocast gradients against its fp64 gradients (G11
+                      depth model, G10 det trunk): the bar the bf16 engine's whole-model gradients are held to
   g14_moco_fp64.npz   the same reference classes converted to double: 10-step loss curve, step-0 gradients and the
                       per-tensor error of the reference's own fp32 gradients against them (the parity gate of
                       tests/test_gpu_curves.py: the fp32 engine must be no further from fp64 than the reference's fp32)
@@ -834,6 +838,153 @@ def g14_moco_fp64(steps=10):
           f"losses fp64 {losses[0]:.9f} .. {losses[-1]:.9f}")
 
 
+def g16_frozen():
+    """frozen=True of the reference's three wrappers (models.py:138-142, 341-345, 459-463; CLI --frozen): the trunk
+    runs under no_grad — in training mode, so a ResNet trunk still uses and updates batch statistics — and only the
+    head / decoder receive gradients."""
+    rm = import_reference_models()
+    ref_loss = _load_by_path("ref_losses", os.path.join(REF, "Depth_estimation", "Metrics", "losses.py"))
+    out = {}
+    cfg = mae_ref.VIT_B
+    imgs = synth.synth_images(2, cfg, seed=71)
+    out["imgs_seed"] = np.array(71)
+    keep = ("pos_embed", "decoder_pos_embed")
+    # ---- ViT_from_MAE(head=True, frozen=True): linear probe
+    m = rm.ViT_from_MAE(None, True, 6, True, None, False, None, 768, 12, 12, "cls")
+    shapes, digest = load_keyed(m, seed=72, keep=keep)
+    out["mae_head/keys"] = np.array(sorted(shapes)); out["mae_head/digest"] = np.array(digest)
+    m.train()
+    y = m(imgs)
+    wy = torch.randn(y.shape, generator=torch.Generator("cpu").manual_seed(73))
+    (y * wy).sum().backward()
+    out["mae_head/cls"] = y.detach().numpy()
+    got = sorted(k for k, p in m.named_parameters() if p.grad is not None)
+    assert got == ["lin_head.bias", "lin_head.weight"], got
+    pack_grads(out, "mae_head/", list(m.named_parameters()), small=8192)
+    # ---- ViT_from_MAE(dense="depth", frozen=True): frozen trunk, DPT decoder trained
+    m = rm.ViT_from_MAE(None, False, 1, True, "depth", False, None, 768, 12, 12, "cls")
+    shapes, digest = load_keyed(m, seed=74, keep=keep)
+    out["mae_depth/keys"] = np.array(sorted(shapes)); out["mae_depth/digest"] = np.array(digest)
+    m.train()
+    g = torch.Generator("cpu").manual_seed(75)
+    target = torch.rand(2, 1, 224, 224, generator=g)
+    target = torch.where(torch.rand(2, 1, 224, 224, generator=g) < 0.1, torch.zeros(()), target)
+    pred = m(imgs)
+    loss = ref_loss.ScaleAndShiftInvariantLoss(alpha=0.1)(pred, target)
+    loss.backward()
+    out["mae_depth/pred_sub"] = pred.detach()[:, :, ::2, ::2].numpy().copy()
+    out["mae_depth/loss"] = np.array(float(loss))
+    with_grad = sorted(k for k, p in m.named_parameters() if p.grad is not None)
+    assert with_grad and all(k.startswith("decoder.") for k in with_grad), with_grad[:4]
+    out["mae_depth/with_grad"] = np.array(with_grad)
+    pack_grads(out, "mae_depth/", list(m.named_parameters()))
+    # ---- ResNet_from_Any(head=True, frozen=True): training-mode BatchNorm inside the no_grad trunk
+    m = rm.ResNet_from_Any(None, True, 6, True, None)
+    shapes, digest = load_keyed(m, seed=76)
+    out["resnet_head/keys"] = np.array(sorted(shapes)); out["resnet_head/digest"] = np.array(digest)
+    m.train()
+    ximgs = torch.randn(4, 3, 128, 128, generator=torch.Generator("cpu").manual_seed(77))
+    y = m(ximgs)
+    wy = torch.randn(y.shape, generator=torch.Generator("cpu").manual_seed(78))
+    (y * wy).sum().backward()
+    out["resnet_head/logits"] = y.detach().numpy()
+    got = sorted(k for k, p in m.named_parameters() if p.grad is not None)
+    assert got == ["lin_head.bias", "lin_head.weight"], got
+    pack_grads(out, "resnet_head/", list(m.named_parameters()), small=16384)
+    out["resnet_head/running_mean/bn1"] = m.bn1.running_mean.numpy().copy()
+    out["resnet_head/running_var/layer4.2.bn3"] = m.layer4[2].bn3.running_var.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g16_frozen.npz"), **out)
+    print(f"g16 ok: depth loss {float(out['mae_depth/loss']):.6f}")
+
+
+def _sample(t, n=2048):
+    """a strided sample of a tensor's elements (the whole tensor when it is small)"""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n]
+
+
+def g17_bf16_bars():
+    """Per-tensor error bars for the bf16 engine's whole-model gradients: the SAME reference
+    classes and keyed weights as G11 depth / G10 t512, evaluated (a) in double — the ground truth — and (b) under
+    the reference's own mixed-precision policy on this host, torch.autocast("cpu", bfloat16) (train_depth.py:41-46
+    uses torch.cuda.amp.autocast: half-precision matmul / conv, fp32 LayerNorm / softmax / loss).  Stored per tensor:
+    a strided sample of the double gradient, its norm, and the relative L2 error of the autocast gradient on that
+    sample.  tests/test_gpu_models_golden.py gates the bf16 engine at 1.5 x that distribution (median and worst)."""
+    rm = import_reference_models()
+    ref_loss = _load_by_path("ref_losses", os.path.join(REF, "Depth_estimation", "Metrics", "losses.py"))
+    out = {}
+
+    def run(tag, build, seed, keep, step):
+        res = {}
+        for mode in ("fp64", "bf16"):
+            m = build()
+            load_keyed(m, seed=seed, keep=keep)
+            m.train()
+            if mode == "fp64":
+                m.double()
+            loss = step(m, mode)
+            loss.backward()
+            res[mode] = ({k: p.grad.detach().double() for k, p in m.named_parameters() if p.grad is not None},
+                         float(loss))
+            del m
+        g64, l64 = res["fp64"]
+        g16, l16 = res["bf16"]
+        names = sorted(g64)
+        assert names == sorted(g16)
+        out[f"{tag}/names"] = np.array(names)
+        out[f"{tag}/loss_fp64"] = np.array(l64)
+        out[f"{tag}/loss_autocast"] = np.array(l16)
+        errs = []
+        for k in names:
+            a, b = _sample(g64[k]), _sample(g16[k])
+            out[f"{tag}/sample/{k}"] = a.float().numpy().copy()
+            errs.append(float((a - b).norm() / (a.norm() + 1e-300)))
+        out[f"{tag}/autocast_err"] = np.array(errs, dtype=np.float64)
+        out[f"{tag}/norm_fp64"] = np.array([float(g64[k].norm()) for k in names], dtype=np.float64)
+        e = np.array(errs)
+        print(f"g17 {tag}: loss fp64 {l64:.6f} autocast {l16:.6f}; autocast gradient error median {np.median(e):.3e} "
+              f"p90 {np.quantile(e, 0.9):.3e} max {e.max():.3e} ({names[int(e.argmax())]})", flush=True)
+
+    # ---- G11's ViT_from_MAE(dense="depth") + SSI loss (seed 44, images 41, target 45)
+    cfg = mae_ref.VIT_B
+    imgs = synth.synth_images(2, cfg, seed=41)
+    g = torch.Generator("cpu").manual_seed(45)
+    target = torch.rand(2, 1, 224, 224, generator=g)
+    target = torch.where(torch.rand(2, 1, 224, 224, generator=g) < 0.1, torch.zeros(()), target)
+
+    def depth_step(m, mode):
+        if mode == "fp64":
+            return ref_loss.ScaleAndShiftInvariantLoss(alpha=0.1)(m(imgs.double()), target.double())
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            pred = m(imgs)
+        return ref_loss.ScaleAndShiftInvariantLoss(alpha=0.1)(pred.float(), target)
+
+    run("mae_depth", lambda: rm.ViT_from_MAE(None, False, 1, False, "depth", False, None, 768, 12, 12, "cls"),
+        44, ("pos_embed", "decoder_pos_embed"), depth_step)
+    # ---- G10's detection trunk at 512^2 (seed 31, inputs 32)
+    gg = torch.Generator("cpu").manual_seed(32)
+    dimgs = torch.randn(1, 3, 512, 512, generator=gg)
+    wgt = torch.randn(1, 1024, 768, generator=gg)
+
+    def det_step(m, mode):
+        if mode == "fp64":
+            return (m.forward_features(dimgs.double()) * wgt.double()).sum()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            tok = m.forward_features(dimgs)
+        return (tok.float() * wgt).sum()
+
+    def det_build():
+        m = rm.VisionTransformer_from_Any(False, 0, False, None, True, 512, 768, 12, 12, "cls")
+        for p in m.fpn.parameters():
+            p.requires_grad_(False)
+        return m
+
+    run("t512", det_build, 31, (), det_step)
+    np.savez_compressed(os.path.join(HERE, "g17_bf16_bars.npz"), **out)
+    print("g17 ok")
+
+
 def g15_det_curve(steps=30):
     """the reference's own VisionTransformer_from_Any(det=True) trunk (models.py:155-210 windowed
     blocks, :310-338) at 512 x 512 (1024 tokens, four 256-token windows), B = 1, trained for 30 steps: tokens
@@ -876,6 +1027,7 @@ def main():
         "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi, "g8": g8_moco, "g9": g9_dpt_seg,
         "g3b": g3b_moco_sincos, "g10": g10_det, "g11": g11_vit_api, "g12": g12_resnet_dec,
         "g13": g13_depth_curve, "g14": g14_moco_curve, "g14fp64": g14_moco_fp64, "g15": g15_det_curve,
+        "g16": g16_frozen, "g17": g17_bf16_bars,
         "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
             **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
             "g5_curve_tiny.npz"),

@@ -156,6 +156,17 @@ def test_channels_last_layernorm_tables_keep_their_layout_cpu():
         gv = a.grad_view(w)
         gv.permute(1, 2, 0).copy_(torch.arange(w.numel(), dtype=torch.float32).view(w.shape[1], w.shape[2], w.shape[0]))
         assert float(gv[3, 1, 2]) == float((1 * w.shape[2] + 2) * w.shape[0] + 3)
+    # state_dict() itself is all-contiguous (the module's hook copies the 18 tables): safetensors takes
+    # it as it is, `.view(-1)` works, and a round trip through the bytes restores values AND the parameter layout
+    from safetensors.torch import load as st_load, save as st_save
+    sd2 = f.state_dict()
+    assert all(v.is_contiguous() for v in sd2.values()) and sd2["fpn1.2.weight"].view(-1).numel() == 32 * 4 * 4
+    back = st_load(st_save(sd2))
+    h = ViTDet_FPN(grid=8, dim=64, out=32)
+    h.load_state_dict(back)
+    assert all(torch.equal(v, sd[k]) for k, v in h.state_dict().items())
+    assert all(not p.is_contiguous() and p.permute(1, 2, 0).is_contiguous()
+               for m in h.modules() if isinstance(m, nn.LayerNorm) for p in (m.weight, m.bias))
 
 
 def test_lds_swizzles_are_conflict_free():

@@ -215,3 +215,91 @@ def test_data_parallel_direct_transport_equals_default():
         for ga, gb in zip(a, b):
             assert np.allclose(ga, gb, rtol=1e-6, atol=1e-8)
     assert all(np.array_equal(x, y) for x, y in zip(results["direct"][0][0], results["direct"][1][0]))
+
+
+def _auto_worker(rank, world, port, q, fault):
+    """SSL4GIE_ALLREDUCE=auto on two processes sharing the device: the probe runs the real direct transport against
+    the torch.distributed one (gloo here), both ranks agree; with the forced-mismatch hook (rank 1's direct result
+    corrupted) the verdict is "rccl" on both ranks and the wrapper carries on in-process on torch.distributed"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SSL4GIE_ALLREDUCE="auto", SSL4GIE_COMM_CUS="0")
+    if fault:
+        os.environ["SSL4GIE_AR_PROBE_FAULT"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    out = {}
+    try:
+        from ssl4gie_amd.engine import GradSink, ParamArena
+        from ssl4gie_amd.parallel import DataParallel
+
+        class Toy(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.a = torch.nn.Linear(256, 256)
+                self.b = torch.nn.Linear(256, 8)
+                self._a = None
+
+            def arena(self):
+                if self._a is None:
+                    self._a = ParamArena(list(self.parameters()))
+                    self._s = GradSink(self._a)
+                return self._a
+
+            def forward(self, x):
+                return (self.b(torch.tanh(self.a(x))) ** 2).mean()
+
+        torch.manual_seed(3)
+        m = Toy().cuda()
+        ddp = DataParallel(m, device_ids=[0])
+        out["probe"] = ddp.transport_probe
+        out["transport"] = ddp.transport
+        x = torch.randn(16, 256, generator=torch.Generator().manual_seed(50 + rank)).cuda()
+        ddp(x).backward()
+        ddp.finish()
+        torch.cuda.synchronize()
+        g = m.a.weight.grad.detach().cpu()
+        gs = [torch.empty_like(g) for _ in range(world)]
+        dist.all_gather(gs, g)
+        out["grads_equal"] = bool(torch.equal(gs[0], gs[1]))
+        # the mean gradient of the two ranks' batches, single process
+        torch.manual_seed(3)
+        r = Toy()
+        tot = 0
+        for k in range(world):
+            xk = torch.randn(16, 256, generator=torch.Generator().manual_seed(50 + k))
+            tot = tot + r(xk) / world
+        tot.backward()
+        out["err"] = float((g - r.a.weight.grad).abs().max() / r.a.weight.grad.abs().max())
+    except Exception as e:  # noqa
+        out["error"] = repr(e)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fault", [False, True])
+def test_transport_probe_two_processes_one_device(fault):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_auto_worker, args=(r, 2, port, q, fault)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert "error" not in res[0] and "error" not in res[1], res
+    assert res[0]["probe"] == res[1]["probe"] and res[0]["transport"] == res[1]["transport"]
+    p0 = res[0]["probe"]
+    assert p0["rccl_ms"] is not None and p0["chosen"] in ("direct", "rccl")
+    if fault:
+        assert p0["chosen"] == "rccl" and "rank(s) [1]" in p0["reason"] and res[0]["transport"] == "gloo"
+    else:
+        assert p0["direct_ms"] is not None, p0     # the direct path ran and matched on both ranks
+        assert res[0]["transport"] == ("direct" if p0["chosen"] == "direct" else "gloo")
+    for r in (0, 1):
+        assert res[r]["grads_equal"] and res[r]["err"] < 1e-5, res[r]
+    print("transport probe:", p0)

@@ -2,12 +2,14 @@
 against torch fp32 of the same op, the decoder against the golden fixture generated from the
 REFERENCE's DPT_decoder class (fp32 engine <= 1e-3 rel), and ViT_from_MAE(dense="depth") end to end
 against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, rel_err
+from conftest import ROOT, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -261,3 +263,39 @@ def test_vit_from_mae_depth_end_to_end_vs_oracle():
         p = dict(m.named_parameters())[name]
         assert rel_err(p.grad, sdo[name].grad) < 5e-3, name
     assert m.norm.weight.grad is None or float(m.norm.weight.grad.abs().max()) == 0.0  # final norm unused
+
+
+def test_bilinear2x_two_by_two_kernels_equal_the_one_pixel_kernels_bit_for_bit(tmp_path):
+    """the round-6 bilinear kernels (2 x 2 outputs / inputs per thread, 9 resp. 36 taps instead of 16 / 64) against
+    the one-pixel-per-thread kernels they replace (SSL4GIE_BILINEAR22=0, read once per process: a child process
+    computes the reference) — identical bits, forward and backward, fp32 and bf16, odd sizes and the 1 x 1 map"""
+    import subprocess
+    import sys
+    from ssl4gie_amd import ops
+    shapes = [(2, 7, 5, 16), (3, 14, 14, 256), (2, 9, 33, 128), (1, 1, 1, 8), (2, 56, 56, 64), (1, 2, 3, 8)]
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {repr(ROOT)})\n"
+        "from ssl4gie_amd import ops\n"
+        f"out = {{}}\n"
+        f"for i, s in enumerate({shapes!r}):\n"
+        "    for dt in (torch.float32, torch.bfloat16):\n"
+        "        g = torch.Generator().manual_seed(100 + i)\n"
+        "        x = torch.randn(*s, generator=g).to(dt).cuda()\n"
+        "        y = ops.bilinear2x_fwd(x)\n"
+        "        dy = torch.randn(y.shape, generator=g).to(dt).cuda()\n"
+        "        out[(i, str(dt))] = (y.cpu(), ops.bilinear2x_bwd(dy).cpu())\n"
+        f"torch.save(out, {repr(str(tmp_path / 'ref.pt'))})\n")
+    env = dict(os.environ, SSL4GIE_BILINEAR22="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=240)
+    ref = torch.load(str(tmp_path / "ref.pt"))
+    for i, s in enumerate(shapes):
+        for dt in (torch.float32, torch.bfloat16):
+            g = torch.Generator().manual_seed(100 + i)
+            x = torch.randn(*s, generator=g).to(dt).cuda()
+            y = ops.bilinear2x_fwd(x)
+            dy = torch.randn(y.shape, generator=g).to(dt).cuda()
+            dx = ops.bilinear2x_bwd(dy)
+            ry, rdx = ref[(i, str(dt))]
+            assert torch.equal(y.cpu(), ry), ("fwd", s, dt)
+            assert torch.equal(dx.cpu(), rdx), ("bwd", s, dt)

@@ -44,7 +44,7 @@ DET_NAMES = ("pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias", "b
              "blocks.11.mlp.fc1.bias", "norm.weight", "norm.bias")
 
 
-@pytest.mark.parametrize("prec,tol,gtol", [("fp32", 1e-3, 3e-3), ("bf16", 6e-2, 0.25)])
+@pytest.mark.parametrize("prec,tol,gtol", [("fp32", 1e-3, 3e-3), ("bf16", 6e-2, None)])  # bf16 gradients: test_g17_*
 def test_g10_det_trunk_512_matches_reference(prec, tol, gtol):
     """reference VisionTransformer_from_Any(det=True, fixed_size=512).forward_features (models.py:
     155-210 windowed blocks 0,1,3,4,6,7,9,10; :310-338): tokens and gradients"""
@@ -64,7 +64,8 @@ def test_g10_det_trunk_512_matches_reference(prec, tol, gtol):
     n = float(g["t512/tok_norm"])
     assert abs(float(tok.detach().double().norm()) - n) < tol * n
     (tok * wgt.to(DEV)).sum().backward()
-    _check_grads(g, "t512/", dict(m.named_parameters()), gtol, DET_NAMES)
+    if gtol is not None:
+        _check_grads(g, "t512/", dict(m.named_parameters()), gtol, DET_NAMES)
     # the interpolated position table's gradient is written through the GradSink into the arena
     # (data-parallel buckets and the arena optimizers read the arena, not loose .grad tensors)
     a = m.arena()
@@ -159,7 +160,7 @@ def test_g11_backbone_heads_match_reference(which):
         assert rel_err(tok[:, ::8], g["mae_head/tok_sub"]) < 1e-3
 
 
-@pytest.mark.parametrize("prec,tol,gtol", [("fp32", 1e-3, 5e-3), ("bf16", 5e-2, 0.3)])
+@pytest.mark.parametrize("prec,tol,gtol", [("fp32", 1e-3, 5e-3), ("bf16", 5e-2, None)])  # bf16 gradients: test_g17_*
 def test_g11_vit_from_mae_depth_matches_reference(prec, tol, gtol):
     """ViT_from_MAE(dense="depth"): taps after blocks 2/5/8/11 without the final norm (models.py:
     450-456), DPT decoder, the reference's SSI loss, gradients of trunk + decoder; the parameters the
@@ -195,7 +196,8 @@ def test_g11_vit_from_mae_depth_matches_reference(prec, tol, gtol):
              "decoder.act_postprocess42.1.weight", "decoder.layer1_rn.weight",
              "decoder.refinenet1.resConfUnit2.conv2.bias", "decoder.refinenet4.out_conv.weight",
              "decoder.output_conv.0.weight", "decoder.output_conv.4.weight")
-    _check_grads(g, "mae_depth/", params, gtol, names)
+    if gtol is not None:
+        _check_grads(g, "mae_depth/", params, gtol, names)
 
 
 def _stage_maps(seed, b=2, s=32):
@@ -263,3 +265,173 @@ def test_g12_resnet_whole_model_and_classifier_match_fixture():
     with torch.no_grad():
         y = m2(imgs.to(DEV))
     assert rel_err(y, g["cls/logits"]) < 3e-3
+
+
+# ------------------------------------------------------------------ frozen=True (linear probe / frozen finetune)
+def _only_these_have_grads(m, prefixes):
+    for k, p in m.named_parameters():
+        if k.startswith(prefixes):
+            assert p.grad is not None, k
+        else:
+            assert p.grad is None, k
+
+
+def test_g16_frozen_vit_linear_probe_matches_reference():
+    """reference ViT_from_MAE(head=True, frozen=True) (models.py:459-472): the trunk under no_grad (a different
+    executor mode: no activation arena, no weight-gradient fork), logits <= 1e-3, only lin_head.* gets gradients"""
+    from oracle import mae_ref, synth
+    from ssl4gie_amd.Models import models
+    g = load_golden("g16_frozen.npz")
+    imgs = synth.synth_images(2, mae_ref.VIT_B, seed=int(g["imgs_seed"]))
+    m = models.ViT_from_MAE(None, True, 6, True, None, False, None, 768, 12, 12, "cls")
+    keyed_weights(m, 72, g["mae_head/keys"], g["mae_head/digest"], keep=("pos_embed", "decoder_pos_embed"))
+    m.to(DEV).set_precision("fp32")
+    m.train()
+    y = m(imgs.to(DEV))
+    assert rel_err(y.detach(), g["mae_head/cls"]) < 1e-3
+    wy = torch.randn(y.shape, generator=torch.Generator("cpu").manual_seed(73))
+    (y * wy.to(DEV)).sum().backward()
+    _only_these_have_grads(m, ("lin_head.",))
+    _check_grads(g, "mae_head/", dict(m.named_parameters()), 3e-3)
+    # bf16 engine: same structure, looser values
+    m.zero_grad(set_to_none=True)
+    m.set_precision("bf16")
+    y = m(imgs.to(DEV))
+    assert rel_err(y.detach(), g["mae_head/cls"]) < 5e-2
+    (y * wy.to(DEV)).sum().backward()
+    _only_these_have_grads(m, ("lin_head.",))
+
+
+@pytest.mark.parametrize("prec,tol,gtol", [("fp32", 1e-3, 3e-3), ("bf16", 5e-2, None)])
+def test_g16_frozen_vit_depth_matches_reference(prec, tol, gtol):
+    """reference ViT_from_MAE(dense="depth", frozen=True) (models.py:459-465): frozen trunk, DPT decoder trained with
+    the SSI loss — prediction and loss <= 1e-3, decoder gradients <= 3e-3, no trunk gradient"""
+    from oracle import mae_ref, synth
+    from ssl4gie_amd.Models import models
+    from ssl4gie_amd.losses import ScaleAndShiftInvariantLoss
+    g = load_golden("g16_frozen.npz")
+    imgs = synth.synth_images(2, mae_ref.VIT_B, seed=int(g["imgs_seed"]))
+    m = models.ViT_from_MAE(None, False, 1, True, "depth", False, None, 768, 12, 12, "cls")
+    keyed_weights(m, 74, g["mae_depth/keys"], g["mae_depth/digest"], keep=("pos_embed", "decoder_pos_embed"))
+    m.to(DEV).set_precision(prec)
+    m.train()
+    gen = torch.Generator("cpu").manual_seed(75)
+    target = torch.rand(2, 1, 224, 224, generator=gen)
+    target = torch.where(torch.rand(2, 1, 224, 224, generator=gen) < 0.1, torch.zeros(()), target)
+    pred = m(imgs.to(DEV))
+    loss = ScaleAndShiftInvariantLoss(alpha=0.1)(pred, target.to(DEV))
+    loss.backward()
+    assert rel_err(pred.detach()[:, :, ::2, ::2], g["mae_depth/pred_sub"]) < tol
+    assert abs(float(loss.detach()) - float(g["mae_depth/loss"])) < tol * float(g["mae_depth/loss"])
+    with_grad = set(g["mae_depth/with_grad"].tolist())
+    for k, p in m.named_parameters():
+        if k in with_grad:
+            assert p.grad is not None, k
+        else:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        if not k.startswith("decoder."):
+            assert p.grad is None, k
+    if gtol is not None:
+        _check_grads(g, "mae_depth/", dict(m.named_parameters()), gtol)
+
+
+def test_g16_frozen_resnet_linear_probe_matches_fixture():
+    """reference ResNet_from_Any(head=True, frozen=True) (models.py:138-149): the no_grad trunk still runs BatchNorm in
+    TRAINING mode (batch statistics, running statistics updated); only lin_head.* gets gradients.  (The trunk below
+    the reference class is oracle/torchvision_restatement.py: unpinned at that boundary, as G12.)"""
+    from ssl4gie_amd.Models import models
+    g = load_golden("g16_frozen.npz")
+    m = models.ResNet_from_Any(None, True, 6, True, None)
+    keyed_weights(m, 76, g["resnet_head/keys"], g["resnet_head/digest"])
+    m.to(DEV).set_precision("fp32")
+    m.train()
+    imgs = torch.randn(4, 3, 128, 128, generator=torch.Generator("cpu").manual_seed(77))
+    y = m(imgs.to(DEV))
+    assert rel_err(y.detach(), g["resnet_head/logits"]) < 3e-3
+    wy = torch.randn(y.shape, generator=torch.Generator("cpu").manual_seed(78))
+    (y * wy.to(DEV)).sum().backward()
+    _only_these_have_grads(m, ("lin_head.",))
+    _check_grads(g, "resnet_head/", dict(m.named_parameters()), 5e-3)
+    from ssl4gie_amd.resnet_engine import flush_batch_counts
+    flush_batch_counts(m)
+    assert rel_err(m.bn1.running_mean, g["resnet_head/running_mean/bn1"]) < 1e-3
+    assert rel_err(m.layer4[2].bn3.running_var, g["resnet_head/running_var/layer4.2.bn3"]) < 3e-3
+    assert int(m.bn1.num_batches_tracked) == 1
+
+
+# ------------------------------------------------------------------ bf16 whole-model gradients, per tensor
+def _sample(t, n=2048):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n]
+
+
+def _bf16_gate(g, tag, params):
+    """per-tensor relative L2 error of the bf16 engine's gradients against the reference's DOUBLE gradients (strided
+    samples stored in G17), held to 1.5 x the DISTRIBUTION of the reference's own bf16-autocast error on the same
+    samples (tests/golden/make_golden.py g17_bf16_bars): median, 90th percentile, and the worst of the well-sampled
+    tensors (>= 1024 elements).  A scalar bias is one signed sum of 1e5 terms — its relative error is a single draw
+    of a heavy-tailed quantity in either arithmetic — so the tiny tensors are only held to 3 x the reference's worst."""
+    names = g[f"{tag}/names"].tolist()
+    ref_err = np.asarray(g[f"{tag}/autocast_err"], dtype=np.float64)
+    errs, big = [], []
+    for k in names:
+        assert params[k].grad is not None, k
+        a = torch.from_numpy(g[f"{tag}/sample/{k}"]).double()
+        b = _sample(params[k].grad).double().cpu()
+        errs.append(float((a - b).norm() / (a.norm() + 1e-300)))
+        big.append(params[k].numel() >= 1024)
+    errs, big = np.array(errs), np.array(big)
+    order = np.argsort(-errs)[:4]
+    print(f"{tag}: worst tensors " + ", ".join(f"{names[i]} {errs[i]:.3e} (ref {ref_err[i]:.3e})" for i in order))
+    assert np.median(errs) <= 1.5 * np.median(ref_err), (np.median(errs), np.median(ref_err))
+    assert np.quantile(errs, 0.9) <= 1.5 * np.quantile(ref_err, 0.9), (np.quantile(errs, 0.9), np.quantile(ref_err, 0.9))
+    wb = int(np.argmax(np.where(big, errs, 0)))
+    assert errs[wb] <= 1.5 * ref_err[big].max(), (names[wb], errs[wb], ref_err[big].max())
+    assert errs.max() <= 3.0 * ref_err.max(), (names[int(errs.argmax())], errs.max(), ref_err.max())
+    return errs
+
+
+def test_g17_bf16_depth_gradients_within_the_references_own_autocast_error():
+    """G11's ViT_from_MAE(dense="depth") + SSI loss on the bf16 engine: every gradient tensor against the reference's
+    fp64 gradient, gated by the reference's own bf16-autocast error (this loss's gradient is ill-conditioned: the L1
+    gradient-matching term of Depth_estimation/Metrics/losses.py:60-77 flips signs under any half-precision rounding
+    of the prediction — the reference's autocast is 19-22 % off on every tensor; the fp32 engine is held to 5e-3 by
+    test_g11_vit_from_mae_depth_matches_reference)"""
+    from oracle import mae_ref, synth
+    from ssl4gie_amd.Models import models
+    from ssl4gie_amd.losses import ScaleAndShiftInvariantLoss
+    g11, g = load_golden("g11_vit_api.npz"), load_golden("g17_bf16_bars.npz")
+    imgs = synth.synth_images(2, mae_ref.VIT_B, seed=int(g11["imgs_seed"]))
+    m = models.ViT_from_MAE(None, False, 1, False, "depth", False, None, 768, 12, 12, "cls")
+    keyed_weights(m, 44, g11["mae_depth/keys"], g11["mae_depth/digest"], keep=("pos_embed", "decoder_pos_embed"))
+    m.to(DEV).set_precision("bf16")
+    gen = torch.Generator("cpu").manual_seed(45)
+    target = torch.rand(2, 1, 224, 224, generator=gen)
+    target = torch.where(torch.rand(2, 1, 224, 224, generator=gen) < 0.1, torch.zeros(()), target)
+    loss = ScaleAndShiftInvariantLoss(alpha=0.1)(m(imgs.to(DEV)), target.to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["mae_depth/loss_fp64"])) < 5e-3 * float(g["mae_depth/loss_fp64"])
+    errs = _bf16_gate(g, "mae_depth", dict(m.named_parameters()))
+    print(f"bf16 depth gradients vs fp64: median {np.median(errs):.3e} max {errs.max():.3e} "
+          f"(reference autocast: {np.median(g['mae_depth/autocast_err']):.3e} / {g['mae_depth/autocast_err'].max():.3e})")
+
+
+def test_g17_bf16_det_trunk_gradients_within_the_references_own_autocast_error():
+    """G10's detection trunk at 512^2 on the bf16 engine: per-tensor gradient error against fp64 within 1.5 x the
+    reference's own bf16-autocast error (median 6.3e-3, worst 9.6e-3) — replaces a 25 % whole-model bar"""
+    from ssl4gie_amd.Models import models
+    g10, g = load_golden("g10_det.npz"), load_golden("g17_bf16_bars.npz")
+    m = models.VisionTransformer_from_Any(False, 0, False, None, True, 1024, 768, 12, 12, "cls")
+    keyed_weights(m, 31, g10["keys"], g10["digest"])
+    m.fixed_size = 512
+    m.patch_embed.img_size = (512, 512)
+    m.to(DEV).set_precision("bf16")
+    gen = torch.Generator("cpu").manual_seed(32)
+    imgs = torch.randn(1, 3, 512, 512, generator=gen)
+    wgt = torch.randn(1, 1024, 768, generator=gen)
+    tok = m.forward_features(imgs.to(DEV))
+    (tok.float() * wgt.to(DEV)).sum().backward()
+    errs = _bf16_gate(g, "t512", dict(m.named_parameters()))
+    print(f"bf16 det-trunk gradients vs fp64: median {np.median(errs):.3e} max {errs.max():.3e} "
+          f"(reference autocast: {np.median(g['t512/autocast_err']):.3e} / {g['t512/autocast_err'].max():.3e})")

@@ -189,8 +189,7 @@ def test_optimizer_step_between_forward_and_backward_is_refused_only_for_its_own
     a step of the optimizer that OWNS them between forward and backward must raise in all three autograd nodes
     (the fused optimizers do not bump Tensor._version), a step of an unrelated optimizer must not."""
     from ssl4gie_amd.dpt_engine import Conv3x3Fn  # noqa: F401
-    from ssl4gie_amd.engine import GradSink, LPCache
-    from ssl4gie_amd import resnet_engine
+    from ssl4gie_amd.engine import GradSink, LPCache, bump_weights_epoch
     from ssl4gie_amd.resnet_engine import BatchNormFn, BnReluConv3x3Fn, BnReluMaxPoolFn
     B, H, W, C = 2, 16, 16, 64
     x = (torch.randn(B, H, W, C, generator=G(5)) * 1.3 + 0.2).to(BF).to(DEV)
@@ -210,10 +209,13 @@ def test_optimizer_step_between_forward_and_backward_is_refused_only_for_its_own
             y = BnReluMaxPoolFn.apply(xi, bn.weight, bn.bias, bn, GradSink(None), st)
         else:
             y, _ = BnReluConv3x3Fn.apply(xi, bn.weight, bn.bias, bn, st, conv.weight, GradSink(None), LPCache(), False)
-        opt = torch.optim.SGD(opt_of(bn), lr=0.1)
-        for q in opt.param_groups[0]["params"]:
-            q.grad = torch.ones_like(q)
-        opt.step()
+        # what ssl4gie_amd.optim's arena optimizers do: rewrite the storage through a raw pointer (no
+        # Tensor._version bump, so autograd's own saved-tensor check cannot see it) and advance the weights epoch
+        owned = opt_of(bn)
+        with torch.no_grad():
+            for q in owned:
+                q.data.add_(0.25)
+        bump_weights_epoch(touched=owned)
         y.backward(torch.ones_like(y))
         return xi.grad
 

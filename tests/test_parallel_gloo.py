@@ -216,6 +216,69 @@ def test_frozen_run_is_not_communicated_world2():
             assert total == (2 if i == 0 else 3), "one slice per trainable segment (bucket larger than either) + the tail"
 
 
+def _probe_worker(rank, world, port, q):
+    """linear probe / frozen finetune (reference `frozen=True`, Models/models.py:138-142,341-345,459-463): the trunk
+    runs under no_grad, its parameters still require grad but never receive one"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssl4gie_amd.parallel import DataParallel
+    torch.manual_seed(1234)
+    m = _Toy()
+
+    def probe_forward(x):
+        m.arena()
+        m._s.new_pass()
+        with torch.no_grad():
+            t = m._lin(x, m.stem) + m.pos * 2.0
+            for blk in m.blocks:
+                t = torch.tanh(m._lin(t, blk))
+        return (m._lin(t, m.head.fc) ** 2).mean()
+
+    m.forward = probe_forward
+    model = DataParallel(m, device_ids=[0], find_unused_parameters=True, bucket_bytes=4 * 2000)
+    batches = _batches(world, False)
+    # single-process gradient of the mean loss, plain torch
+    torch.manual_seed(1234)
+    r = _Toy()
+    tot = 0
+    for b in batches:
+        with torch.no_grad():
+            t = b[0] @ r.stem.weight.t() + r.stem.bias + r.pos * 2.0
+            for blk in r.blocks:
+                t = torch.tanh(t @ blk.weight.t() + blk.bias)
+        tot = tot + ((t @ r.head.fc.weight.t() + r.head.fc.bias) ** 2).mean() / len(batches)
+    tot.backward()
+    res = []
+    for step in range(3):
+        for p_ in m.parameters():
+            p_.grad = None
+        before = model.n_collectives
+        loss = model(batches[rank][0])
+        loss.backward()
+        model.finish()
+        ok = True
+        for (k, p_), (_, e) in zip(m.named_parameters(), r.named_parameters()):
+            if k.startswith("head."):
+                ok &= p_.grad is not None and torch.allclose(p_.grad, e.grad, rtol=1e-5, atol=1e-7)
+            else:
+                ok &= p_.grad is None or float(p_.grad.abs().max()) == 0.0
+        res.append((bool(ok), model.n_collectives - before, model.n_late))
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_frozen_trunk_under_no_grad_world2():
+    """`frozen=True` wrappers under DataParallel(find_unused_parameters=True): every trunk parameter is unused in the
+    learnt plan, the head's gradients are the rank mean, and every rank issues the same collectives per step"""
+    out = sorted(_run(False, 0, 0, target=_probe_worker))
+    assert out[0][1] == out[1][1] or [s[:2] for s in out[0][1]] == [s[:2] for s in out[1][1]]
+    for rank, steps in out:
+        for ok, ncoll, late in steps:
+            assert ok and late == 0
+        assert steps[1][1] == steps[2][1] and steps[1][1] <= 3, steps   # the head's slice + the unused tails
+
+
 def _loop_worker(rank, world, port, q):
     """gradient accumulation under no_sync(), a parameter that turns up after it was learnt as unused,
     a backward pass that raises half-way, a module.-prefixed checkpoint round trip"""
@@ -548,3 +611,73 @@ def test_barlow_twins_cross_corr_exchange_world2():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+# ------------------------------------------------------------------ SSL4GIE_ALLREDUCE=auto: the transport probe
+def test_choose_transport_is_a_pure_rank_uniform_verdict():
+    from ssl4gie_amd.parallel import choose_transport
+    ok = lambda ref, d, c=(1, 2.0): {"direct_ok": True, "ref_ms": ref, "direct_ms": d, "checksum": c}
+    assert choose_transport([ok(2.0, 1.0), ok(2.1, 1.2)])[0] == "direct"
+    assert choose_transport([ok(2.0, 1.0), ok(2.1, 2.5)])[0] == "rccl"            # max over ranks decides
+    assert choose_transport([ok(2.0, 1.0), ok(2.0, 1.0, (1, 2.5))])[0] == "rccl"  # replicas would drift apart
+    bad = {"direct_ok": False, "ref_ms": 2.0, "direct_ms": float("inf"), "checksum": None, "error": "run: timeout"}
+    chosen, reason = choose_transport([ok(2.0, 1.0), bad])
+    assert chosen == "rccl" and "[1]" in reason and "timeout" in reason
+
+
+class _FakeDirect:
+    """stands in for DirectAllReduce on gloo: a correct all-reduce(mean) with optional failure modes"""
+    closed = 0
+
+    def __init__(self, pg, fail_init=False, fail_run=False):
+        if fail_init:
+            raise RuntimeError("no peer access")
+        self.pg, self.fail_run = pg, fail_run
+
+    def set_timeout(self, s):
+        self.timeout = s
+
+    def all_reduce_(self, t, scale, stream=None):
+        if self.fail_run:
+            raise RuntimeError("rank 0 did not arrive in time")
+        dist.all_reduce(t, group=self.pg)
+        t.mul_(scale)
+
+    def raise_if_failed(self):
+        pass
+
+    def close(self):
+        _FakeDirect.closed += 1
+
+
+def _transport_probe_worker(rank, world, port, q, case):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssl4gie_amd.parallel import probe_transports
+    kw = {}
+    if case == "fault":
+        kw["fault_rank"] = 1
+    # "run": a peer never signals — on the real transport every rank's kernel then times out into the sticky error
+    make = lambda: _FakeDirect(None, fail_init=(case == "init" and rank == 0), fail_run=(case == "run"))
+    h, rep = probe_transports(None, "cpu", make, n_elems=1 << 16, iters=2, **kw)
+    q.put((rank, h is not None, rep, _FakeDirect.closed))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("case", ["clean", "fault", "init", "run"])
+def test_transport_probe_agrees_and_falls_back_in_process_world2(case):
+    """the probe behind SSL4GIE_ALLREDUCE=auto with a stand-in transport: both ranks reach the same verdict and return;
+    a corrupted result on one rank (the forced-mismatch hook), a handle that cannot be created on one rank and a
+    peer that never arrives (the sticky-error path) all end in "rccl" on BOTH ranks, in this process, with the
+    handle closed — never in a hang or a restart"""
+    out = sorted(_run(False, 0, 0, target=_transport_probe_worker, extra=(case,)))
+    (r0, has0, rep0, closed0), (r1, has1, rep1, closed1) = out
+    assert rep0 == rep1 and has0 == has1 == (rep0["chosen"] == "direct")
+    assert rep0["mib"] == 0.2 and rep0["rccl_ms"] is not None
+    if case == "clean":
+        assert rep0["chosen"] in ("direct", "rccl") and ("faster" in rep0["reason"])
+    else:
+        assert rep0["chosen"] == "rccl"
+        assert {"fault": "rank(s) [1]", "init": "init: no peer access", "run": "did not arrive in time"}[case] in rep0["reason"]
+        assert closed0 + closed1 >= 1   # whoever held a handle released it

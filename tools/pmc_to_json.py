@@ -13,6 +13,17 @@ KINDS = {"gemm_bf16_nt": ("gemm_bf16_nt256_kernel", "gemm_bf16_nt_kernel"),
          "attn_bwd_bf16": ("attn_bwd_bf16_kernel", "attn_long_bwd_dq_kernel", "attn_long_bwd_dkv_kernel")}
 
 
+def tree_hash():
+    """the commit the counters were taken on (+dirty when the work tree differs), or None outside a git checkout"""
+    import subprocess
+    try:
+        h = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True).stdout.strip()
+        return h + ("+dirty" if dirty else "")
+    except Exception:
+        return None
+
+
 def main(src, dst, note):
     rd = {k: 0.0 for k in KINDS}
     wr = {k: 0.0 for k in KINDS}
@@ -33,7 +44,7 @@ def main(src, dst, note):
         rd[kind] += 2.0 * float(f.group(1)) * 1024 * n
         wr[kind] += float(w.group(1)) * 1024 * n
         cnt[kind] += n
-    out = {"source": note,
+    out = {"source": note, "tree": tree_hash(),
            "hbm_bytes_per_launch": {k: int((rd[k] + wr[k]) / cnt[k]) for k in KINDS if cnt[k]},
            "read_bytes_per_launch": {k: int(rd[k] / cnt[k]) for k in KINDS if cnt[k]},
            "write_bytes_per_launch": {k: int(wr[k] / cnt[k]) for k in KINDS if cnt[k]},
