@@ -14,7 +14,7 @@
  *   - returns 0 on success, SSL4GIE_EARG (1000) for an invalid argument, otherwise a hipError_t;
  *   - callable from any host thread; the only mutable process-wide settings are the execution
  *     options ssl4gie_set_wgrad_stream / ssl4gie_set_compute_cus and the profiler;
- *   - ssl4gie_abi_version() = 6 (5: before SSL4GIE_PROF_KINDS grew from 5 to 7 — the profiler's arrays; 1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`; 2: before
+ *   - ssl4gie_abi_version() = 7 (6: before ssl4gie_bn_coef_stats / ssl4gie_bn_apply_bits / ssl4gie_bn_bwd_reduce_bits existed — additions only; 5: before SSL4GIE_PROF_KINDS grew from 5 to 7 — the profiler's arrays; 1: before ssl4gie_gemm_desc gained `colsum_a` / `conv`; 2: before
  *     ssl4gie_block_bwd's `accumulate` became a flag word and the grouped / deferred weight-gradient
  *     entry points existed; 3: before the direct transport's error word / time-out / all-gather,
  *     ssl4gie_bn_combine_stats and ssl4gie_debug_nt256_stamps existed — additions only; 4: before
@@ -521,6 +521,20 @@ int ssl4gie_bn_bwd_reduce_xmask(const void* dy, const void* x, const float* gamm
 int ssl4gie_bn_bwd_apply_xmask(const void* dy, const void* x, const float* gamma, const float* beta,
                                const float* mean, const float* rstd, const float* sums, float inv_count, void* dx,
                                float* workspace, int dtype, long long rows, int C, void* stream);
+/* SyncBatchNorm with the single-process fusions (ABI 7): the GLOBAL statistics come back from the exchange, so the
+ * fused consumers take them instead of computing their own.  coef_stats: (mean, rstd, gamma, beta) -> coef [2][C]
+ * (y = x coef[0] + coef[1]) for ssl4gie_bn_maxpool3x3s2_fwd and the SSL4GIE_EPI_AFFINE_AUX_RELU epilogue; apply_bits:
+ * y = relu(x coef[0] + coef[1] (+ res)) and the ReLU bit map of ssl4gie_bn_fwd_partials_bits (bf16); bwd_reduce_bits:
+ * ssl4gie_bn_bwd_reduce with the mask read from that bit map (dres = the masked gradient, then ssl4gie_bn_bwd_apply
+ * on dres with relu = 0).  Reference: torch.nn.SyncBatchNorm (convert_sync_batchnorm, Models/moco_v3/main_moco.py:196,
+ * Depth_estimation/train_depth.py:225). */
+int ssl4gie_bn_coef_stats(const float* mean, const float* rstd, const float* gamma, const float* beta, float* coef,
+                          int C, void* stream);
+int ssl4gie_bn_apply_bits(const void* x, const float* coef, const void* res, void* y, unsigned char* relu_bits,
+                          int dtype, long long rows, int C, void* stream);
+int ssl4gie_bn_bwd_reduce_bits(const void* dy, const unsigned char* relu_bits, const void* x, const float* mean,
+                               const float* rstd, void* dres, float* sums, float* workspace, int dtype,
+                               long long rows, int C, void* stream);
 /* MoCo._update_momentum_encoder (moco/builder.py:57-61): dst = dst m + src (1 - m), fp32, over a
  * whole parameter-arena slice */
 int ssl4gie_ema_update(float* dst, const float* src, float m, long long n, void* stream);

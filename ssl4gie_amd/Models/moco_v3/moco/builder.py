@@ -117,12 +117,35 @@ class MoCo(EngineModule):
         update reads the base weights, which the forward does not change, so doing it FIRST is the same
         arithmetic as the reference's order (builder.py:75-96) — losses, gradients, momentum weights and
         running statistics are bit-identical (tests/test_gpu_moco.py).  SSL4GIE_MOCO_OVERLAP=0 turns it off.
-        Not across ranks: with SyncBatchNorm two streams would interleave collectives differently on every rank."""
+        Across ranks (round 6): the momentum encoder's SyncBatchNorm layers exchange their statistics on a process
+        group OF THEIR OWN (`_momentum_group`, created collectively at the first forward; the direct exchange gets a
+        handle of its own through it): per communicator the collectives are issued in the same order on every rank
+        — the momentum branch's in layer order, then the base branch's — whatever the two streams do on the device.
+        SSL4GIE_MOCO_OVERLAP_RANKS=0 keeps the rounds 3-5 behaviour (no overlap with world_size > 1)."""
         import os
         import torch.distributed as dist
         if os.environ.get("SSL4GIE_MOCO_OVERLAP", "1") == "0" or not x.is_cuda:
             return False
-        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return True
+        if os.environ.get("SSL4GIE_MOCO_OVERLAP_RANKS", "1") == "0":
+            return False
+        return self._momentum_group() is not None
+
+    def _momentum_group(self):
+        """the communicator of the momentum branch's SyncBatchNorm exchanges (None: a layer already has a group the
+        caller chose — left alone, no overlap).  new_group is collective: every rank gets here in its first forward."""
+        import torch.distributed as dist
+        if getattr(self, "_mom_pg", None) is None:
+            sbn = [m_ for m_ in self.momentum_encoder.modules() if isinstance(m_, nn.SyncBatchNorm)]
+            if any(m_.process_group is not None for m_ in sbn):
+                self._mom_pg = False
+            else:
+                self._mom_pg = dist.new_group() if sbn else True   # (no SyncBatchNorm: nothing to separate)
+                if sbn:
+                    for m_ in sbn:
+                        m_.process_group = self._mom_pg
+        return self._mom_pg or None
 
     def _forward_overlapped(self, x1, x2, m):
         main = torch.cuda.current_stream()

@@ -117,9 +117,16 @@ class ResNet50(EngineModule):
         w, _ = self.lp_cache.get(conv.weight, self.dtype_)
         stats = ops.linear_colstats_only(x2, w)
         mom = bn.momentum if bn.momentum is not None else 0.1
-        coef, _, _ = ops.bn_coef_partials(stats, x2.shape[0], bn.weight.detach() if bn.weight is not None else None,
-                                          bn.bias.detach() if bn.bias is not None else None, bn.running_mean,
-                                          bn.running_var, mom, bn.eps)
+        gd = bn.weight.detach() if bn.weight is not None else None
+        bd = bn.bias.detach() if bn.bias is not None else None
+        sync, group = _sync_group(bn)
+        if sync:   # SyncBatchNorm: the statistics-only product's partials -> exchange -> global coefficients
+            from ..resnet_engine import sync_batch_stats
+            mean_l, var_l = ops.bn_stats_from_partials(stats, x2.shape[0])   # of the product's n_out columns
+            mean, rstd, _ = sync_batch_stats(mean_l, var_l, x2.shape[0], bn, group)
+            coef = ops.bn_coef_stats(mean, rstd, gd, bd)
+        else:
+            coef, _, _ = ops.bn_coef_partials(stats, x2.shape[0], gd, bd, bn.running_mean, bn.running_var, mom, bn.eps)
         if bn.num_batches_tracked is not None:
             _count_batch(bn)
         r2 = res.contiguous().view(-1, n_out) if res is not None else None
@@ -129,7 +136,8 @@ class ResNet50(EngineModule):
         from .. import ops
         if not _BN_RECOMPUTE or torch.is_grad_enabled() or self.dtype_ != torch.bfloat16:
             return False
-        if not (bn.training or bn.running_mean is None) or _sync_group(bn)[0]:
+        from ..resnet_engine import _SYNC_FUSED
+        if not (bn.training or bn.running_mean is None) or (_sync_group(bn)[0] and not _SYNC_FUSED):
             return False
         st = conv.stride[0]
         rows = x.shape[0] * ((x.shape[1] - 1) // st + 1) * ((x.shape[2] - 1) // st + 1)

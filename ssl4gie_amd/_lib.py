@@ -21,7 +21,7 @@ if _dbg == "1" or _dbg.startswith("x"):  # "x<tag>": a tools/build_variant.sh ex
 
 # the one copy of the ABI revision on the Python side: build(), the tests and load() compare the
 # library's ssl4gie_abi_version() with it (include/ssl4gie_hip.h documents the history)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 PROF_KINDS = 7  # SSL4GIE_PROF_KINDS: entries of the launch profiler's arrays
 
@@ -139,6 +139,9 @@ PROTOTYPES = {
     "ssl4gie_bn_bwd_reduce_xmask": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_apply_xmask": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_reduce": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, vp]),
+    "ssl4gie_bn_coef_stats": (i32, [vp, vp, vp, vp, vp, i32, vp]),
+    "ssl4gie_bn_apply_bits": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, vp]),
+    "ssl4gie_bn_bwd_reduce_bits": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
     "ssl4gie_bn_bwd_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, vp, i32, i64, i32, vp]),
     "ssl4gie_ema_update": (i32, [vp, vp, f32, i64, vp]),
     "ssl4gie_maxpool3x3s2_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -132,6 +132,14 @@ DEVI void bl_src(int d, int n_in, int n_out, int& i0, int& i1, float& w1) {
     i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
     w1 = s - (float)i0;
 }
+// one output element from its four taps: rows first, then the vertical lerp (ATen's upsample_bilinear2d order), with
+// the multiply-adds written out — under -ffp-contract=fast the compiler is otherwise free to contract the two
+// forward kernels differently, and they must agree bit for bit
+DEVI float bl_lerp(float f00, float f01, float f10, float f11, float wx, float wy) {
+    const float top = __builtin_fmaf(f01, wx, f00 * (1.f - wx));
+    const float bot = __builtin_fmaf(f11, wx, f10 * (1.f - wx));
+    return __builtin_fmaf(bot, wy, top * (1.f - wy));
+}
 // Grid (x chunks, output / input row, image): the row and the image come from the block index, so a thread's
 // index arithmetic is one 32-bit division (the flat form spent four 64-bit divisions per 16-byte store and ran at
 // half of the HBM rate: profiles/r04dw) and the vertical taps / weights are uniform over the block.
@@ -156,12 +164,7 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(const T* __restrict
     unpack<T>(*(const typename Vec<T>::raw*)(base + ((size_t)y1 * W + x0) * C), f10);
     unpack<T>(*(const typename Vec<T>::raw*)(base + ((size_t)y1 * W + x1) * C), f11);
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-        // same operation order as ATen's upsample_bilinear2d: rows first, then the vertical lerp
-        const float top = f00[j] * (1.f - wx) + f01[j] * wx;
-        const float bot = f10[j] * (1.f - wx) + f11[j] * wx;
-        o[j] = top * (1.f - wy) + bot * wy;
-    }
+    for (int j = 0; j < V; ++j) o[j] = bl_lerp(f00[j], f01[j], f10[j], f11[j], wx, wy);
     *(typename Vec<T>::raw*)(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c) = pack<T>(o);
 }
 // backward in gather form: an input pixel collects from every output pixel whose two taps include it, in the
@@ -260,11 +263,7 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd22_kernel(const T* __restri
         float f00[V], f01[V], f10[V], f11[V], o[V];
         unpack<T>(r00, f00); unpack<T>(r01, f01); unpack<T>(r10, f10); unpack<T>(r11, f11);
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const float top = f00[i] * (1.f - wx) + f01[i] * wx;
-            const float bot = f10[i] * (1.f - wx) + f11[i] * wx;
-            o[i] = top * (1.f - wy) + bot * wy;
-        }
+        for (int i = 0; i < V; ++i) o[i] = bl_lerp(f00[i], f01[i], f10[i], f11[i], wx, wy);
         *(raw*)(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c) = pack<T>(o);
     };
     auto sel = [](bool p, const raw& a, const raw& bb) -> raw {
@@ -292,84 +291,9 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd22_kernel(const T* __restri
     const raw b0b = sel(rb1, lb[1], lb[2]), b1b = sel(rb1, rbv[1], rbv[2]);
     lerp_store(t0b, t1b, b0b, b1b, wxb, wyb, 2 * k + 1, oxb);
 }
-// Backward, 2 x 2 INPUT pixels per thread: rows (2m, 2m + 1) x columns (2n, 2n + 1) collect from the output rows
-// 4m - 3 .. 4m + 5 and columns 4n - 3 .. 4n + 5 (nine candidates each, six of them with a non-zero coefficient in
-// the interior): 36 tap loads per four stores instead of 64.  Per input pixel the contributions are added in the
-// same (output row, output column) order with the same products cy * cx as in bilinear2x_bwd_kernel; a candidate
-// that does not touch the pixel adds a signed zero (finite gradients: bit-identical, tests/test_gpu_dpt.py).
-template <typename T>
-__global__ __launch_bounds__(256) void bilinear2x_bwd22_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H,
-                                                               int W, int C) {
-    constexpr int V = Vec<T>::N;
-    typedef typename Vec<T>::raw raw;
-    const unsigned cpr = (unsigned)(C / V);
-    const int Ho = 2 * H, Wo = 2 * W;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
-    const unsigned un = t / cpr;
-    if (2 * un >= (unsigned)W) return;
-    const int n = (int)un, c = (int)(t - un * cpr) * V;
-    const int m = blockIdx.y, b = blockIdx.z;
-    const int iya = 2 * m, iyb = 2 * m + 1, ixa = 2 * n, ixb = 2 * n + 1;   // iyb / ixb may lie outside (odd sizes)
-    float acc[2][2][V];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[r][q][i] = 0.f;
-    const int oy_lo = 4 * m - 3 > 0 ? 4 * m - 3 : 0, oy_hi = 4 * m + 5 < Ho - 1 ? 4 * m + 5 : Ho - 1;
-    const int ox_lo = 4 * n - 3 > 0 ? 4 * n - 3 : 0, ox_hi = 4 * n + 5 < Wo - 1 ? 4 * n + 5 : Wo - 1;
-    float cxa[9], cxb[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int ox = ox_lo + k;
-        int x0, x1;
-        float wx;
-        bl_src(ox <= ox_hi ? ox : ox_hi, W, Wo, x0, x1, wx);
-        float a = 0.f, bq = 0.f;
-        if (x0 == ixa) a += 1.f - wx;
-        if (x1 == ixa) a += wx;
-        if (x0 == ixb) bq += 1.f - wx;
-        if (x1 == ixb) bq += wx;
-        cxa[k] = ox <= ox_hi ? a : 0.f;
-        cxb[k] = ox <= ox_hi ? bq : 0.f;
-    }
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-        int y0, y1;
-        float wy;
-        bl_src(oy, H, Ho, y0, y1, wy);
-        float cya = 0.f, cyb = 0.f;
-        if (y0 == iya) cya += 1.f - wy;
-        if (y1 == iya) cya += wy;
-        if (y0 == iyb) cyb += 1.f - wy;
-        if (y1 == iyb) cyb += wy;
-        if (cya == 0.f && cyb == 0.f) continue;   // uniform over the block
-        const T* row = dy + (((size_t)b * Ho + oy) * Wo + ox_lo) * C + c;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const float ca = cxa[k], cb = cxb[k];
-            if (ca == 0.f && cb == 0.f) continue;
-            float f[V];
-            unpack<T>(*(const raw*)(row + (size_t)k * C), f);
-            const float waa = cya * ca, wab = cya * cb, wba = cyb * ca, wbb = cyb * cb;
-#pragma unroll
-            for (int i = 0; i < V; ++i) {
-                acc[0][0][i] += waa * f[i];
-                acc[0][1][i] += wab * f[i];
-                acc[1][0][i] += wba * f[i];
-                acc[1][1][i] += wbb * f[i];
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int iy = 2 * m + r, ix = 2 * n + q;
-            if (iy < H && ix < W) *(raw*)(dx + (((size_t)b * H + iy) * W + ix) * C + c) = pack<T>(acc[r][q]);
-        }
-}
-static bool bilinear22() {  // SSL4GIE_BILINEAR22=0: one output (input) pixel per thread again (A/B; same bits)
+// (The matching backward — 2 x 2 input pixels per thread, 36 taps instead of 64 — measured slower and is not built:
+// tools/experiments/bilinear_bwd22_kernel.hip.txt, profiles/r06d_bilinear_ab.log.)
+static bool bilinear22() {  // SSL4GIE_BILINEAR22=0: one output pixel per thread in the forward again (A/B; same bits)
     static int on = -1;
     if (on < 0) { const char* e = getenv("SSL4GIE_BILINEAR22"); on = (e && e[0] == '0') ? 0 : 1; }
     return on != 0;
@@ -606,16 +530,6 @@ extern "C" int ssl4gie_bilinear2x_bwd(const void* dy, void* dx, int dtype, int B
     REQUIRE(dy && dx && dt_ok(dtype) && B > 0 && H > 0 && W > 0 && C > 0 && C % vecn(dtype) == 0);
     hipStream_t st = (hipStream_t)stream;
     REQUIRE(H <= 65535 && B <= 65535);
-    if (bilinear22()) {
-        const unsigned per = (unsigned)((W + 1) / 2) * (unsigned)(C / vecn(dtype));
-        const dim3 grid((per + 255) / 256, (H + 1) / 2, B), block(256);
-        if (dtype == SSL4GIE_BF16)
-            hipLaunchKernelGGL(bilinear2x_bwd22_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy, (bf16_t*)dx, H, W, C);
-        else
-            hipLaunchKernelGGL(bilinear2x_bwd22_kernel<float>, grid, block, 0, st, (const float*)dy, (float*)dx, H, W, C);
-        LAUNCH_CHECK();
-        return 0;
-    }
     const unsigned per_row = (unsigned)W * (unsigned)(C / vecn(dtype));
     const dim3 grid((per_row + 255) / 256, H, B), block(256);
     if (dtype == SSL4GIE_BF16)

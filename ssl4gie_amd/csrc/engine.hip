@@ -20,7 +20,7 @@
 #include "prof.h"
 #include "internal.h"
 
-extern "C" int ssl4gie_abi_version(void) { return 6; }
+extern "C" int ssl4gie_abi_version(void) { return 7; }
 
 namespace { extern int g_wgrad_stream; }
 // 1: block weight gradients on the library's side stream (default), 0: everything on the caller's
@@ -109,7 +109,7 @@ SideStream* side_stream() {
     if (!ss->s) {
         hipStream_t st = nullptr;
         // SSL4GIE_WGRAD_PRIO=high|low: scheduling priority of the weight-gradient stream against the caller's
-        // (default: the same).  Measured on the MAE step (profiles/r04bs): see DESIGN.md section 5.
+        // (default: the same).  Measured on the MAE step (profiles/r04bs): see profiles/HISTORY.md section 5.
         const char* pe = getenv("SSL4GIE_WGRAD_PRIO");
         int least = 0, greatest = 0;
         if (pe && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
@@ -124,8 +124,11 @@ SideStream* side_stream() {
                 return nullptr;
             }
         }
-        static int two = -1;
-        if (two < 0) { const char* e = getenv("SSL4GIE_WGRAD_STREAMS"); two = (e && e[0] == '2') ? 1 : 0; }
+        // (measured null, profiles/HISTORY.md: the second stream exists in the debug library only — ADVICE r5)
+        int two = 0;
+#ifdef SSL4GIE_DEBUG_KNOBS
+        { const char* e = getenv("SSL4GIE_WGRAD_STREAMS"); two = (e && e[0] == '2') ? 1 : 0; }
+#endif
         if (two) {
             hipStream_t st2 = nullptr;
             if (hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) == hipSuccess) {
@@ -192,7 +195,11 @@ BwdLayout bwd_layout(const ssl4gie_block_dims* d) {
     }
     L.gemm_ws_bytes = g;
     L.gemm_ws = o; o += align_up(g);
-    L.gemm_ws2 = o; o += align_up(g);  // the (proj, qkv) pair's own slabs: it may run beside the (fc2, fc1) pair
+#ifdef SSL4GIE_DEBUG_KNOBS
+    L.gemm_ws2 = o; o += align_up(g);  // the (proj, qkv) pair's own slabs: it may run beside the (fc2, fc1) pair (SSL4GIE_WGRAD_STREAMS=2)
+#else
+    L.gemm_ws2 = L.gemm_ws;  // one weight-gradient stream: the two pairs run in order and share the slabs
+#endif
     L.attn_ws = o; o += align_up(ssl4gie_attn_workspace_bytes(d->dtype, d->B, d->N, d->H, d->D / d->H));
     L.total = o;
     return L;

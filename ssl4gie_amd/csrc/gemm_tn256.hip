@@ -826,7 +826,13 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, 
     // plain operands, no skipped fragment blocks: the k-split kernel (SSL4GIE_TN256K=0: the column-split one; the
     // results are bit-identical, the knob exists for A/B timing)
     static int ksplit = -1;
-    if (ksplit < 0) { const char* s = getenv("SSL4GIE_TN256K"); ksplit = !s ? 1 : (s[0] == '0' ? 0 : (s[0] == '5' ? 5 : 1)); }
+    if (ksplit < 0) {  // SSL4GIE_TN256K=0: the column-split kernel of rounds 1-4 (A/B); =5 (debug library only): a five-stage ring, measured null
+        const char* s = getenv("SSL4GIE_TN256K");
+        ksplit = !s ? 1 : (s[0] == '0' ? 0 : 1);
+#ifdef SSL4GIE_DEBUG_KNOBS
+        if (s && s[0] == '5') ksplit = 5;
+#endif
+    }
     if (ksplit && cv == 0 && !partial) {
 #define K_LAUNCH(CS_, RING_)                                                                          \
     do {                                                                                           \
@@ -847,8 +853,11 @@ static int tn256_launch_impl(const ssl4gie_gemm_desc* descs, int n, int splits, 
         // (pair launches 589 vs 586-591 us, MAE step 22.08 vs 22.09-22.13 ms same-box: profiles/r05j): the
         // stream's cost is not latency a deeper ring would cover (an L2-RESIDENT stream makes the kernel 14 % faster,
         // profiles/r05b, so it is the L2 -> LDS path under load)
+#ifdef SSL4GIE_DEBUG_KNOBS
         if (ksplit == 5) { if (any_colsum) K_LAUNCH(true, 5); else K_LAUNCH(false, 5); }
-        else { if (any_colsum) K_LAUNCH(true, 4); else K_LAUNCH(false, 4); }
+        else
+#endif
+        { if (any_colsum) K_LAUNCH(true, 4); else K_LAUNCH(false, 4); }
 #undef K_LAUNCH
         LAUNCH_CHECK();
         return 0;

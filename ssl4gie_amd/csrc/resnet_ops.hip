@@ -1200,6 +1200,51 @@ extern "C" int ssl4gie_bn_bwd_apply(const void* dy, const void* y, const void* x
     return 0;
 }
 
+// ---- SyncBatchNorm with the single-process fusions (round 6) ----------------------------------------------------
+// With world_size > 1 the statistics cross an exchange between the producing GEMM's partials and the apply, so the
+// fused forms take the GLOBAL (mean, rstd) the exchange returned instead of computing their own:
+//   ssl4gie_bn_coef_stats      (mean, rstd, gamma, beta) -> coef [2][C] for a consumer that applies it itself: the
+//                              bn1 -> relu -> maxpool pass of the stem (ssl4gie_bn_maxpool3x3s2_fwd) and the
+//                              SSL4GIE_EPI_AFFINE_AUX_RELU epilogue of the momentum encoder's widening 1x1 products;
+//   ssl4gie_bn_apply_bits      y = relu(x coef[0] + coef[1] (+ res)) and the ReLU bit map of ssl4gie_bn_fwd_partials_bits;
+//   ssl4gie_bn_bwd_reduce_bits the first backward half of ssl4gie_bn_bwd_reduce with the mask from that bit map
+//                              (dres = the masked gradient; the second half is ssl4gie_bn_bwd_apply on dres, relu 0).
+// Reference: torch.nn.SyncBatchNorm via convert_sync_batchnorm, Models/moco_v3/main_moco.py:196,
+// Depth_estimation/train_depth.py:225.
+extern "C" int ssl4gie_bn_coef_stats(const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     float* coef, int C, void* stream) {
+    REQUIRE(mean && rstd && coef && C > 0);
+    hipLaunchKernelGGL(bn_fwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, rstd,
+                       gamma, beta, coef, C);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ssl4gie_bn_apply_bits(const void* x, const float* coef, const void* res, void* y,
+                                     unsigned char* relu_bits, int dtype, long long rows, int C, void* stream) {
+    REQUIRE(x && coef && y && relu_bits && dtype == SSL4GIE_BF16 && rows > 0 && C > 0 && C % 8 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(PROF_BN, (double)rows * C * 2 * (2 + (res ? 1 : 0)), st);
+    const long long total = rows * C;
+    RN_LAUNCH(dtype, bn_apply_kernel, total / rvn(dtype), (const T*)x, coef, (const T*)res, (T*)y, 1, C, total,
+              relu_bits);
+    return 0;
+}
+extern "C" int ssl4gie_bn_bwd_reduce_bits(const void* dy, const unsigned char* relu_bits, const void* x,
+                                          const float* mean, const float* rstd, void* dres, float* sums,
+                                          float* workspace, int dtype, long long rows, int C, void* stream) {
+    REQUIRE(dy && relu_bits && x && mean && rstd && dres && sums && workspace && dtype == SSL4GIE_BF16 && rows > 0 &&
+            C > 0 && C % 8 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = bn_parts(rows, C);
+    dim3 grid(bn_strips(C, dtype), parts), block(256);
+    float* partial = workspace + 3 * (size_t)C;
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 2>), grid, block, 0, st, (const bf16_t*)dy,
+                       (const bf16_t*)relu_bits, (const bf16_t*)x, mean, rstd, (bf16_t*)dres, partial, 1, rows, C,
+                       (const float*)nullptr, (const float*)nullptr);
+    LAUNCH_CHECK();
+    return ssl4gie_internal_reduce_partials(partial, sums, parts, 2 * C, (size_t)2 * C, 0, st);
+}
+
 // ---- SyncBatchNorm: pooled statistics out of the gathered per-rank records ----------------------------
 // gathered [W][2C + 1] = (mean_w[C], biased var_w[C], rows_w) of every rank (ranks may hold different
 // row counts): total = sum rows_w, mean = sum rows_w/total mean_w, var = sum rows_w/total (var_w +

@@ -1127,6 +1127,21 @@ def bn_stats(x2d, partials=None):
     return mean, var
 
 
+def bn_stats_from_partials(partials, rows):
+    """local (mean, biased variance) of a map known only through its producer's partials [parts, 2, C] (the
+    statistics-only product of linear_colstats_only: the map itself is never written)"""
+    _dev(partials)
+    C = partials.shape[2]
+    assert partials.dtype == torch.float32 and partials.shape[1] == 2 and partials.is_contiguous()
+    L = _lib.load()
+    mean = torch.empty(C, dtype=torch.float32, device=partials.device)
+    var = torch.empty(C, dtype=torch.float32, device=partials.device)
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=partials.device)
+    _lib.check(L.ssl4gie_bn_stats_partials(ptr(partials), partials.shape[0], ptr(mean), ptr(var), ptr(ws), rows, C,
+                                           stream()), "bn_stats_partials")
+    return mean, var
+
+
 def bn_bwd_reduce(dy2d, y2d, x2d, mean, rstd, relu, want_dres):
     _dev(dy2d, y2d, x2d, mean, rstd)
     rows, C = x2d.shape
@@ -1137,6 +1152,45 @@ def bn_bwd_reduce(dy2d, y2d, x2d, mean, rstd, relu, want_dres):
     _lib.check(L.ssl4gie_bn_bwd_reduce(ptr(dy2d), ptr(y2d), ptr(x2d), ptr(mean), ptr(rstd), ptr(dres),
                                        ptr(sums), int(relu), ptr(ws), code(x2d.dtype), rows, C,
                                        stream()), "bn_bwd_reduce")
+    return sums, dres
+
+
+def bn_coef_stats(mean, rstd, gamma, beta):
+    """coef [2, C] (y = x coef[0] + coef[1]) of a BatchNorm whose statistics are given — the GLOBAL ones a
+    SyncBatchNorm exchange returned (ssl4gie_bn_coef_stats)"""
+    _dev(mean, rstd, gamma, beta)
+    C = mean.numel()
+    coef = torch.empty(2, C, dtype=torch.float32, device=mean.device)
+    _lib.check(_lib.load().ssl4gie_bn_coef_stats(ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(coef), C, stream()),
+               "bn_coef_stats")
+    return coef
+
+
+def bn_apply_bits(x2d, coef, res):
+    """relu(x coef[0] + coef[1] (+ res)) + the ReLU bit map (bf16): the apply half of bn_fwd_bits with given
+    coefficients (ssl4gie_bn_apply_bits) -> (y, bits)"""
+    _dev(x2d, coef, res)
+    rows, C = x2d.shape
+    assert x2d.dtype == torch.bfloat16 and coef.shape == (2, C) and coef.is_contiguous()
+    y = torch.empty_like(x2d)
+    bits = torch.empty(rows * C // 8, dtype=torch.uint8, device=x2d.device)
+    _lib.check(_lib.load().ssl4gie_bn_apply_bits(ptr(x2d), ptr(coef), ptr(res), ptr(y), ptr(bits), code(x2d.dtype),
+                                                 rows, C, stream()), "bn_apply_bits")
+    return y, bits
+
+
+def bn_bwd_reduce_bits(dy2d, bits, x2d, mean, rstd):
+    """SyncBatchNorm + residual + ReLU backward, first half with the mask from the forward's bit map:
+    -> (LOCAL sums [2, C], dres = the masked gradient) (ssl4gie_bn_bwd_reduce_bits)"""
+    _dev(dy2d, bits, x2d, mean, rstd)
+    rows, C = x2d.shape
+    assert bits.dtype == torch.uint8 and bits.numel() == rows * C // 8
+    L = _lib.load()
+    sums = torch.empty(2, C, dtype=torch.float32, device=x2d.device)
+    dres = torch.empty_like(x2d)
+    ws = torch.empty(L.ssl4gie_bn_workspace_bytes(rows, C), dtype=torch.uint8, device=x2d.device)
+    _lib.check(L.ssl4gie_bn_bwd_reduce_bits(ptr(dy2d), ptr(bits), ptr(x2d), ptr(mean), ptr(rstd), ptr(dres), ptr(sums),
+                                            ptr(ws), code(x2d.dtype), rows, C, stream()), "bn_bwd_reduce_bits")
     return sums, dres
 
 

@@ -259,6 +259,10 @@ def flush_batch_counts(model):
             _flush_one(m)
 
 
+# SSL4GIE_SYNCBN_FUSED=0: under SyncBatchNorm (world_size > 1) the bit-map backward, the stem's bn -> relu -> maxpool
+# pass and the momentum encoder's statistics-only + affine-epilogue products fall back to the separate passes
+# (rounds 4-5 behaviour: A/B of what BASELINE config 3 costs in its multi-rank form)
+_SYNC_FUSED = __import__("os").environ.get("SSL4GIE_SYNCBN_FUSED", "1") != "0"
 # SSL4GIE_BN_BITS=0: BatchNorm + residual + ReLU backward reads the ReLU output for its mask again (A/B)
 _BN_BITS = __import__("os").environ.get("SSL4GIE_BN_BITS", "1") != "0"
 # SSL4GIE_BN_XMASK=0: read the ReLU output for the mask of residual-free BatchNorm + ReLU layers again (A/B)
@@ -310,7 +314,13 @@ class BatchNormFn(torch.autograd.Function):
         elif training:
             mean_l, var_l = ops.bn_stats(x2, partials=stats)
             mean, rstd, total = sync_batch_stats(mean_l, var_l, x2.shape[0], bn, group)
-            y, _, _ = ops.bn_fwd(x2, g, b, r2, None, None, 0.0, bn.eps, relu, False, mean, rstd)
+            if _BN_BITS and _SYNC_FUSED and relu and r2 is not None and x2.dtype == torch.bfloat16 \
+                    and any(ctx.needs_input_grad):
+                # bn3 of a bottleneck under SyncBatchNorm: the same bit-map form as on one rank, fed with the
+                # GLOBAL statistics the exchange returned (round 6)
+                y, bits = ops.bn_apply_bits(x2, ops.bn_coef_stats(mean, rstd, g, b), r2)
+            else:
+                y, _, _ = ops.bn_fwd(x2, g, b, r2, None, None, 0.0, bn.eps, relu, False, mean, rstd)
         else:
             mean = bn.running_mean
             rstd = torch.rsqrt(bn.running_var + bn.eps)  # [C] floats: host-side plumbing
@@ -358,6 +368,8 @@ class BatchNormFn(torch.autograd.Function):
             bd = beta.detach() if beta is not None else None
             if xm:
                 sums, dres = ops.bn_bwd_reduce_xmask(dy2, x2, gd, bd, mean, rstd), None
+            elif relu and has_res and y is not None and y.dtype == torch.uint8:   # `y` holds the forward's bit map
+                sums, dres = ops.bn_bwd_reduce_bits(dy2, y, x2, mean, rstd)
             else:
                 sums, dres = ops.bn_bwd_reduce(dy2, y, x2, mean, rstd, relu, has_res)
             for tgt, row in ((tb, 0), (tg, 1)):  # parameter gradients are the LOCAL sums
@@ -406,14 +418,22 @@ class BnReluMaxPoolFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, bn, sink: GradSink, stats):
         B, H, W, C = x.shape
         mom = bn.momentum if bn.momentum is not None else 0.1
-        coef, mean, rstd = ops.bn_coef_partials(stats, B * H * W, gamma.detach() if gamma is not None else None,
-                                                beta.detach() if beta is not None else None, bn.running_mean,
-                                                bn.running_var, mom, bn.eps)
+        gd = gamma.detach() if gamma is not None else None
+        bd = beta.detach() if beta is not None else None
+        sync, group = _sync_group(bn)
+        total = None
+        if sync:   # SyncBatchNorm: local statistics from the partials -> exchange -> coefficients of the GLOBAL ones
+            mean_l, var_l = ops.bn_stats(x.view(-1, C), partials=stats)
+            mean, rstd, total = sync_batch_stats(mean_l, var_l, B * H * W, bn, group)
+            coef = ops.bn_coef_stats(mean, rstd, gd, bd)
+        else:
+            coef, mean, rstd = ops.bn_coef_partials(stats, B * H * W, gd, bd, bn.running_mean, bn.running_var, mom, bn.eps)
         if bn.num_batches_tracked is not None:
             _count_batch(bn)
         y, arg = ops.maxpool3x3s2_fwd(x.contiguous(), coef, True)
         ctx.save_for_backward(x, gamma, beta, mean, rstd, arg)
         ctx.sink = sink
+        ctx.sync = (sync, group, total)
         ctx.wepoch = weights_epoch()   # the backward rebuilds the ReLU mask from gamma / beta (see BatchNormFn)
         return y
 
@@ -426,16 +446,31 @@ class BnReluMaxPoolFn(torch.autograd.Function):
         B, H, W, C = x.shape
         dz = ops.maxpool3x3s2_bwd(dy.contiguous(), arg, H, W)
         (tg, tb), acc, rets = ctx.sink.plan([gamma, beta])
-        dx = ops.bn_bwd_xmask(dz.view(-1, C), x.contiguous().view(-1, C), gamma.detach() if gamma is not None else None,
-                              beta.detach() if beta is not None else None, mean, rstd, tg, tb, acc)
+        gd = gamma.detach() if gamma is not None else None
+        bd = beta.detach() if beta is not None else None
+        sync, group, total = ctx.sync
+        if not sync:
+            dx = ops.bn_bwd_xmask(dz.view(-1, C), x.contiguous().view(-1, C), gd, bd, mean, rstd, tg, tb, acc)
+            return dx.view(B, H, W, C), rets[0], rets[1], None, None, None
+        dz2, x2 = dz.view(-1, C), x.contiguous().view(-1, C)
+        sums = ops.bn_bwd_reduce_xmask(dz2, x2, gd, bd, mean, rstd)
+        for tgt, row in ((tb, 0), (tg, 1)):  # parameter gradients are the LOCAL sums (DDP averages them)
+            if tgt is not None:
+                if acc:
+                    tgt.add_(sums[row])
+                else:
+                    tgt.copy_(sums[row])
+        gsums = sync_sum(sums, group)
+        gsums /= total
+        dx = ops.bn_bwd_apply_xmask(dz2, x2, gd, bd, mean, rstd, gsums, 1.0)
         return dx.view(B, H, W, C), rets[0], rets[1], None, None, None
 
 
 def bn_relu_maxpool_ok(x, bn, stats):
-    """whether BnReluMaxPoolFn applies: training-mode statistics from the convolution's partials, one process
-    (SyncBatchNorm exchanges between the statistics and the apply), vector-width channels"""
+    """whether BnReluMaxPoolFn applies: training-mode statistics from the convolution's partials (under
+    SyncBatchNorm: local partials -> exchange -> coefficients of the global statistics), vector-width channels"""
     return (_STEM_POOL_FUSED and stats is not None and (bn.training or bn.running_mean is None)
-            and not _sync_group(bn)[0] and x.shape[-1] % (8 if x.dtype == torch.bfloat16 else 4) == 0)
+            and (_SYNC_FUSED or not _sync_group(bn)[0]) and x.shape[-1] % (8 if x.dtype == torch.bfloat16 else 4) == 0)
 
 
 # SSL4GIE_STEM_POOL_FUSED=0: bn1 / relu / maxpool of the ResNet stem as separate passes again (A/B)

@@ -266,7 +266,7 @@ def test_vit_from_mae_depth_end_to_end_vs_oracle():
 
 
 def test_bilinear2x_two_by_two_kernels_equal_the_one_pixel_kernels_bit_for_bit(tmp_path):
-    """the round-6 bilinear kernels (2 x 2 outputs / inputs per thread, 9 resp. 36 taps instead of 16 / 64) against
+    """the round-6 bilinear forward (2 x 2 outputs per thread, 9 taps instead of 16; the backward keeps one pixel per thread) against
     the one-pixel-per-thread kernels they replace (SSL4GIE_BILINEAR22=0, read once per process: a child process
     computes the reference) — identical bits, forward and backward, fp32 and bf16, odd sizes and the 1 x 1 map"""
     import subprocess
