@@ -135,10 +135,12 @@ DEVI void bl_src(int d, int n_in, int n_out, int& i0, int& i1, float& w1) {
 // one output element from its four taps: rows first, then the vertical lerp (ATen's upsample_bilinear2d order), with
 // the multiply-adds written out — under -ffp-contract=fast the compiler is otherwise free to contract the two
 // forward kernels differently, and they must agree bit for bit
+// (the form is the one the compiler had chosen for the round 1-5 kernel — product of the second tap, multiply-add of
+// the first — so that the committed 60-step fp32 depth curve, G13, keeps its rounding)
 DEVI float bl_lerp(float f00, float f01, float f10, float f11, float wx, float wy) {
-    const float top = __builtin_fmaf(f01, wx, f00 * (1.f - wx));
-    const float bot = __builtin_fmaf(f11, wx, f10 * (1.f - wx));
-    return __builtin_fmaf(bot, wy, top * (1.f - wy));
+    const float top = __builtin_fmaf(1.f - wx, f00, f01 * wx);
+    const float bot = __builtin_fmaf(1.f - wx, f10, f11 * wx);
+    return __builtin_fmaf(1.f - wy, top, bot * wy);
 }
 // Grid (x chunks, output / input row, image): the row and the image come from the block index, so a thread's
 // index arithmetic is one 32-bit division (the flat form spent four 64-bit divisions per 16-byte store and ran at

@@ -168,13 +168,14 @@ def combine_batch_stats(mean_l, var_l, count_l, group=None):
 
 def sync_batch_stats(mean_l, var_l, rows, bn, group=None):
     """SyncBatchNorm's forward exchange -> (mean, rstd, total rows as a 0-d device tensor), running
-    statistics updated.  Default: one torch.distributed all_gather + the pooled combine in torch.  With
-    SSL4GIE_SYNCBN=direct on the GPU: the record goes through the library's peer-to-peer all-gather (three
-    tiny launches, no RCCL call) and ONE kernel does the pooled combine, rstd and the running statistics."""
+    statistics updated.  On the GPU the pooled combine, rstd and the running statistics are ONE kernel
+    (ssl4gie_bn_combine_stats) behind the all-gather of the (mean, var, count) records — torch.distributed's
+    all_gather_into_tensor (RCCL) by default, the library's peer-to-peer all-gather with SSL4GIE_SYNCBN=direct /
+    auto; round 6: the torch.distributed path no longer runs its ~20 element-wise torch kernels per layer.
+    CPU tensors (gloo tests) take the torch formulation of the same arithmetic."""
     from . import parallel
-    ex = parallel.syncbn_exchange(group) if mean_l.is_cuda else None
     mom = bn.momentum if bn.momentum is not None else 0.1
-    if ex is None:
+    if not mean_l.is_cuda:
         mean, var, total = combine_batch_stats(mean_l, var_l, rows, group)
         rstd = torch.rsqrt(var + bn.eps)
         if bn.running_mean is not None:
@@ -182,20 +183,27 @@ def sync_batch_stats(mean_l, var_l, rows, bn, group=None):
                 bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
                 bn.running_var.mul_(1 - mom).add_(var * (total / (total - 1.0).clamp_(min=1.0)), alpha=mom)
         return mean, rstd, total
+    import torch.distributed as dist
     from . import _lib
+    ex = parallel.syncbn_exchange(group)
+    world = ex.world if ex is not None else dist.get_world_size(group)
     C = mean_l.numel()
     rec = torch.empty(2 * C + 1, dtype=torch.float32, device=mean_l.device)
     rec[:C] = mean_l
     rec[C:2 * C] = var_l
     rec[2 * C] = float(rows)
-    gathered = torch.empty(ex.world * (2 * C + 1), dtype=torch.float32, device=mean_l.device)
-    ex.all_gather_(rec, gathered)
-    SYNC_BN_DIRECT[0] += 1
+    gathered = torch.empty(world * (2 * C + 1), dtype=torch.float32, device=mean_l.device)
+    if ex is None:
+        dist.all_gather_into_tensor(gathered, rec, group=group)
+        SYNC_BN_COLLECTIVES[0] += 1
+    else:
+        ex.all_gather_(rec, gathered)
+        SYNC_BN_DIRECT[0] += 1
     out = torch.empty(2 * C + 1, dtype=torch.float32, device=mean_l.device)
     mean, rstd, total = out[:C], out[C:2 * C], out[2 * C]
     rm = bn.running_mean if bn.running_mean is not None else None
     _lib.check(_lib.load().ssl4gie_bn_combine_stats(
-        gathered.data_ptr(), ex.world, C, float(bn.eps), float(mom), ops.ptr(rm),
+        gathered.data_ptr(), world, C, float(bn.eps), float(mom), ops.ptr(rm),
         ops.ptr(bn.running_var if rm is not None else None), mean.data_ptr(), rstd.data_ptr(), total.data_ptr(),
         ops.stream()), "bn_combine_stats")
     return mean, rstd, total

@@ -187,7 +187,10 @@ def test_dpt_decoder_matches_reference_golden(prec, tol, gtol):
         if prec == "fp32" and key in g.files:
             assert rel_err(p.grad, g[key]) < 2e-3, str(name)
     for i in range(4):
-        assert rel_err(acts[i].grad[:, :4, :64], g[f"act_grad_slice/{i}"]) < (2e-3 if prec == "fp32" else 0.2)
+        # bf16: the SSI loss's L1 gradient-matching term makes dL/dpred ill-conditioned under ANY half-precision
+        # rounding of the prediction — the reference's own bf16-autocast gradients are 0.19 (median) to 0.22 (worst
+        # tensor) off its fp64 gradients on this model (G17, tests/golden/make_golden.py g17_bf16_bars): 1.5 x that
+        assert rel_err(acts[i].grad[:, :4, :64], g[f"act_grad_slice/{i}"]) < (2e-3 if prec == "fp32" else 0.33)
         assert torch.count_nonzero(acts[i].grad[:, 0]) == 0  # the cls row is sliced away
 
 
