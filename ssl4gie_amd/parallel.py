@@ -614,7 +614,12 @@ def probe_transports(process_group, device, make_direct, n_elems: int = 16 << 20
         import os
         direct.set_timeout(float(os.environ.get("SSL4GIE_AR_TIMEOUT_S", "600")))
     fin = lambda v: None if v is None or v != v or v == float("inf") else round(v, 3)
-    report = {"rccl_ms": fin(max(r["ref_ms"] for r in recs)),
+    try:
+        ref_backend = str(dist.get_backend(process_group))
+    except Exception:  # noqa: BLE001
+        ref_backend = "unknown"
+    report = {"rccl_ms": fin(max(r["ref_ms"] for r in recs)),   # the torch.distributed transport (RCCL = "nccl"; gloo in rehearsals)
+              "reference_backend": ref_backend,
               "direct_ms": fin(max(r["direct_ms"] for r in recs)),
               "mib": round(4 * n_elems / 2 ** 20, 1), "chosen": chosen, "reason": reason}
     return direct, report
