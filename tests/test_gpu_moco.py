@@ -2,6 +2,7 @@
 (G8), the momentum update, and a whole MoCo_ResNet step against the CPU oracle composition."""
 from functools import partial
 
+import numpy as np
 import pytest
 import torch
 
@@ -237,3 +238,78 @@ def test_momentum_branch_on_a_side_stream_vit(monkeypatch):
         assert len(a[part]) == len(b[part]) and len(a[part]) > 10
         for x, y in zip(a[part], b[part]):
             assert torch.equal(x, y)
+
+
+def _moco_2rank_worker(rank, world, port, q):
+    """MoCo_ResNet under SyncBatchNorm + DataParallel on two processes sharing the device: three LARS steps with the
+    momentum branch beside the base branch ACROSS RANKS (its SyncBatchNorm layers on a process group of their own)
+    and without — same kernels, same operands, same exchange order per communicator: identical bits"""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SSL4GIE_COMM_CUS="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    out = {}
+    try:
+        from ssl4gie_amd.Models.moco_v3.moco.optimizer import LARS
+        from ssl4gie_amd.parallel import DataParallel
+        g = torch.Generator().manual_seed(50 + rank)
+        x1 = torch.randn(16, 3, 64, 64, generator=g).cuda()
+        x2 = torch.randn(16, 3, 64, 64, generator=g).cuda()
+
+        def run(overlap):
+            os.environ["SSL4GIE_MOCO_OVERLAP_RANKS"] = "1" if overlap else "0"
+            torch.manual_seed(0)
+            m = _moco()
+            with torch.no_grad():
+                for name, p in m.named_parameters():
+                    if name.endswith("bn3.weight"):
+                        p.fill_(0.5)
+            m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+            m.cuda().set_precision("bf16")
+            ddp = DataParallel(m, device_ids=[0])
+            opt = LARS([p for p in m.parameters() if p.requires_grad], lr=0.05, weight_decay=1e-6, momentum=0.9)
+            losses = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                loss = ddp(x1, x2, 0.99)
+                loss.backward()
+                opt.step()
+                torch.cuda.synchronize()
+                losses.append(float(loss.detach()))
+            took = getattr(m, "_mom_pg", None) not in (None, False) and overlap
+            vals = [p.detach().float().cpu().clone() for p in m.parameters()] + \
+                   [b.detach().float().cpu().clone() for n, b in m.named_buffers() if "running" in n]
+            return losses, vals, took
+
+        la, va, _ = run(False)
+        lb, vb, took = run(True)
+        out["overlap_taken"] = bool(took)
+        out["losses"] = (la, lb)
+        out["equal"] = la == lb and all(torch.equal(a, b) for a, b in zip(va, vb))
+        out["finite"] = all(np.isfinite(la))
+    except Exception:  # noqa: BLE001
+        import traceback
+        out["error"] = traceback.format_exc()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_momentum_branch_overlaps_across_ranks_with_its_own_process_group():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_moco_2rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert "error" not in res[r], res[r]["error"]
+        assert res[r]["overlap_taken"] and res[r]["finite"], res[r]
+        assert res[r]["equal"], res[r]["losses"]
