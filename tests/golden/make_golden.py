@@ -35,6 +35,8 @@ Fixtures written:
                       128 x 128 views, B = 16, 1-process gloo (BASELINE.json configs[2])
   g16_frozen.npz      frozen=True (linear probe / frozen finetune, models.py:138-142,341-345,459-463): ViT_from_MAE head,
                       ViT_from_MAE + DPT depth, ResNet_from_Any head — outputs, head / decoder gradients, no trunk gradients
+  g18_eval_mode.npz   model.eval() inference (eval_*.py / predict_*.py): BatchNorm with running statistics after two
+                      training-mode forwards — ResNet_from_Any dense + classifier, ViT_from_MAE(dense="seg")
   g17_bf16_bars.npz   per-tensor error of the reference's own bf16-autocast gradients against its fp64 gradients (G11
                       depth model, G10 det trunk): the bar the bf16 engine's whole-model gradients are held to
   g14_moco_fp64.npz   the same reference classes converted to double: 10-step loss curve, step-0 gradients and the
@@ -985,6 +987,54 @@ def g17_bf16_bars():
     print("g17 ok")
 
 
+def g18_eval_mode():
+    """Inference as the reference's eval_*.py / predict_*.py run it: `model.eval()` under `torch.no_grad()` — BatchNorm
+    with RUNNING statistics, Dropout off.  The keyed weights start from running_mean = 0 / running_var = 1, so two
+    training-mode forwards move the running statistics first (momentum 0.1), then the evaluation batch goes through
+    in eval mode: ResNet_from_Any dense + classifier (models.py:106-152), ViT_from_MAE(dense="seg") with the DPT seg
+    head's BatchNorm fusion blocks (DPT_decoder.py:461,483-497)."""
+    rm = import_reference_models()
+    out = {}
+    gen = torch.Generator("cpu").manual_seed(81)
+    xt = [torch.randn(4, 3, 128, 128, generator=gen) for _ in range(2)]
+    xe = torch.randn(4, 3, 128, 128, generator=gen)
+    for tag, build, seed in (("resnet_dense", lambda: rm.ResNet_from_Any(None, False, 1, False, "depth"), 82),
+                             ("resnet_cls", lambda: rm.ResNet_from_Any(None, True, 6, False, None), 83)):
+        m = build()
+        shapes, digest = load_keyed(m, seed=seed)
+        out[f"{tag}/keys"] = np.array(sorted(shapes)); out[f"{tag}/digest"] = np.array(digest)
+        m.train()
+        with torch.no_grad():
+            for x in xt:
+                m(x)
+        m.eval()
+        with torch.no_grad():
+            y = m(xe)
+        out[f"{tag}/out"] = y.numpy()
+        out[f"{tag}/running_var/layer3.5.bn2"] = m.layer3[5].bn2.running_var.numpy().copy()
+        print(f"g18 {tag}: |out| {float(y.double().norm()):.5f}")
+    cfg = mae_ref.VIT_B
+    imgs_t = [synth.synth_images(2, cfg, seed=84 + i) for i in range(2)]
+    imgs_e = synth.synth_images(2, cfg, seed=86)
+    m = rm.ViT_from_MAE(None, False, 1, False, "seg", False, None, 768, 12, 12, "cls")
+    shapes, digest = load_keyed(m, seed=87, keep=("pos_embed", "decoder_pos_embed"))
+    out["mae_seg/keys"] = np.array(sorted(shapes)); out["mae_seg/digest"] = np.array(digest)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0   # the two warm-up forwards must be reproducible on the other side
+    with torch.no_grad():
+        for x in imgs_t:
+            m(x)
+    m.eval()
+    with torch.no_grad():
+        y = m(imgs_e)
+    out["mae_seg/out_sub"] = y[:, :, ::2, ::2].numpy().copy()
+    out["mae_seg/out_norm"] = np.array(float(y.double().norm()))
+    np.savez_compressed(os.path.join(HERE, "g18_eval_mode.npz"), **out)
+    print(f"g18 ok: seg |out| {float(out['mae_seg/out_norm']):.5f}")
+
+
 def g15_det_curve(steps=30):
     """the reference's own VisionTransformer_from_Any(det=True) trunk (models.py:155-210 windowed
     blocks, :310-338) at 512 x 512 (1024 tokens, four 256-token windows), B = 1, trained for 30 steps: tokens
@@ -1027,7 +1077,7 @@ def main():
         "lr": g_lr_sched, "g6": g6_dpt, "g7": g7_ssi, "g8": g8_moco, "g9": g9_dpt_seg,
         "g3b": g3b_moco_sincos, "g10": g10_det, "g11": g11_vit_api, "g12": g12_resnet_dec,
         "g13": g13_depth_curve, "g14": g14_moco_curve, "g14fp64": g14_moco_fp64, "g15": g15_det_curve,
-        "g16": g16_frozen, "g17": g17_bf16_bars,
+        "g16": g16_frozen, "g17": g17_bf16_bars, "g18": g18_eval_mode,
         "curve_tiny": lambda: curve(ref_mae, mae_ref.MAEConfig(
             **{**mae_ref.TINY.__dict__, "norm_pix_loss": True}), 8, 100, 1.5e-4,
             "g5_curve_tiny.npz"),
